@@ -1,0 +1,331 @@
+"""Pins oracle/wtpse_cpu.py (the CPU restatement) against fixtures produced by the reference itself
+(oracle/make_golden.py).  CPU-only; runs in the `-m "not gpu"` suite."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import wtpse_cpu as O
+from oracle.filler import filled_state
+from oracle.inputs import make_inputs, make_noise, make_feature
+
+SEED_W = 1234
+HP = dict(O.DEFAULT_HPARAMS)
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def close(a, b, rtol=1e-5, atol=1e-6, what=""):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = np.abs(a - b)
+    tol = atol + rtol * np.abs(b)
+    assert (err <= tol).all(), f"{what}: max err {err.max():.3e} (ref scale {np.abs(b).max():.3e})"
+
+
+# ---------------------------------------------------------------- templates of the state_dicts (names + shapes only)
+def convd_template(pre, cin, c):
+    t = {}
+    for i, ci in ((1, cin), (2, c), (3, c)):
+        t[f"{pre}conv{i}.weight"] = torch.empty(c, ci, 3, 3)
+        t[f"{pre}conv{i}.bias"] = torch.empty(c)
+        t.update(bn_template(f"{pre}bn{i}", c))
+    return t
+
+
+def bn_template(name, c):
+    return {f"{name}.weight": torch.empty(c), f"{name}.bias": torch.empty(c),
+            f"{name}.running_mean": torch.empty(c), f"{name}.running_var": torch.empty(c),
+            f"{name}.num_batches_tracked": torch.empty((), dtype=torch.long)}
+
+
+def convu_template(pre, planes, first):
+    t = {}
+    if not first:
+        t[f"{pre}conv1.weight"] = torch.empty(planes, 2 * planes, 3, 3)
+        t[f"{pre}conv1.bias"] = torch.empty(planes)
+        t.update(bn_template(f"{pre}bn1", planes))
+    t[f"{pre}conv2.weight"] = torch.empty(planes // 2, planes, 1, 1)
+    t[f"{pre}conv2.bias"] = torch.empty(planes // 2)
+    t.update(bn_template(f"{pre}bn2", planes // 2))
+    t[f"{pre}conv3.weight"] = torch.empty(planes, planes, 3, 3)
+    t[f"{pre}conv3.bias"] = torch.empty(planes)
+    t.update(bn_template(f"{pre}bn3", planes))
+    return t
+
+
+def conv_template(name, co, ci, k):
+    return {f"{name}.weight": torch.empty(co, ci, k, k), f"{name}.bias": torch.empty(co)}
+
+
+def unet_template(pre, n=16):
+    t = {}
+    t.update(convd_template(pre + "down1.", n, 2 * n))
+    t.update(convd_template(pre + "down2.", 2 * n, 4 * n))
+    t.update(convd_template(pre + "down3.", 4 * n, 8 * n))
+    t.update(convd_template(pre + "down4.", 8 * n, 16 * n))
+    t.update(convu_template(pre + "up1.", 16 * n, True))
+    t.update(convu_template(pre + "up2.", 8 * n, False))
+    t.update(convu_template(pre + "up3.", 4 * n, False))
+    t.update(convu_template(pre + "up4.", 2 * n, False))
+    return t
+
+
+def deepwt_template(pre):
+    t = {}
+    t.update(conv_template(pre + "DoubleConv.double_conv.0", 16, 3, 3))
+    t.update(conv_template(pre + "DoubleConv.double_conv.2", 16, 16, 3))
+    t.update(conv_template(pre + "DoubleConv2.double_conv.0", 16, 16, 3))
+    t.update(conv_template(pre + "DoubleConv2.double_conv.2", 16, 16, 3))
+    return t
+
+
+def head_template(pre, n=16):
+    t = {}
+    t.update(conv_template(pre + "0", 2 * n, 2 * n, 1))
+    t.update(conv_template(pre + "2", 8, 2 * n, 1))
+    t.update(conv_template(pre + "4", 1, 8, 1))
+    return t
+
+
+def main_template(shape_prior=True):
+    n = 16
+    t = {}
+    if shape_prior:
+        t.update(deepwt_template("wt_model."))
+    t.update(convd_template("inc.", 3, n))
+    t.update(unet_template(""))
+    if shape_prior:
+        p = "prior_dist."
+        t.update(conv_template(p + "inc.double_conv.0", n, 1, 3))
+        t.update(bn_template(p + "inc.double_conv.1", n))
+        t.update(conv_template(p + "inc.double_conv.3", n, n, 3))
+        t.update(bn_template(p + "inc.double_conv.4", n))
+        t.update(conv_template(p + "fusion.0", n, 2 * n, 1))
+        t.update(unet_template(p))
+        t.update(head_template(p + "mu_prior."))
+        t.update(head_template(p + "logvar_prior."))
+    t.update(conv_template("mu.0", 2 * n, 2 * n, 1))
+    t.update(conv_template("mu.2", 8, 2 * n, 1))
+    t.update(conv_template("outc.0", 1, 8, 1))
+    t.update(conv_template("attention_layer.layer1", 1, 1, 1))
+    return t
+
+
+def shape_template():
+    t = {}
+    t.update(deepwt_template("wt_model."))
+    t.update(unet_template(""))
+    t.update(head_template("mu_prior."))
+    t.update(head_template("logvar_prior."))
+    return t
+
+
+def main_state(two_step=False, shape_prior=True):
+    return filled_state(main_template(shape_prior), SEED_W + (7 if two_step else 0))
+
+
+def shape_state(oc=False):
+    return filled_state(shape_template(), SEED_W + (11 if oc else 3))
+
+
+def test_param_counts():
+    # SURVEY.md §8b [probe]: WT_PSE 6 378 661, shape net 3 189 570, seg-only 3 186 019
+    cnt = lambda t: sum(v.numel() for k, v in t.items() if not O.is_buffer(k))
+    assert cnt(main_template()) == 6378661
+    assert cnt(shape_template()) == 3189570
+    assert cnt(main_template(False)) == 3186019
+    assert len(main_template()) == 387 and len(shape_template()) == 181
+
+
+# ---------------------------------------------------------------- a-4 / a-5
+def test_wtloss_and_mmd(golden_dir):
+    g = load(golden_dir, "wtloss.npz")
+    for ci, (B, pb, H, white, margin, seed) in enumerate(g["cases"]):
+        B, pb, H, seed = int(B), int(pb), int(H), int(seed)
+        z = make_feature(seed, (B, 16, H, H), bool(white)).requires_grad_(True)
+        off, dg, dom = O.whitening_loss(z, 3, pb, margin)
+        (off + dg + dom).backward()
+        p = f"c{ci}_"
+        close(off.item(), g[p + "off"], what=p + "off")
+        close(dg.item(), g[p + "diag"], what=p + "diag")
+        close((off + dg).item(), g[p + "ins"], what=p + "ins")
+        # MMD is a cancellation-prone difference of O(1) kernel means: absolute tolerance
+        close(dom.item(), g[p + "dom"], rtol=1e-3, atol=2e-7, what=p + "dom")
+        close(dom.item(), g[p + "dom2"], rtol=1e-3, atol=2e-7, what=p + "dom2")
+        close(O.gram(z.detach()).numpy(), g[p + "gram"], what=p + "gram")
+        close(O.checksum(z.grad), g[p + "dz_cs"], rtol=1e-4, atol=1e-7, what=p + "dz_cs")
+        if H <= 8:
+            close(z.grad.numpy(), g[p + "dz"], rtol=1e-4, atol=1e-8, what=p + "dz")
+        v = torch.from_numpy(g[p + "v"]).requires_grad_(True)
+        d = O.mmd(v, 3, pb)
+        d.backward()
+        close(d.item(), g[p + "mmd"], rtol=1e-3, atol=2e-7, what=p + "mmd")
+        close(v.grad.numpy(), g[p + "dmmd_dv"], rtol=1e-3, atol=1e-7, what=p + "dmmd")
+
+
+# ---------------------------------------------------------------- a-1 / a-2 / a-3 / a-10
+@pytest.mark.parametrize("name,bi,kind", [("convd_first", 0, "d"), ("convd", 1, "d"), ("convu_first", 2, "u"), ("convu", 3, "u")])
+def test_blocks(golden_dir, name, bi, kind):
+    g = load(golden_dir, "blocks.npz")
+    B, H = 4, 16
+    spec = {"convd_first": (convd_template("", 3, 16), (B, 3, H, H), None, True),
+            "convd": (convd_template("", 16, 32), (B, 16, H, H), None, False),
+            "convu_first": (convu_template("", 64, True), (B, 64, H // 2, H // 2), (B, 32, H, H), True),
+            "convu": (convu_template("", 32, False), (B, 64, H // 2, H // 2), (B, 16, H, H), False)}[name]
+    tmpl, xs, ps, first = spec
+    sd = O.as_leaves(filled_state(tmpl, SEED_W + 20 + bi))
+    x = make_noise(300 + bi, xs).requires_grad_(True)
+    if kind == "d":
+        y = O.conv_d(sd, "", x, first, True)
+    else:
+        prev = make_noise(400 + bi, ps).requires_grad_(True)
+        y = O.conv_u(sd, "", x, prev, first, True)
+    (y * make_noise(500 + bi, y.shape)).sum().backward()
+    close(y.detach().numpy(), g[name + ".y"], rtol=1e-4, atol=1e-5, what="y")
+    close(x.grad.numpy(), g[name + ".dx"], rtol=1e-3, atol=1e-4, what="dx")
+    if kind == "u":
+        close(prev.grad.numpy(), g[name + ".dprev"], rtol=1e-3, atol=1e-4, what="dprev")
+    for k in O.param_names(sd):
+        if k.startswith("conv") and k.endswith(".bias"):
+            continue   # pre-BN conv bias: gradient is cancellation noise
+        ref = g[f"{name}.g.{k}"]
+        close(sd[k].grad.numpy(), ref, rtol=2e-3, atol=2e-4 * max(1.0, np.abs(ref).max()), what="g." + k)
+    for k in sd:
+        if O.is_buffer(k):
+            close(sd[k].numpy(), g[f"{name}.buf.{k}"], rtol=1e-5, atol=1e-6, what="buf." + k)
+    with torch.no_grad():
+        args = (sd, "", x.detach()) if kind == "d" else (sd, "", x.detach(), prev.detach())
+        y_eval = O.conv_d(*args, first, False) if kind == "d" else O.conv_u(*args, first, False)
+    close(y_eval.numpy(), g[name + ".y_eval"], rtol=1e-4, atol=1e-5, what="y_eval")
+
+
+def test_deepwt_attention(golden_dir):
+    g = load(golden_dir, "blocks.npz")
+    B, H = 4, 16
+    sd = O.as_leaves(filled_state(deepwt_template(""), SEED_W + 30))
+    x = make_noise(310, (B, 3, H, H)).requires_grad_(True)
+    zs = O.deep_wt(sd, "", x)
+    sum((z * make_noise(510 + i, z.shape)).sum() for i, z in enumerate(zs)).backward()
+    for i, z in enumerate(zs):
+        close(z.detach().numpy(), g[f"deepwt.z{i + 1}"], rtol=1e-5, atol=1e-6)
+    close(x.grad.numpy(), g["deepwt.dx"], rtol=1e-4, atol=1e-5)
+    for k in O.param_names(sd):
+        close(sd[k].grad.numpy(), g["deepwt.g." + k], rtol=1e-4, atol=1e-4)
+    sd = filled_state(conv_template("layer1", 1, 1, 1), SEED_W + 31)
+    a, pre = O.attention(sd, "", make_noise(311, (B, 1, H, H)))
+    close(a.numpy(), g["attention.sig"]); close(pre.numpy(), g["attention.pre"])
+
+
+# ---------------------------------------------------------------- a-7 / a-8 / a-9
+def _check_grads(sd, g, prefix, skip_bias_of_bn_convs=True):
+    seen = 0
+    for k in O.param_names(sd):
+        key = prefix + k
+        if sd[k].grad is None:
+            assert key not in g.files, key
+            continue
+        assert key in g.files, key
+        if ".conv" in "." + k and k.endswith(".bias"):
+            continue
+        if ".inc.double_conv.0.bias" in k or ".inc.double_conv.3.bias" in k:
+            continue    # teacher DoubleConv: conv bias directly followed by BN
+        ref = g[key]
+        close(O.checksum(sd[k].grad), ref, rtol=5e-3, atol=5e-6 + 5e-4 * abs(ref[1]) / max(sd[k].numel(), 1) * 32, what=key)
+        seen += 1
+    return seen
+
+
+@pytest.mark.parametrize("ci", [0, 1, 2])
+def test_network_calls(golden_dir, ci):
+    g = load(golden_dir, "network.npz")
+    B, pb, H, s_in, s_a, s_t, s_s = (int(v) for v in g["cases"][ci])
+    p = f"c{ci}_"
+    img, od, oc = make_inputs(s_in, B, H, H)
+    main, shape = main_state(), shape_state()
+    main_oc, shape_oc = main_state(True), shape_state(True)
+    with torch.no_grad():
+        logit, att = O.wt_pse_predict(main, shape, HP, img, False)
+        roi = (img + 1) * (torch.sigmoid(logit) > 0.75).float() - 1
+        logit2, att2 = O.wt_pse_predict(main_oc, shape_oc, HP, torch.stack((roi, roi), 0), True)
+    close(logit.numpy(), g[p + "pred_logit"], rtol=1e-4, atol=1e-5, what="pred_logit")
+    close(att.numpy(), g[p + "pred_att"], rtol=1e-4, atol=1e-5, what="pred_att")
+    close(logit2.numpy(), g[p + "pred2_logit"], rtol=1e-4, atol=1e-5, what="pred2_logit")
+    close(att2.numpy(), g[p + "pred2_att"], rtol=1e-4, atol=1e-5, what="pred2_att")
+    # update
+    main = O.as_leaves(main)
+    out, m1, _, ins, dom = O.wt_pse_update(main, HP, img, od, img, True, make_noise(s_a, (B, 1, H, H)), 3, pb)
+    loss = O.seg_loss_od(out, od) + ins + dom
+    loss.backward()
+    close(out.detach().numpy(), g[p + "upd_out"], rtol=1e-4, atol=1e-5, what="upd_out")
+    assert (m1.numpy() != g[p + "upd_mask"]).mean() < 1e-3
+    close(ins.item(), g[p + "upd_ins"], rtol=1e-5, what="ins")
+    close(dom.item(), g[p + "upd_dom"], rtol=1e-3, atol=2e-7, what="dom")
+    close(loss.item(), g[p + "upd_loss"], rtol=1e-5, what="loss")
+    assert _check_grads(main, g, p + "upd_g.") > 100
+    for k in main:
+        if O.is_buffer(k):
+            close(O.checksum(main[k].float()), g[p + "upd_buf." + k], rtol=1e-4, atol=1e-5, what=k)
+    # shape update on the same teacher state (buffers already advanced once, as in the generator)
+    shape = O.as_leaves(shape)
+    for k in O.param_names(main):
+        main[k].grad = None
+    kd, ins_t, ins_off, ins_diag, dom_s = O.shape_update(shape, main, HP, img, od, img, True,
+                                                         make_noise(s_t, (B, 1, H, H)), make_noise(s_s, (B, 1, H, H)), pb)
+    (kd + ins_t + dom_s).backward()
+    close(kd.item(), g[p + "shp_kd"], rtol=1e-4, what="kd")
+    close(ins_t.item(), g[p + "shp_ins_total"], rtol=1e-5)
+    close(ins_off.item(), g[p + "shp_ins_off"], rtol=1e-5)
+    close(ins_diag.item(), g[p + "shp_ins_diag"], rtol=1e-5)
+    close(dom_s.item(), g[p + "shp_dom"], rtol=1e-3, atol=2e-7)
+    assert _check_grads(shape, g, p + "shp_g.") > 50
+
+
+def test_seg_only(golden_dir):
+    g = load(golden_dir, "network.npz")
+    hp0 = dict(HP, whitening=False, shape_prior=False)
+    sd = O.as_leaves(main_state(shape_prior=False))
+    img, od, _ = make_inputs(650, 6, 32, 32)
+    out = O.wt_pse_update(sd, hp0, img, od, img, True, None, 3, 2)
+    assert out[1:] == (0, 0, 0, 0)
+    O.seg_loss_od(out[0], od).backward()
+    close(out[0].detach().numpy(), g["segonly_out"], rtol=1e-4, atol=1e-5)
+    _check_grads(sd, g, "segonly_g.")
+    with torch.no_grad():
+        pred, none = O.wt_pse_predict(sd, None, hp0, img, False)
+    assert none is None
+    close(pred.numpy(), g["segonly_pred"], rtol=1e-4, atol=1e-5)
+
+
+# ---------------------------------------------------------------- a-11
+def test_iterations(golden_dir):
+    g = load(golden_dir, "iteration.npz")
+    B, pb, H, iters, s_in, s_n = (int(v) for v in g["meta"])
+    nets = O.Nets(main_state(), shape_state(), main_state(True), shape_state(True))
+    keys = [str(k) for k in g["loss_keys"]]
+    for it in range(iters):
+        img, od, oc = make_inputs(s_in + it, B, H, H)
+        nz = {k: make_noise(s_n + 10 * it + j, (B, 1, H, H)) for j, k in enumerate(["a", "b_t", "b_s", "c", "d_t", "d_s"])}
+        res = O.train_iteration(nets, HP, img, od, oc, nz, pb)
+        for j, k in enumerate(keys):
+            tol = dict(rtol=1e-3, atol=3e-7) if k.startswith("dom") else dict(rtol=2e-4, atol=1e-6)
+            close(res[k], g["losses"][it][j], what=f"it{it}.{k}", **tol)
+    for tag, sd in zip(["od", "shape_od", "oc", "shape_oc"], [nets.od, nets.shape_od, nets.oc, nets.shape_oc]):
+        for k in sd:
+            if ".conv" in "." + k and k.endswith(".bias"):
+                continue
+            if ".inc.double_conv.0.bias" in k or ".inc.double_conv.3.bias" in k:
+                continue
+            ref = g[f"{tag}.{k}"]
+            # Adam's first steps move every weight by ~lr regardless of gradient scale: compare at lr/10
+            close(O.checksum(sd[k].float()), ref, rtol=1e-4, atol=5e-5 * max(1.0, min(sd[k].numel(), 32) ** 0.5), what=f"{tag}.{k}")
+
+
+def test_dice(golden_dir):
+    g = load(golden_dir, "dice.npz")
+    for s, t, d in zip(g["seg"], g["gt"], g["dice"]):
+        assert O.dice_coefficient(s, t) == pytest.approx(float(d), abs=1e-12)
