@@ -1,0 +1,139 @@
+/* wtpse_hip.h — C ABI of libwtpse_hip.so: the MI355X (gfx950) kernels behind the WT-PSE training hot path.
+ *
+ * The reference (tonyckc/WT-PSE-code) has no FFI of its own: its boundary is the Python class surface of
+ * algorithms.py / shape_networks.py, which wt-pse-code_amd/{algorithms,shape_networks}.py mirror.
+ * This library sits directly below that surface.  Each entry point replaces the stock ATen dispatches the
+ * reference reaches from the cited lines.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; every pointer is DEVICE memory unless stated; tensors are NCHW fp32,
+ *     contiguous, caller-owned.  No allocation, no host synchronisation and no stream creation inside: scratch
+ *     ("partial", "slab", "ws") is passed in, `stream` is a hipStream_t (NULL = default stream), so every call is
+ *     legal inside hipGraph capture.
+ *   - return 0 on success, -1 (WTPSE_EINVAL) for rejected arguments, otherwise the hipError_t of the launch.
+ *   - "pro" (prologue) = optional per-channel [C][2] (scale, shift) applied to an input as it is loaded, followed by
+ *     ReLU when the matching relu bit is set: BatchNorm-apply + activation fused into the consumer.
+ */
+#ifndef WTPSE_HIP_H
+#define WTPSE_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- convolution: nn.Conv2d 3x3 pad 1 / 1x1 (algorithms.py:882-888,926-933,404-424,991,1006-1012,1199-1201;
+ *      shape_networks.py:182-193,332-338,376-383,459-465) ------------------------------------------------------- */
+
+/* OIHW parameters -> kernel layouts, all convs of a network in one launch.
+ * desc: n_desc x 8 ints {w_off, Cout, Cin, taps, wf_off, wd_off(-1: none), 0, 0}, offsets in floats into
+ * `params` / `packed`.  wf = [ceil4(Cin)][taps][ceil16(Cout)], wd = [ceil4(Cout)][taps][ceil16(Cin)] (tap-flipped). */
+int wtpse_pack_conv_weights(const float* params, const int* desc, int n_desc, float* packed, void* stream);
+
+/* out = conv(cat(in0, in1)) [+ bias] [ReLU].  in1 may be NULL (C1 = 0): torch.cat (algorithms.py:955,1018) is virtual.
+ * pro: [C0+C1][2] or NULL; pro_relu bit0 / bit1: ReLU on in0 / in1 after the affine.
+ * Output channels [0, Csplit) go to out0, the rest to out1 (Csplit == Cout, out1 NULL: no split).
+ * stats: NULL or [wtpse_conv_stats_blocks(B,H,W)][Cout][2] per-workgroup (sum, sum^2) of the output (train-mode
+ * BatchNorm statistics, algorithms.py:883-889); not combinable with relu_out.
+ * The data gradient is this same call on dY with the `wd` layout. */
+int wtpse_conv_fwd(const float* in0, int C0, const float* in1, int C1, const float* wpacked, const float* bias,
+                   const float* pro, int pro_relu, float* out0, float* out1, int Csplit, float* stats, int B, int H,
+                   int W, int Cout, int ksize, int relu_out, void* stream);
+int wtpse_conv_stats_blocks(int B, int H, int W);
+
+/* dW[Cout][C0+C1][k][k] (+)= sum dY * X, dbias (+)= sum dY (dbias/dbias_slab NULL: skip).  slab: [ksplit][Cout*Cin*k*k],
+ * dbias_slab: [ksplit][Cout], ksplit = wtpse_wgrad_ksplit(...).  x inputs take the same prologue as the forward. */
+int wtpse_conv_wgrad(const float* dy, const float* x0, int C0, const float* x1, int C1, const float* pro, int pro_relu,
+                     float* slab, float* dbias_slab, int ksplit, float* dw, float* dbias, int accumulate, int B, int H,
+                     int W, int Cout, int ksize, void* stream);
+int wtpse_wgrad_ksplit(int B, int H, int W, int Cin, int Cout);
+
+/* ---- BatchNorm2d, eps 1e-5, momentum 0.1 (algorithms.py:862-864) ---------------------------------------------- */
+/* train mode: fold the conv epilogue's partials -> scale_shift[C][2], save_mean/invstd[C]; update running stats
+ * (unbiased variance) and num_batches_tracked (int64) when given. */
+int wtpse_bn_finalize(const float* stats_partial, int nblk, int C, long long count, const float* gamma, const float* beta,
+                      float* running_mean, float* running_var, long long* num_batches, float momentum, float eps,
+                      float* scale_shift, float* save_mean, float* save_invstd, void* stream);
+/* eval mode: scale_shift from the running statistics. */
+int wtpse_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                         float eps, int C, float* scale_shift, void* stream);
+/* z = act(y * scale + shift), materialised (scale_shift NULL: identity). */
+int wtpse_affine_act(const float* y, const float* scale_shift, int relu, float* z, int B, int C, int HW, void* stream);
+/* dz (grad wrt z = act(bn(y))) -> dgamma, dbeta, dy.  partial: [wtpse_bn_bwd_nsplit][C][2], coef: [C][3]. */
+int wtpse_bn_bwd(const float* dz, const float* y, const float* scale_shift, int relu, const float* gamma,
+                 const float* save_mean, const float* save_invstd, float* partial, float* coef, float* dgamma,
+                 float* dbeta, int accumulate, float* dy, int B, int C, int HW, void* stream);
+int wtpse_bn_bwd_nsplit(int B, int C, int HW);
+
+/* ---- WT (whitening) loss: compute_whitening_loss + compute_MMD (algorithms.py:1277-1309,59-121;
+ *      shape_networks.py:561-594,240-309) ------------------------------------------------------------------------ */
+/* z [B,16,HW] -> gram[B][256] (incl. eps*I), v[B][120], offdiag[B], diag[B], rowval[D*n] (fp64), dmmd_dv[D*n][120],
+ * losses[3] = {ins_offdiag, ins_diag, domain}.  partial: [B * wtpse_wt_split(B,HW,&chunk)][256]. */
+int wtpse_wt_loss_fwd(const float* z, int B, int C, int HW, float eps, float margin, int domain_num, int per_domain,
+                      float* partial, float* gram, float* v, float* offdiag, float* diag, double* rowval,
+                      float* dmmd_dv, float* losses, void* stream);
+int wtpse_wt_split(int B, int HW, int* chunk_out);
+/* dz (+)= d(w_off*g_off*ins_off + w_diag*g_diag*ins_diag + w_dom*g_dom*dom)/dz.  g_*: device scalars (NULL = 1).
+ * Mws: [B][256] scratch. */
+int wtpse_wt_loss_bwd(const float* z, int B, int C, int HW, float margin, int domain_num, int per_domain,
+                      const float* gram, const float* offdiag, const float* diag, const float* dmmd_dv,
+                      const float* g_off, const float* g_diag, const float* g_dom, float w_off, float w_diag, float w_dom,
+                      float* Mws, float* dz, int accumulate, void* stream);
+/* Fold per-map losses [nmaps][3] into out[4] = (ins_total, ins_off, ins_diag, dom) with the reference's quirks:
+ * mode 0 = WT_PSE.update (algorithms.py:1259-1267), mode 1 = student incl. accumulator overwrite (shape_networks.py:546-548). */
+int wtpse_wt_combine(const float* losses, int nmaps, float den, int mode, float* out, void* stream);
+/* MMD alone on v [D*n][120] (data-parallel: after the all-gather of v). sum(rowval) is the loss. */
+int wtpse_mmd_fwd(const float* v, int domain_num, int per_domain, double* rowval, float* dmmd_dv, void* stream);
+
+/* ---- pooling / upsampling (algorithms.py:890,901,929,949) ------------------------------------------------------- */
+int wtpse_maxpool2_fwd(const float* x, const float* pro, int relu, float* out, int B, int C, int H, int W, void* stream);
+int wtpse_maxpool2_bwd(const float* x, const float* pro, int relu, const float* dout, float* dx, int accumulate, int B,
+                       int C, int H, int W, void* stream);
+/* bilinear x2, align_corners=False; H, W are the INPUT sizes. */
+int wtpse_upsample2x_fwd(const float* x, const float* pro, int relu, float* out, int B, int C, int H, int W, void* stream);
+int wtpse_upsample2x_bwd(const float* dout, float* dx, int accumulate, int B, int C, int H, int W, void* stream);
+
+/* ---- shape attention + fusion (algorithms.py:1126-1129,1243-1248,1342-1344) ------------------------------------- */
+/* att = sigmoid(w*z + b), fuse = coef*emb + att*emb, mask = att > 0.75.  wb: device {w, b}.  att/att_pre/mask optional. */
+int wtpse_attn_fuse_fwd(const float* z, const float* wb, const float* emb, float coef, float* att, float* att_pre,
+                        float* mask, float* fuse, int B, int CE, int HW, void* stream);
+/* partial: [2*ceil(B*HW/256)]; d_wb[2] (+)= (dw, db); dz optional. */
+int wtpse_attn_fuse_bwd(const float* dfuse, const float* z, const float* emb, const float* att, const float* wb, float coef,
+                        float* demb, float* dz, float* partial, float* d_wb, int accumulate, int B, int CE, int HW,
+                        void* stream);
+
+/* ---- sampling (algorithms.py:1068-1075; shape_networks.py:490-510) ----------------------------------------------- */
+int wtpse_reparam_fwd(const float* mu, const float* logvar, const float* eps, float* z, long long n, void* stream);
+int wtpse_reparam_bwd(const float* dz, const float* logvar, const float* eps, float* dlogvar, long long n, void* stream);
+int wtpse_exp_half(const float* logvar, float* std_, long long n, void* stream);
+int wtpse_reparam_student(const float* mu, const float* std_, const float* eps, float* z, long long n, void* stream);
+/* if any element is NaN: nan_to_num the whole tensor.  flag: one device int (scratch). No host sync. */
+int wtpse_nan_scrub(float* x, long long n, int* flag, void* stream);
+/* Philox4x32-10 + Box-Muller; element i depends only on (seed, offset + i): offset = global element index (multiple of 4). */
+int wtpse_randn(float* out, long long n, unsigned long long seed, unsigned long long offset, void* stream);
+
+/* ---- caller-side losses and optimiser (Trainer.py:19,787,842-871; shape_networks.py:596-597; train.py:120-138) --- */
+/* `partial` scratch: wtpse_reduce_blocks(n) floats (x2 for wtpse_pos_weight).  g: device scalar upstream gradient or NULL. */
+int wtpse_reduce_blocks(long long n);
+int wtpse_bce_sigmoid_fwd(const float* x, const float* t, long long n, float* partial, float* loss, void* stream);
+int wtpse_bce_sigmoid_bwd(const float* x, const float* t, const float* g, float w, long long n, float* dx, void* stream);
+int wtpse_pos_weight(const float* mask, const float* t, long long n, float* partial, float* sums, float* pw, void* stream);
+int wtpse_pos_weight_from_sums(const float* sums, float* pw, void* stream);
+int wtpse_bce_logits_pw_fwd(const float* x, const float* mask, const float* t, const float* pw, long long n, float* partial,
+                            float* loss, void* stream);
+int wtpse_bce_logits_pw_bwd(const float* x, const float* mask, const float* t, const float* pw, const float* g, float w,
+                            long long n, float* dx, void* stream);
+int wtpse_mse_fwd(const float* a, const float* b, long long n, float* partial, float* loss, void* stream);
+int wtpse_mse_bwd(const float* a, const float* b, const float* g, float w, long long n, float* da, void* stream);
+int wtpse_roi(const float* image, const float* logit, float* roi, float* od_pred, int B, int C, int HW, void* stream);
+int wtpse_adam(float* p, const float* g, float* m, float* v, long long n, double lr, double beta1, double beta2, double eps,
+               int step, void* stream);
+
+/* ---- small utilities ------------------------------------------------------------------------------------------- */
+int wtpse_relu_mask(const float* dz, const float* ref, float* dy, int accumulate, long long n, void* stream);
+int wtpse_axpy(float* dst, const float* src, float alpha, long long n, void* stream);
+int wtpse_reduce_rows(const float* partial, int rows, int cols, float* out, int accumulate, float scale, void* stream);
+int wtpse_zero(void* p, long long nbytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

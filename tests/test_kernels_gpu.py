@@ -1,0 +1,347 @@
+"""Kernel-level parity (-m gpu): every C-ABI entry point against stock PyTorch fp32 ops on the host CPU,
+on seeded inputs at sizes the CPU finishes in seconds — including ragged tiles, 1-/3-/8-channel layers, the
+16x16 and 8x32 tile shapes, virtual concat, fused prologue/epilogue and all three MFMA modes."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def ops():
+    from wtpse_hip import ops as o
+    return o
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).float()
+
+
+def close(a, b, rtol=1e-4, atol=1e-5, what=""):
+    a = a.detach().cpu().double()
+    b = b.detach().cpu().double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    bad = err > tol
+    assert not bad.any(), f"{what}: {int(bad.sum())}/{bad.numel()} off, max err {err.max():.3e} at {int(err.argmax())}, ref scale {b.abs().max():.3e}"
+
+
+def pack(w):
+    """OIHW -> (packed buffer, wf_off, wd_off) through wtpse_pack_conv_weights."""
+    o = ops()
+    co, ci, k, _ = w.shape
+    t = k * k
+    wf = ((ci + 3) & ~3) * t * ((co + 15) & ~15)
+    wd = ((co + 3) & ~3) * t * ((ci + 15) & ~15)
+    flat = w.reshape(-1).contiguous().to(DEV)
+    packed = torch.full((wf + wd,), float("nan"), device=DEV)
+    desc = torch.tensor([0, co, ci, t, 0, wf, 0, 0], dtype=torch.int32, device=DEV)
+    o.lib().call("wtpse_pack_conv_weights", flat.data_ptr(), desc.data_ptr(), 1, packed.data_ptr(), o.stream_ptr())
+    return packed, 0, wf
+
+
+CONV_CASES = [
+    # B, C0, C1, Cout, H, W, k
+    (2, 16, 0, 16, 16, 32, 3),     # MODE 0, one full 8x32 tile per 8 rows
+    (2, 3, 0, 16, 20, 40, 3),      # 3-channel input, ragged tiles
+    (1, 1, 0, 16, 9, 33, 3),       # 1-channel input
+    (2, 16, 0, 32, 16, 16, 3),     # MODE 1, 16x16 tile
+    (2, 32, 0, 64, 8, 8, 3),       # MODE 2, image smaller than a tile
+    (1, 64, 64, 128, 16, 16, 3),   # concat, two cout blocks
+    (2, 16, 16, 32, 24, 48, 3),    # concat at MODE 1, ragged
+    (3, 32, 0, 16, 17, 35, 1),     # 1x1, MODE 0
+    (2, 256, 0, 128, 4, 4, 1),     # 1x1, MODE 2, multi-chunk
+    (2, 32, 0, 8, 16, 32, 1),      # head: Cout = 8
+    (2, 8, 0, 1, 16, 32, 1),       # head: Cout = 1
+    (1, 128, 0, 256, 2, 2, 3),     # deepest level of the 32x32 test network
+    (2, 40, 0, 96, 12, 20, 3),     # non-power-of-two channels (MODE 1, 3 cout blocks)
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_forward(case):
+    o = ops()
+    B, C0, C1, Co, H, W, k = case
+    x0 = rnd(B, C0, H, W, seed=1)
+    x1 = rnd(B, C1, H, W, seed=2) if C1 else None
+    w = rnd(Co, C0 + C1, k, k, seed=3, scale=0.2)
+    b = rnd(Co, seed=4)
+    ref = F.conv2d(torch.cat([x0, x1], 1) if C1 else x0, w, b, padding=k // 2)
+    packed, wf, _ = pack(w)
+    y, _, stats = o.conv_fwd(x0.to(DEV), x1.to(DEV) if C1 else None, packed.data_ptr() + 4 * wf, b.to(DEV), Co, k,
+                             want_stats=True)
+    close(y, ref, what="conv")
+    s = stats.double().sum(0).cpu()
+    close(s[:, 0], ref.double().sum((0, 2, 3)), rtol=1e-4, atol=1e-3, what="stat sum")
+    close(s[:, 1], (ref.double() ** 2).sum((0, 2, 3)), rtol=1e-4, atol=1e-3, what="stat sumsq")
+    yr, _, _ = o.conv_fwd(x0.to(DEV), x1.to(DEV) if C1 else None, packed.data_ptr() + 4 * wf, None, Co, k, relu_out=True)
+    close(yr, F.relu(ref - b.view(1, -1, 1, 1)), what="conv relu nobias")
+
+
+@pytest.mark.parametrize("case", [(2, 16, 16, 32, 16, 32, 3), (2, 16, 0, 16, 16, 32, 3), (1, 32, 32, 64, 8, 16, 1)])
+def test_conv_prologue(case):
+    """BatchNorm-apply + ReLU fused into the loader; zero padding applies after the activation."""
+    o = ops()
+    B, C0, C1, Co, H, W, k = case
+    x0 = rnd(B, C0, H, W, seed=5)
+    x1 = rnd(B, C1, H, W, seed=6) if C1 else None
+    pro = torch.stack([rnd(C0 + C1, seed=7) * 0.5 + 1.0, rnd(C0 + C1, seed=8)], 1).contiguous()
+    w = rnd(Co, C0 + C1, k, k, seed=9, scale=0.2)
+    xin = torch.cat([x0, x1], 1) if C1 else x0
+    act = xin * pro[:, 0].view(1, -1, 1, 1) + pro[:, 1].view(1, -1, 1, 1)
+    act = torch.cat([F.relu(act[:, :C0]), act[:, C0:]], 1)      # ReLU on in0 only (bit 0)
+    ref = F.conv2d(act, w, None, padding=k // 2)
+    packed, wf, _ = pack(w)
+    y, _, _ = o.conv_fwd(x0.to(DEV), x1.to(DEV) if C1 else None, packed.data_ptr() + 4 * wf, None, Co, k, pro=pro.to(DEV), pro_relu=1)
+    close(y, ref, what="prologue")
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_dgrad_wgrad(case):
+    o = ops()
+    B, C0, C1, Co, H, W, k = case
+    x0 = rnd(B, C0, H, W, seed=11).requires_grad_(True)
+    x1 = rnd(B, C1, H, W, seed=12).requires_grad_(True) if C1 else None
+    w = rnd(Co, C0 + C1, k, k, seed=13, scale=0.2).requires_grad_(True)
+    b = rnd(Co, seed=14).requires_grad_(True)
+    dy = rnd(B, Co, H, W, seed=15)
+    y = F.conv2d(torch.cat([x0, x1], 1) if C1 else x0, w, b, padding=k // 2)
+    y.backward(dy)
+    packed, _, wd = pack(w.detach())
+    if C0 + C1 > 4:   # the data gradient of the 1-/3-channel input layers is never needed
+        d0, d1, _ = o.conv_fwd(dy.to(DEV), None, packed.data_ptr() + 4 * wd, None, C0 + C1, k, split=(C0 if C1 else None))
+        close(d0, x0.grad, what="dgrad0")
+        if C1:
+            close(d1, x1.grad, what="dgrad1")
+    dw = torch.full_like(w, float("nan")).to(DEV)
+    db = torch.full_like(b, float("nan")).to(DEV)
+    o.conv_wgrad(dy.to(DEV), x0.detach().to(DEV), x1.detach().to(DEV) if C1 else None, k, dw, db)
+    scale = float(w.grad.abs().max())
+    close(dw, w.grad, rtol=2e-4, atol=2e-5 * max(scale, 1.0), what="wgrad")
+    close(db, b.grad, rtol=2e-4, atol=1e-4, what="bgrad")
+    o.conv_wgrad(dy.to(DEV), x0.detach().to(DEV), x1.detach().to(DEV) if C1 else None, k, dw, None, accumulate=True)
+    close(dw, 2 * w.grad, rtol=2e-4, atol=4e-5 * max(scale, 1.0), what="wgrad accumulate")
+
+
+@pytest.mark.parametrize("shape,relu", [((4, 16, 16, 32), True), ((3, 32, 9, 7), False), ((2, 64, 4, 4), True)])
+def test_batchnorm_train(shape, relu):
+    o = ops()
+    B, C, H, W = shape
+    xin = rnd(B, 8, H, W, seed=21)
+    w = rnd(C, 8, 3, 3, seed=22, scale=0.3)
+    bias = rnd(C, seed=23)
+    gamma = (rnd(C, seed=24) * 0.2 + 1).requires_grad_(True)
+    beta = (rnd(C, seed=25) * 0.2).requires_grad_(True)
+    rm, rv = rnd(C, seed=26) * 0.1, rnd(C, seed=27).abs() + 0.5
+    yref = F.conv2d(xin, w, bias, padding=1).requires_grad_(True)
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    zref = F.batch_norm(yref, rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5)
+    if relu:
+        zref = F.relu(zref)
+    dz = rnd(*shape, seed=28)
+    zref.backward(dz)
+    packed, wf, _ = pack(w)
+    y, _, stats = o.conv_fwd(xin.to(DEV), None, packed.data_ptr() + 4 * wf, bias.to(DEV), C, 3, want_stats=True)
+    rm_d, rv_d = rm.to(DEV), rv.to(DEV)
+    nbt = torch.zeros((), dtype=torch.long, device=DEV)
+    g_d, b_d = gamma.detach().to(DEV), beta.detach().to(DEV)
+    ss, mean, invstd = o.bn_finalize(stats, B * H * W, g_d, b_d, rm_d, rv_d, nbt)
+    z = o.affine_act(y, ss, relu)
+    close(z, zref, what="bn fwd")
+    close(rm_d, rm_ref, what="running_mean")
+    close(rv_d, rv_ref, what="running_var")
+    assert int(nbt.item()) == 1
+    dg, dbt = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    dy = o.bn_bwd(dz.to(DEV), y, ss, relu, g_d, mean, invstd, dg, dbt)
+    close(dy, yref.grad, rtol=2e-4, atol=2e-5, what="bn dy")
+    close(dg, gamma.grad, rtol=2e-4, atol=2e-4, what="dgamma")
+    close(dbt, beta.grad, rtol=2e-4, atol=2e-4, what="dbeta")
+    ss_e = o.bn_eval_coeffs(g_d, b_d, rm_d, rv_d)
+    close(o.affine_act(y, ss_e, False), F.batch_norm(yref.detach(), rm_ref, rv_ref, gamma.detach(), beta.detach(), False, 0.1, 1e-5),
+          what="bn eval")
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 8, 12), (1, 3, 7, 9), (2, 16, 32, 32)])
+def test_pool_and_upsample(shape):
+    o = ops()
+    x = rnd(*shape, seed=31).requires_grad_(True)
+    p = F.max_pool2d(F.relu(x), 2)
+    dp = rnd(*p.shape, seed=32)
+    p.backward(dp)
+    xd = x.detach().to(DEV)
+    close(o.maxpool2_fwd(xd, None, True), p, what="pool fwd")
+    # gradient wrt relu(x) (the tensor as loaded); the ReLU mask is the producer's job
+    xr = F.relu(x.detach()).requires_grad_(True)
+    F.max_pool2d(xr, 2).backward(dp)
+    close(o.maxpool2_bwd(xd, dp.to(DEV), None, False, None, True), xr.grad, what="pool bwd")
+    acc = rnd(*shape, seed=33)
+    close(o.maxpool2_bwd(xd, dp.to(DEV), acc.clone().to(DEV), True, None, True), xr.grad + acc, what="pool bwd acc")
+    x2 = rnd(*shape, seed=34).requires_grad_(True)
+    u = F.interpolate(x2, scale_factor=2, mode="bilinear", align_corners=False)
+    du = rnd(*u.shape, seed=35)
+    u.backward(du)
+    close(o.upsample2x_fwd(x2.detach().to(DEV)), u, what="up fwd")
+    close(o.upsample2x_bwd(du.to(DEV)), x2.grad, rtol=1e-4, atol=1e-5, what="up bwd")
+
+
+def test_wt_loss_against_oracle_and_golden(golden_dir):
+    """a-4 / a-5: forward triple and dL/dz against the CPU oracle and the reference-generated fixtures."""
+    import os
+    from oracle import wtpse_cpu as O
+    from oracle.inputs import make_feature
+    o = ops()
+    g = np.load(os.path.join(golden_dir, "wtloss.npz"))
+    for ci, (B, pb, H, white, margin, seed) in enumerate(g["cases"]):
+        B, pb, H, seed = int(B), int(pb), int(H), int(seed)
+        z = make_feature(seed, (B, 16, H, H), bool(white))
+        zr = z.clone().requires_grad_(True)
+        off, dg, dom = O.whitening_loss(zr, 3, pb, float(margin))
+        (off + dg + dom).backward()
+        st = o.wt_loss_fwd(z.to(DEV), 3, pb, float(margin))
+        l = st.losses.cpu()
+        p = f"c{ci}_"
+        for got, ref, key in ((l[0], off, "off"), (l[1], dg, "diag")):
+            close(got, ref.detach(), rtol=1e-5, atol=1e-7, what=p + key)
+            assert abs(float(got) - float(g[p + key])) <= 1e-6 + 1e-5 * abs(float(g[p + key]))
+        assert abs(float(l[2]) - float(g[p + "dom"])) <= 3e-7 + 1e-3 * abs(float(g[p + "dom"])), (float(l[2]), float(g[p + "dom"]))
+        close(st.gram.view(B, 16, 16), torch.from_numpy(g[p + "gram"]), rtol=1e-5, atol=1e-6, what=p + "gram")
+        close(st.v, torch.from_numpy(g[p + "v"]), rtol=1e-5, atol=1e-6, what=p + "v")
+        dz = torch.zeros_like(z).to(DEV)
+        o.wt_loss_bwd(st, dz, False)
+        close(dz, zr.grad, rtol=2e-3, atol=1e-8 + 2e-4 * float(zr.grad.abs().max()), what=p + "dz")
+        if H <= 8:
+            close(dz, torch.from_numpy(g[p + "dz"]), rtol=2e-3, atol=1e-8 + 2e-4 * float(zr.grad.abs().max()), what=p + "dz golden")
+        # accumulate + device-scalar upstream gradients + host weights
+        base = rnd(*z.shape, seed=40)
+        dz2 = base.clone().to(DEV)
+        two = torch.tensor(2.0, device=DEV)
+        o.wt_loss_bwd(st, dz2, True, g_off=two, g_diag=two, g_dom=two, w_off=0.5, w_diag=0.5, w_dom=0.5)
+        close(dz2, base + zr.grad, rtol=2e-3, atol=1e-6 + 2e-4 * float(zr.grad.abs().max()), what=p + "dz acc")
+
+
+def test_wt_loss_unaligned_hw():
+    from oracle import wtpse_cpu as O
+    o = ops()
+    z = rnd(3, 16, 5, 7, seed=41)
+    off, dg, dom = O.whitening_loss(z, 3, 1, 0.0)
+    st = o.wt_loss_fwd(z.to(DEV), 3, 1, 0.0)
+    close(st.losses[:2], torch.stack([off, dg]), rtol=1e-5, atol=1e-7)
+
+
+def test_attention_fuse_and_sampling():
+    o = ops()
+    B, CE, H, W = 3, 8, 9, 11
+    z = rnd(B, 1, H, W, seed=51).requires_grad_(True)
+    emb = rnd(B, CE, H, W, seed=52).requires_grad_(True)
+    wb = torch.tensor([0.7, -0.2], requires_grad=True)
+    pre = z * wb[0] + wb[1]
+    att = torch.sigmoid(pre)
+    fuse = 0.3 * emb + att * emb
+    dfuse = rnd(B, CE, H, W, seed=53)
+    fuse.backward(dfuse)
+    wb_d = wb.detach().to(DEV)
+    a, p, m, f = o.attn_fuse_fwd(z.detach().to(DEV), wb_d.data_ptr(), emb.detach().to(DEV), 0.3, True, True, True)
+    close(a, att, what="att"); close(p, pre, what="pre"); close(f, fuse, what="fuse")
+    assert torch.equal(m.cpu(), (att > 0.75).float())
+    dwb = torch.zeros(2, device=DEV)
+    demb, dz = o.attn_fuse_bwd(dfuse.to(DEV), z.detach().to(DEV), emb.detach().to(DEV), a, wb_d.data_ptr(), 0.3, dwb.data_ptr(), True)
+    close(demb, emb.grad, what="demb"); close(dz, z.grad, what="dz"); close(dwb, wb.grad, rtol=1e-4, atol=1e-4, what="dwb")
+    mu, lv, eps = rnd(B, 1, H, W, seed=54).requires_grad_(True), rnd(B, 1, H, W, seed=55).requires_grad_(True), rnd(B, 1, H, W, seed=56)
+    zz = mu + torch.exp(lv / 2) * eps
+    g = rnd(B, 1, H, W, seed=57)
+    zz.backward(g)
+    close(o.reparam_fwd(mu.detach().to(DEV), lv.detach().to(DEV), eps.to(DEV)), zz, what="reparam")
+    close(o.reparam_bwd(g.to(DEV), lv.detach().to(DEV), eps.to(DEV)), lv.grad, what="dlogvar")
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    std = torch.exp(lv.detach() / 2)
+    s = mu.detach() + std * eps
+    close(o.reparam_student(mu.detach().to(DEV), lv.detach().to(DEV), eps.to(DEV), flag), s * std + mu.detach(), what="student sample")
+
+
+def test_nan_scrub_only_when_nan_present():
+    o = ops()
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    x = torch.tensor([1.0, float("inf"), -2.0, 5.0] * 100, device=DEV)
+    y = x.clone()
+    o.nan_scrub_(y, flag)
+    assert torch.equal(x.cpu(), y.cpu())            # inf alone is left in place (shape_networks.py:490)
+    x[7] = float("nan")
+    y = x.clone()
+    o.nan_scrub_(y, flag)
+    assert torch.equal(y.cpu(), torch.nan_to_num(x.cpu()))
+
+
+def test_losses_roi_adam():
+    o = ops()
+    n = (4, 1, 13, 17)
+    x = (rnd(*n, seed=61) * 3).requires_grad_(True)
+    t = (rnd(*n, seed=62) > 0).float()
+    ref = F.binary_cross_entropy(torch.sigmoid(x), t)
+    ref.backward()
+    close(o.bce_sigmoid_fwd(x.detach().to(DEV), t.to(DEV)), ref.detach(), rtol=1e-5, atol=1e-6, what="bce")
+    close(o.bce_sigmoid_bwd(x.detach().to(DEV), t.to(DEV)), x.grad, rtol=1e-4, atol=1e-8, what="dbce")
+    m = (rnd(*n, seed=63) > -0.5).float()
+    x2 = (rnd(*n, seed=64) * 3).requires_grad_(True)
+    pw = m.sum() / (m * t).sum()
+    ref2 = F.binary_cross_entropy_with_logits(x2 * m, t, pos_weight=pw)
+    ref2.backward()
+    sums, pw_d = o.pos_weight_sums(m.to(DEV), t.to(DEV))
+    close(pw_d, pw, rtol=1e-6, what="pos_weight")
+    close(o.bce_logits_pw_fwd(x2.detach().to(DEV), m.to(DEV), t.to(DEV), pw_d), ref2.detach(), rtol=1e-5, atol=1e-6, what="bce pw")
+    close(o.bce_logits_pw_bwd(x2.detach().to(DEV), m.to(DEV), t.to(DEV), pw_d), x2.grad, rtol=1e-4, atol=1e-8, what="dbce pw")
+    _, pw1 = o.pos_weight_sums(torch.zeros(*n, device=DEV), t.to(DEV))
+    assert float(pw1) == 1.0                            # 0/0 -> 1 (Trainer.py:866-867)
+    a, b = rnd(*n, seed=65).requires_grad_(True), rnd(*n, seed=66)
+    mse = F.mse_loss(b, a)
+    mse.backward()
+    close(o.mse_fwd(b.to(DEV), a.detach().to(DEV)), mse.detach(), rtol=1e-5, what="mse")
+    close(o.mse_bwd(a.detach().to(DEV), b.to(DEV)), a.grad, rtol=1e-5, atol=1e-9, what="dmse")
+    img = rnd(4, 3, 13, 17, seed=67)
+    od = (torch.sigmoid(x.detach()) > 0.75).float()
+    roi, od_d = o.roi(img.to(DEV), x.detach().to(DEV))
+    assert torch.equal(od_d.cpu(), od)
+    close(roi, (img + 1) * od - 1, what="roi")
+    # Adam against torch.optim.Adam over 3 steps
+    p = torch.nn.Parameter(rnd(1000, seed=68))
+    opt = torch.optim.Adam([p], lr=5e-4, betas=(0.9, 0.99))
+    pd, md, vd = p.detach().clone().to(DEV), torch.zeros(1000, device=DEV), torch.zeros(1000, device=DEV)
+    for step in range(1, 4):
+        gr = rnd(1000, seed=70 + step)
+        p.grad = gr.clone()
+        opt.step()
+        o.adam_step(pd, gr.to(DEV), md, vd, 5e-4, 0.9, 0.99, 1e-8, step)
+    close(pd, p.detach(), rtol=1e-6, atol=1e-7, what="adam")
+
+
+def test_randn_stream_properties():
+    o = ops()
+    a = o.randn((1 << 20,), DEV, seed=7, offset=0)
+    assert abs(float(a.mean())) < 5e-3 and abs(float(a.std()) - 1.0) < 5e-3
+    assert float(a.abs().max()) < 7.0
+    # a shard that starts at global element 4096 reproduces the same stream (data-parallel noise)
+    b = o.randn((1000,), DEV, seed=7, offset=4096)
+    assert torch.equal(a[4096:5096].cpu(), b.cpu())
+    assert not torch.equal(a[:1000].cpu(), o.randn((1000,), DEV, seed=8, offset=0).cpu())
+
+
+def test_mmd_module():
+    import algorithms
+    from oracle import wtpse_cpu as O
+    v = rnd(12, 120, seed=81) * 0.1
+    got = algorithms.compute_MMD(3, 4).forward(v.to(DEV))
+    ref = O.mmd(v, 3, 4)
+    assert abs(float(got) - float(ref)) < 3e-7 + 1e-3 * abs(float(ref))
+
+
+def test_rejects_bad_arguments():
+    from wtpse_hip.lib import WtpseError
+    o = ops()
+    with pytest.raises(WtpseError):
+        o.lib().call("wtpse_conv_fwd", 0, 16, 0, 0, 0, 0, 0, 0, 0, 0, 16, 0, 1, 8, 8, 16, 3, 0, 0)
+    with pytest.raises(ValueError):
+        o.conv_fwd(torch.zeros(1, 16, 8, 8), None, 0, None, 16, 3)     # host tensor: no CPU fallback

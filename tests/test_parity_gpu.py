@@ -1,0 +1,352 @@
+"""Network-level parity (-m gpu): the drop-in modules on MI355X against (i) the reference-generated fixtures
+under tests/golden/ and (ii) the CPU oracle on the same seeded inputs, through the public class surface
+(`update` / `predict` / `loss.backward()` / torch.optim.Adam) and through the fused step harness.
+
+Tolerance: north_star asks logits / Dice / WT-loss values within 1e-4 fp32 of the reference."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import wtpse_cpu as O
+from oracle.filler import fill_state_dict
+from oracle.inputs import make_inputs, make_noise
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+SEED_W = 1234
+HP = dict(O.DEFAULT_HPARAMS)
+TOL = 1e-4
+
+
+def close(a, b, rtol=1e-4, atol=1e-4, what=""):
+    a = torch.as_tensor(np.asarray(a.detach().cpu()) if torch.is_tensor(a) else np.asarray(a)).double()
+    b = torch.as_tensor(np.asarray(b.detach().cpu()) if torch.is_tensor(b) else np.asarray(b)).double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = (a - b).abs()
+    bad = err > atol + rtol * b.abs()
+    assert not bad.any(), f"{what}: {int(bad.sum())}/{bad.numel()} off, max err {err.max():.3e}, ref scale {b.abs().max():.3e}"
+
+
+def build_nets(pb, full=True):
+    import algorithms
+    import shape_networks
+    hp = HP if full else dict(HP, whitening=False, shape_prior=False)
+    mk = lambda two_step: algorithms.WT_PSE(n_channels=3, n_classes=1, hparams=hp, device=DEV, two_step=two_step,
+                                            per_domain_batch=pb, source_domain_num=3).to(DEV)
+    main, main_oc = mk(False), mk(True)
+    fill_state_dict(main, SEED_W)
+    fill_state_dict(main_oc, SEED_W + 7)
+    if not full:
+        return main, None, main_oc, None
+    shape = shape_networks.ShapeVariationalDist_x(hp, DEV, n_classes=1, number_source_domain=3, batch_size=pb).to(DEV)
+    shape_oc = shape_networks.ShapeVariationalDist_x(hp, DEV, n_classes=1, number_source_domain=3, batch_size=pb).to(DEV)
+    fill_state_dict(shape, SEED_W + 3)
+    fill_state_dict(shape_oc, SEED_W + 11)
+    return main, shape, main_oc, shape_oc
+
+
+def is_prebn_bias(k):
+    return ((".conv" in "." + k) and k.endswith(".bias")) or ".inc.double_conv.0.bias" in k or ".inc.double_conv.3.bias" in k
+
+
+def check_grads_vs_checksums(module, g, prefix, min_seen):
+    seen = 0
+    for k, p in module.named_parameters():
+        key = prefix + k
+        if key not in g.files:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        if is_prebn_bias(k):
+            continue
+        assert p.grad is not None, k
+        ref = g[key]
+        got = O.checksum(p.grad.cpu())
+        scale = abs(ref[1]) / max(p.numel(), 1)           # mean |grad|
+        err = np.abs(got - ref)
+        tol = 5e-3 * np.abs(ref) + 5e-6 + 2e-3 * scale * np.array([p.numel() ** 0.5, p.numel()] + [1.0] * (len(ref) - 2))
+        assert (err <= tol).all(), f"{key}: max err {err.max():.3e} tol {tol[err.argmax()]:.3e} scale {scale:.3e}"
+        seen += 1
+    assert seen >= min_seen, seen
+
+
+# ---------------------------------------------------------------- a-1 / a-2 / a-3: blocks against reference fixtures
+@pytest.mark.parametrize("name,bi", [("convd_first", 0), ("convd", 1), ("convu_first", 2), ("convu", 3)])
+def test_blocks_vs_golden(golden_dir, name, bi):
+    from wtpse_hip import nn as E
+    g = np.load(os.path.join(golden_dir, "blocks.npz"))
+    B, H = 4, 16
+    spec = {"convd_first": (lambda: E.ConvDBlock(3, 16, first=True), (B, 3, H, H), None),
+            "convd": (lambda: E.ConvDBlock(16, 32), (B, 16, H, H), None),
+            "convu_first": (lambda: E.ConvUBlock(64, first=True), (B, 64, H // 2, H // 2), (B, 32, H, H)),
+            "convu": (lambda: E.ConvUBlock(32), (B, 64, H // 2, H // 2), (B, 16, H, H))}[name]
+
+    class Holder(E.HipNet):
+        def __init__(self, blk):
+            super().__init__()
+            self.blk = blk
+            self._finish_init()
+
+    h = Holder(spec[0]()).to(DEV)
+    fill_state_dict(h.blk, SEED_W + 20 + bi)
+    h.ensure_ready(repack=True)
+    x = make_noise(300 + bi, spec[1]).to(DEV)
+    wgt = None
+    if spec[2] is None:
+        y, tape = E.convd_fwd(h.blk, x, False, True)
+    else:
+        prev = make_noise(400 + bi, spec[2]).to(DEV)
+        y, tape = E.convu_fwd(h.blk, x, prev, False, True)
+    close(y, g[name + ".y"], what="y")
+    dy = make_noise(500 + bi, tuple(y.shape)).to(DEV)
+    h.begin_backward()
+    if spec[2] is None:
+        dx = E.convd_bwd(h.blk, tape, dy, None, need_dx=True)
+    else:
+        dx, dprev = E.convu_bwd(h.blk, tape, dy)
+        close(dprev, g[name + ".dprev"], rtol=1e-3, atol=2e-4, what="dprev")
+    h.end_backward()
+    close(dx, g[name + ".dx"], rtol=1e-3, atol=2e-4, what="dx")
+    for k, p in h.blk.named_parameters():
+        if is_prebn_bias(k):
+            continue
+        ref = g[f"{name}.g.{k}"]
+        close(p.grad, ref, rtol=2e-3, atol=3e-4 * max(1.0, float(np.abs(ref).max())), what="g." + k)
+    for k, b in h.blk.named_buffers():
+        close(b.float(), g[f"{name}.buf.{k}"].astype(np.float32), rtol=1e-4, atol=1e-5, what="buf." + k)
+    h.blk.eval()
+    h.eval()
+    if spec[2] is None:
+        ye, _ = E.convd_fwd(h.blk, x, False, False, want_tape=False)
+    else:
+        ye, _ = E.convu_fwd(h.blk, x, prev, False, False, want_tape=False)
+    close(ye, g[name + ".y_eval"], what="y_eval")
+
+
+def test_deepwt_vs_golden(golden_dir):
+    import algorithms
+    g = np.load(os.path.join(golden_dir, "blocks.npz"))
+    m = algorithms.WT_PSE(3, 1, HP, DEV, False, per_domain_batch=1).to(DEV)
+    fill_state_dict(m.wt_model, SEED_W + 30)
+    x = make_noise(310, (4, 3, 16, 16)).to(DEV)
+    zs = m.wt_model.forward(x)
+    for i, z in enumerate(zs):
+        close(z, g[f"deepwt.z{i + 1}"], rtol=1e-4, atol=2e-5, what=f"z{i + 1}")
+    fill_state_dict(m.attention_layer, SEED_W + 31)
+    a, pre = m.attention_layer.forward(make_noise(311, (4, 1, 16, 16)).to(DEV))
+    close(a, g["attention.sig"], atol=1e-5); close(pre, g["attention.pre"], atol=1e-5)
+
+
+# ---------------------------------------------------------------- a-7 / a-8 / a-9 through the public API + torch autograd
+@pytest.mark.parametrize("ci", [0, 1, 2])
+def test_network_calls_vs_golden(golden_dir, ci):
+    g = np.load(os.path.join(golden_dir, "network.npz"))
+    B, pb, H, s_in, s_a, s_t, s_s = (int(v) for v in g["cases"][ci])
+    p = f"c{ci}_"
+    img, od, oc = (t.to(DEV) for t in make_inputs(s_in, B, H, H))
+    main, shape, main_oc, shape_oc = build_nets(pb)
+    for m in (main, shape, main_oc, shape_oc):
+        m.eval()
+    with torch.no_grad():
+        logit, att = main.predict(shape, img)
+        roi = (img + 1) * (torch.sigmoid(logit) > 0.75).float() - 1
+        logit2, att2 = main_oc.predict(shape_oc, torch.stack((roi, roi), 0))
+    close(logit, g[p + "pred_logit"], atol=TOL, what="pred_logit")
+    close(att, g[p + "pred_att"], atol=TOL, what="pred_att")
+    close(logit2, g[p + "pred2_logit"], atol=TOL, what="pred2_logit")
+    close(att2, g[p + "pred2_att"], atol=TOL, what="pred2_att")
+    # call A through update() + autograd, loss glue in torch exactly as Trainer.py:787-804 does it
+    main.train(); shape.train()
+    main.zero_grad()
+    main.set_noise([make_noise(s_a, (B, 1, H, H))])
+    out, m1, m2, ins, dom = main.update(img, od, two_stage_inputs=img, sp_mask=od, two_step=True)
+    loss = F.binary_cross_entropy(torch.sigmoid(out), od) + ins + dom
+    loss.backward()
+    close(out, g[p + "upd_out"], atol=TOL, what="upd_out")
+    assert float((m1.cpu() != torch.from_numpy(g[p + "upd_mask"])).float().mean()) < 1e-3
+    close(ins, g[p + "upd_ins"], rtol=1e-4, atol=1e-6, what="ins")
+    close(dom, g[p + "upd_dom"], rtol=1e-3, atol=3e-7, what="dom")
+    close(loss, g[p + "upd_loss"], rtol=1e-4, atol=1e-5, what="loss")
+    check_grads_vs_checksums(main, g, p + "upd_g.", 100)
+    for k, b in main.named_buffers():
+        close(O.checksum(b.float().cpu()), g[p + "upd_buf." + k], rtol=1e-4, atol=1e-4, what=k)
+    # call B
+    shape.zero_grad(); main.zero_grad()
+    kd, ins_t, ins_off, ins_diag, dom_s = shape.update(main, img, od, two_stage_inputs=img, two_step=True)
+    (kd + ins_t + dom_s).backward()
+    close(kd, g[p + "shp_kd"], rtol=1e-3, atol=1e-5, what="kd")
+    close(ins_t, g[p + "shp_ins_total"], rtol=1e-4, atol=1e-6)
+    close(ins_off, g[p + "shp_ins_off"], rtol=1e-4, atol=1e-6)
+    close(ins_diag, g[p + "shp_ins_diag"], rtol=1e-4, atol=1e-6)
+    close(dom_s, g[p + "shp_dom"], rtol=1e-3, atol=3e-7)
+    check_grads_vs_checksums(shape, g, p + "shp_g.", 50)
+    assert all(q.grad is None for q in shape.logvar_prior.parameters())     # never reached, as in the reference
+    assert all(q.grad is None for q in main.parameters())                   # teacher backward skipped
+
+
+def test_seg_only_vs_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "network.npz"))
+    main, _, _, _ = build_nets(2, full=False)
+    img, od, _ = (t.to(DEV) for t in make_inputs(650, 6, 32, 32))
+    main.train()
+    out = main.update(img, od, two_stage_inputs=img, two_step=True)
+    assert out[1:] == (0, 0, 0, 0)
+    F.binary_cross_entropy(torch.sigmoid(out[0]), od).backward()
+    close(out[0], g["segonly_out"], atol=TOL)
+    check_grads_vs_checksums(main, g, "segonly_g.", 40)
+    main.eval()
+    with torch.no_grad():
+        pred, none = main.predict(None, img)
+    assert none is None
+    close(pred, g["segonly_pred"], atol=TOL)
+
+
+# ---------------------------------------------------------------- a-11: full A-D iterations
+def _iteration_inputs(g):
+    B, pb, H, iters, s_in, s_n = (int(v) for v in g["meta"])
+    for it in range(iters):
+        img, od, oc = make_inputs(s_in + it, B, H, H)
+        nz = {k: make_noise(s_n + 10 * it + j, (B, 1, H, H)) for j, k in enumerate(["a", "b_t", "b_s", "c", "d_t", "d_s"])}
+        yield it, img, od, oc, nz
+
+
+def _check_params_vs_golden(nets, g):
+    for tag, net in zip(["od", "shape_od", "oc", "shape_oc"], nets):
+        for k, v in net.state_dict().items():
+            if is_prebn_bias(k):
+                continue
+            ref = g[f"{tag}.{k}"]
+            got = O.checksum(v.float().cpu())
+            err = np.abs(got - ref)
+            tol = 1e-4 * np.abs(ref) + 6e-5 * max(1.0, min(v.numel(), 32) ** 0.5)
+            assert (err <= tol).all(), f"{tag}.{k}: {err.max():.3e}"
+
+
+def test_iterations_harness_vs_golden(golden_dir):
+    """The fused step harness (HIP losses + flat Adam) over 3 iterations against the reference's own trajectory."""
+    from wtpse_hip.step import TrainStep
+    g = np.load(os.path.join(golden_dir, "iteration.npz"))
+    pb = int(g["meta"][1])
+    main, shape, main_oc, shape_oc = build_nets(pb)
+    ts = TrainStep(main, shape, main_oc, shape_oc, HP)
+    keys = [str(k) for k in g["loss_keys"]]
+    for it, img, od, oc, nz in _iteration_inputs(g):
+        res = ts.step(img.to(DEV), od.to(DEV), oc.to(DEV), {"a": nz["a"], "c": nz["c"]})
+        for j, k in enumerate(keys):
+            if k not in res:
+                continue           # main_od / shape_od ... are sums formed by the caller
+            tol = dict(rtol=1e-3, atol=5e-7) if k.startswith("dom") else dict(rtol=3e-4, atol=2e-5)
+            close(res[k], g["losses"][it][j], what=f"it{it}.{k}", **tol)
+    _check_params_vs_golden([main, shape, main_oc, shape_oc], g)
+
+
+def test_iterations_dropin_vs_golden(golden_dir):
+    """Same trajectory through the reference's own calling convention: update() -> torch loss glue -> .backward()
+    -> torch.optim.Adam, i.e. what the unchanged Trainer.py does (Trainer.py:766-914)."""
+    g = np.load(os.path.join(golden_dir, "iteration.npz"))
+    pb = int(g["meta"][1])
+    nets = build_nets(pb)
+    model, model_shape, model_oc, model_shape_oc = nets
+    opts = [torch.optim.Adam(n.parameters(), lr=5e-4, betas=(0.9, 0.99)) for n in nets]
+    optim, optim_shape, optim_oc, optim_shape_oc = opts
+    bce = torch.nn.BCELoss()
+    keys = [str(k) for k in g["loss_keys"]]
+    for n in nets:
+        n.train()
+    for it, image, target_od, target_oc, nz in _iteration_inputs(g):
+        image, target_od, target_oc = image.to(DEV), target_od.to(DEV), target_oc.to(DEV)
+        res = {}
+        optim.zero_grad(); model.zero_grad()
+        model.set_noise([nz["a"]])
+        output, _, _, ins, dom = model.update(image, target_od, two_stage_inputs=image, sp_mask=target_od, two_step=True)
+        loss_seg = bce(torch.sigmoid(output), target_od)
+        loss_main = loss_seg + HP["instance_wt_gm"] * ins + HP["domain_wt_gm"] * dom
+        loss_main.backward(); optim.step()
+        res.update(seg_od=loss_seg, ins_od=ins, dom_od=dom, main_od=loss_main)
+        optim_shape.zero_grad(); model_shape.zero_grad()
+        kd, ins_t, ins_ij, ins_ii, dom_s = model_shape.update(model, image, target_od, two_stage_inputs=image, two_step=True)
+        loss_shape = kd + HP["instance_wt_gm"] * ins_t + HP["domain_wt_gm"] * dom_s
+        loss_shape.backward(); optim_shape.step()
+        res.update(kd_od=kd, ins_shape_od=ins_t, ins_ij_od=ins_ij, ins_ii_od=ins_ii, dom_shape_od=dom_s, shape_od=loss_shape)
+        od_pred = (torch.sigmoid(output) > 0.75).float().detach().float()
+        optim_oc.zero_grad(); model_oc.zero_grad()
+        image += 1
+        image_roi = image * od_pred
+        image_roi -= 1
+        model_oc.set_noise([nz["c"]])
+        output_oc, _, _, ins_c, dom_c = model_oc.update(image_roi, target_oc, two_stage_inputs=image_roi, two_step=True)
+        pw = torch.sum(od_pred) / torch.sum(od_pred * target_oc)
+        if torch.isinf(pw) or torch.isnan(pw):
+            pw = torch.tensor(1.).to(DEV)
+        loss_seg_oc = F.binary_cross_entropy_with_logits(output_oc * od_pred, target_oc, pos_weight=pw)
+        loss_main_oc = loss_seg_oc + HP["instance_wt_gm"] * ins_c + HP["domain_wt_gm"] * dom_c
+        loss_main_oc.backward(); optim_oc.step()
+        res.update(seg_oc=loss_seg_oc, ins_oc=ins_c, dom_oc=dom_c, main_oc=loss_main_oc)
+        optim_shape_oc.zero_grad(); model_shape_oc.zero_grad()
+        kd2, ins_t2, _, _, dom_s2 = model_shape_oc.update(model_oc, image_roi, target_oc, two_stage_inputs=image_roi, two_step=True)
+        loss_shape_oc = kd2 + HP["instance_wt_gm"] * ins_t2 + HP["domain_wt_gm"] * dom_s2
+        loss_shape_oc.backward(); optim_shape_oc.step()
+        res.update(kd_oc=kd2, ins_shape_oc=ins_t2, dom_shape_oc=dom_s2, shape_oc=loss_shape_oc)
+        for j, k in enumerate(keys):
+            tol = dict(rtol=1e-3, atol=5e-7) if k.startswith("dom") else dict(rtol=3e-4, atol=2e-5)
+            close(res[k], g["losses"][it][j], what=f"it{it}.{k}", **tol)
+    _check_params_vs_golden(nets, g)
+
+
+# ---------------------------------------------------------------- full-resolution checks against the oracle (no fixture)
+def test_update_256_vs_oracle():
+    """256x256 (BASELINE.json's resolution), B=6: logits, WT-loss values and Dice of the thresholded prediction
+    against the CPU oracle on the same inputs — the 1e-4 bar of north_star."""
+    B, pb, H = 6, 2, 256
+    img, od, oc = make_inputs(77, B, H, H)
+    eps = make_noise(78, (B, 1, H, H))
+    main, shape, _, _ = build_nets(pb)
+    sd_main = {k: v.detach().cpu().clone() for k, v in main.state_dict().items()}
+    sd_shape = {k: v.detach().cpu().clone() for k, v in shape.state_dict().items()}
+    main.train()
+    main.set_noise([eps])
+    with torch.no_grad():
+        out, _, _, ins, dom = main.update(img.to(DEV), od.to(DEV), two_stage_inputs=img.to(DEV), two_step=True)
+        ref_out, _, _, ref_ins, ref_dom = O.wt_pse_update(dict(sd_main), HP, img, od, img, True, eps, 3, pb)
+    close(out, ref_out, atol=TOL, what="logits@256")
+    close(ins, ref_ins, rtol=1e-4, atol=1e-6, what="ins@256")
+    close(dom, ref_dom, rtol=1e-3, atol=1e-6, what="dom@256")
+    main.eval(); shape.eval()
+    with torch.no_grad():
+        pred, _ = main.predict(shape, img.to(DEV))
+        ref_pred, _ = O.wt_pse_predict(sd_main, sd_shape, HP, img, False)
+    close(pred, ref_pred, atol=TOL, what="predict@256")
+    for b in range(B):
+        d_hip = O.dice_coefficient((torch.sigmoid(pred[b, 0]) > 0.75).cpu().numpy(), od[b, 0].numpy())
+        d_ref = O.dice_coefficient((torch.sigmoid(ref_pred[b, 0]) > 0.75).numpy(), od[b, 0].numpy())
+        assert abs(d_hip - d_ref) <= 1e-4, (b, d_hip, d_ref)
+
+
+def test_wt_loss_full_size_properties():
+    """[32,16,256,256] (BASELINE.json configs[1..2]): value against the oracle, scale law G(a z) = a^2 G(z)
+    (checked on the off-diagonal sum, margin 0), and the adjoint identity <dL/dz, z> = 2 * sum_b <dL/dG_b, G_b - eps I>."""
+    from wtpse_hip import ops
+    B, pb = 32, 10
+    g = torch.Generator().manual_seed(5)
+    z = torch.randn(B, 16, 256, 256, generator=g) * 0.5
+    zd = z.to(DEV)
+    st = ops.wt_loss_fwd(zd, 3, pb, 0.0)
+    off, dg, dom = O.whitening_loss(z, 3, pb, 0.0)
+    close(st.losses[0], off, rtol=1e-4, atol=1e-7, what="off")
+    close(st.losses[1], dg, rtol=1e-4, atol=1e-7, what="diag")
+    close(st.losses[2], dom, rtol=2e-3, atol=1e-6, what="dom")
+    st2 = ops.wt_loss_fwd((zd * 2.0).contiguous(), 3, pb, 0.0)
+    close(st2.offdiag, st.offdiag * 4.0, rtol=1e-4, atol=1e-7, what="scale law")
+    dz = torch.empty_like(zd)
+    ops.wt_loss_bwd(st, dz, False, w_dom=0.0)
+    # L = mean_b off_b/120 + mean_b diag_b/16 with G linear in z z^T: <dL/dz, z> = 2 <dL/dG, z z^T/(HW-1)>
+    G = st.gram.view(B, 16, 16).double().cpu()
+    eye = torch.eye(16, dtype=torch.float64)
+    Gz = G - 1e-5 * eye
+    triu = torch.ones(16, 16, dtype=torch.float64).triu(1)
+    dG = torch.sign(G) * triu / (120.0 * B) + torch.sign(G - eye) * eye / (16.0 * B)
+    rhs = 2.0 * (dG * Gz).sum()
+    lhs = (dz.double() * zd.double()).sum().cpu()
+    assert abs(float(lhs - rhs)) <= 1e-4 * abs(float(rhs)) + 1e-7, (float(lhs), float(rhs))

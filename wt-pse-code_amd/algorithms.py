@@ -1,0 +1,251 @@
+"""Drop-in for the reference's ``algorithms.py`` on MI355X: same module name, same ``get_algorithm_class`` lookup,
+same ``WT_PSE`` constructor / ``update()`` / ``predict()`` signature and returns, same ``state_dict`` keys
+(reference algorithms.py:21-25, 1134-1353; consumed by train.py:82-98 and Trainer.py:779,856,170,182).
+
+Underneath, every operation is a hand-written gfx950 kernel reached through the C ABI of libwtpse_hip.so
+(include/wtpse_hip.h); torch provides device memory, the stream and one autograd node per ``update()``.
+There is no CPU path: modules must live on a HIP device.
+
+Only the reachable configuration space of the reference is supported: ``shape_prior`` and ``whitening`` both on
+(the WT-PSE method) or both off (plain segmentation U-Net, BASELINE.json configs[1]); the mixed settings crash in
+the reference itself.
+"""
+import torch
+import torch.nn as nn
+
+from wtpse_hip import nn as E
+from wtpse_hip import ops
+
+__all__ = ["get_algorithm_class", "WT_PSE", "compute_MMD"]
+
+
+def get_algorithm_class(algorithm_name):
+    """Return the algorithm class with the given name (reference algorithms.py:21-25)."""
+    if algorithm_name not in globals():
+        raise NotImplementedError("Algorithm not found: {}".format(algorithm_name))
+    return globals()[algorithm_name]
+
+
+class compute_MMD(object):
+    """Pairwise Gaussian-kernel MMD over contiguous domain row blocks (reference algorithms.py:59-121)."""
+
+    def __init__(self, domain_num, batch_size):
+        self.domain_num = domain_num
+        self.batch_size = batch_size
+        self.kernel_type = "gaussian"
+
+    def forward(self, inputs, **kwargs):
+        v = inputs.contiguous()
+        R = self.domain_num * self.batch_size
+        rowval = torch.empty((R,), dtype=torch.float64, device=v.device)
+        dv = torch.empty((R, 120), dtype=torch.float32, device=v.device)
+        ops.lib().call("wtpse_mmd_fwd", v.data_ptr(), self.domain_num, self.batch_size, rowval.data_ptr(), dv.data_ptr(),
+                       ops.stream_ptr())
+        out = torch.empty((1,), dtype=torch.float32, device=v.device)
+        tmp = rowval.to(torch.float32).reshape(R, 1).contiguous()
+        ops.lib().call("wtpse_reduce_rows", tmp.data_ptr(), R, 1, out.data_ptr(), 0, 1.0, ops.stream_ptr())
+        return out[0]
+
+
+class _UpdateFn(torch.autograd.Function):
+    """One autograd node per WT_PSE.update(): forward runs the fused schedule and keeps a tape, backward replays it."""
+
+    @staticmethod
+    def forward(ctx, anchor, net, inputs, mask, wt_inputs):
+        res, tape = net._forward_update(inputs, mask, wt_inputs, want_tape=True)
+        ctx.net, ctx.tape = net, tape
+        if tape.shape_prior:
+            out, att_mask, scal = res
+            ctx.mark_non_differentiable(att_mask)
+            return out, att_mask, scal[0], scal[3]
+        return res[0]
+
+    @staticmethod
+    def backward(ctx, d_out, *rest):
+        d_ins = rest[1] if len(rest) > 1 else None
+        d_dom = rest[2] if len(rest) > 2 else None
+        # a missing upstream gradient means the caller's loss does not use that output: weight 0
+        ctx.net._backward_update(ctx.tape, d_out, d_ins, d_dom, w_ins=0.0 if d_ins is None else 1.0,
+                                 w_dom=0.0 if d_dom is None else 1.0)
+        ctx.tape = None
+        return None, None, None, None, None
+
+
+class WT_PSE(E.HipNet, E.UNetBody):
+    def __init__(self, n_channels, n_classes, hparams, device, two_step, per_domain_batch=8, source_domain_num=3,
+                 feature_dim=8, bilinear=True):
+        super(WT_PSE, self).__init__()
+        self.n_channels = n_channels
+        self.n_classes = n_classes
+        self.device = device
+        self.hparams = hparams
+        self.two_step = two_step
+        self.per_domain_batch = per_domain_batch
+        self.number_source_domain = source_domain_num
+        self.num_domains = 3
+        self.feature_dim = feature_dim
+        self.bilinear = bilinear
+        self.eps = 1e-5
+        self.dim = 16
+        self.whitening = hparams['whitening']
+        self.start_shape_step = hparams['shape_start']
+        self.cat_shape = hparams['cat_shape']
+        self.margin = hparams['margin']
+        self.mmd_operator = compute_MMD(domain_num=source_domain_num, batch_size=per_domain_batch)
+        if bool(hparams['shape_prior']) != bool(hparams['whitening']):
+            raise NotImplementedError("shape_prior and whitening must be switched together (the mixed settings fail in "
+                                      "the reference: algorithms.py:994,1022-1023,1235)")
+        if self.cat_shape or not hparams['shape_attention']:
+            raise NotImplementedError("only the reference defaults cat_shape=False, shape_attention=True are built")
+        n = 16
+        # registration order == reference state_dict order (algorithms.py:1161-1204)
+        if self.whitening:
+            self.wt_model = E.DeepWTP(3, n)
+        self.inc = E.ConvDBlock(n_channels, n, first=True)
+        self._make_body(n)
+        if hparams['shape_prior']:
+            self.prior_dist = E.TeacherP(n)
+        self.mu = E.Seq(_0=E.ConvP(2 * n, 2 * n, 1), _2=E.ConvP(2 * n, feature_dim, 1))
+        self.outc = E.Seq(_0=E.ConvP(feature_dim, n_classes, 1))
+        self.attention_layer = E.AttentionP()
+        self.global_step = 0
+        self._finish_init()
+
+    # ------------------------------------------------------------------------------------------------ public API
+    def update(self, inputs, mask, step=0, plot_show=0, two_stage_inputs=None, sp_mask=None, two_step=False):
+        """Reference algorithms.py:1216-1275.  Returns (logits, att_mask, att_mask, ins_wt_loss, dom_wt_loss)."""
+        self.ensure_ready(repack=True)
+        inputs = self._as_input(inputs)
+        mask = self._as_input(mask)
+        wt_in = self._as_input(two_stage_inputs) if (two_step and two_stage_inputs is not None) else inputs
+        if torch.is_grad_enabled():
+            res = _UpdateFn.apply(self._get_anchor(), self, inputs, mask, wt_in)
+            if self.hparams['shape_prior']:
+                out, att_mask, ins, dom = res
+                return out, att_mask, att_mask, ins, dom
+            return res, 0, 0, 0, 0
+        res, _ = self._forward_update(inputs, mask, wt_in, want_tape=False)
+        if self.hparams['shape_prior']:
+            out, att_mask, scal = res
+            return out, att_mask, att_mask, scal[0], scal[3]
+        return res[0], 0, 0, 0, 0
+
+    def predict(self, learn_x_network, inputs_all):
+        """Reference algorithms.py:1311-1353 (uses the STUDENT's wt_model and shape net). -> (logits, pre-sigmoid attention)."""
+        self.ensure_ready(repack=True)
+        if self.two_step:
+            inputs, wt_in = self._as_input(inputs_all[0]), self._as_input(inputs_all[1])
+        else:
+            inputs = wt_in = self._as_input(inputs_all)
+        training = self.training
+        emb = self._embedding(inputs, training, None)
+        if not self.hparams['shape_prior']:
+            out, _ = E._conv(self.outc[0], emb)
+            return out, None
+        learn_x_network.ensure_ready(repack=True)
+        w = E.deepwt_fwd(learn_x_network.wt_model, wt_in, want_tape=False)
+        z = learn_x_network._student_mu(w.z2, True, learn_x_network.training, None)
+        _, pre, _, fuse = ops.attn_fuse_fwd(z, self.attention_layer.layer1.weight.data_ptr(), emb,
+                                            float(self.hparams['shape_attention_coeffient']), False, True, False)
+        out, _ = E._conv(self.outc[0], fuse)
+        return out, pre
+
+    def forward(self, x):
+        return self.predict(x)
+
+    def compute_whitening_loss(self, z):
+        """Reference algorithms.py:1277-1309 -> (instance_loss, domain_loss); forward values only."""
+        st = ops.wt_loss_fwd(z.contiguous(), self.number_source_domain, self.per_domain_batch, self.margin, self.eps)
+        comb = ops.wt_combine(st.losses.view(1, 3), 1.0, 0)
+        return comb[0], comb[3]
+
+    # ------------------------------------------------------------------------------------------------ schedules
+    def _as_input(self, t):
+        if not t.is_cuda:
+            raise RuntimeError("WT_PSE on MI355X takes device tensors (got %s)" % t.device)
+        return t.detach().to(torch.float32).contiguous()
+
+    def _get_anchor(self):
+        a = self.__dict__.get("_anchor")
+        if a is None or a.device != self._flat.device:
+            a = torch.zeros(1, device=self._flat.device, requires_grad=True)
+            object.__setattr__(self, "_anchor", a)
+        return a
+
+    def _embedding(self, inputs, training, tape):
+        want = tape is not None
+        x1, c_inc = E.convd_fwd(self.inc, inputs, False, training, want)
+        feat, c_unet = E.unet_fwd(self, x1, False, training, want)
+        emb, c_mu = E.head_fwd(self.mu, feat, (0, 2), want)
+        if want:
+            tape.inc, tape.unet, tape.mu = c_inc, c_unet, c_mu
+        return emb
+
+    def _forward_update(self, inputs, mask, wt_in, want_tape):
+        hp = self.hparams
+        t = E.Tape()
+        t.shape_prior = bool(hp['shape_prior'])
+        training = self.training
+        emb = self._embedding(inputs, training, t if want_tape else None)
+        if not t.shape_prior:
+            out, _ = E._conv(self.outc[0], emb)
+            t.emb = emb
+            return (out,), t
+        coef = float(hp['shape_attention_coeffient'])
+        w = E.deepwt_fwd(self.wt_model, wt_in, want_tape)
+        th = E.teacher_fwd(self.prior_dist, w.z2, True, mask, training, True, want_tape)
+        eps = self.next_noise(th.mu.shape)
+        z_post = ops.reparam_fwd(th.mu, th.logvar, eps)
+        att, _, att_mask, fuse = ops.attn_fuse_fwd(z_post, self.attention_layer.layer1.weight.data_ptr(), emb, coef,
+                                                   True, False, True)
+        # WT loss on the first two maps, divided by len([z1, z2, relu(z2)]) = 3 (algorithms.py:1259-1267)
+        losses = torch.empty((2, 3), dtype=torch.float32, device=inputs.device)
+        D, n = self.number_source_domain, self.per_domain_batch
+        st1 = self._wt_loss(w.z1, D, n, losses[0])
+        st2 = self._wt_loss(w.z2, D, n, losses[1])
+        scal = ops.wt_combine(losses, 3.0, 0)
+        out, _ = E._conv(self.outc[0], fuse)
+        if want_tape:
+            t.w, t.th, t.eps, t.z_post, t.att, t.emb, t.fuse, t.st1, t.st2, t.coef = w, th, eps, z_post, att, emb, fuse, st1, st2, coef
+        return (out, att_mask, scal), t
+
+    def _wt_loss(self, z, D, n, losses_out):
+        if self._dp is not None:
+            return self._dp.wt_loss_fwd(z, D, n, float(self.margin), self.eps, losses_out)
+        return ops.wt_loss_fwd(z, D, n, float(self.margin), self.eps, losses_out)
+
+    def _wt_loss_bwd(self, st, dz, **kw):
+        if self._dp is not None:
+            return self._dp.wt_loss_bwd(st, dz, True, **kw)
+        return ops.wt_loss_bwd(st, dz, True, **kw)
+
+    def _backward_update(self, t, d_out, d_ins=None, d_dom=None, w_ins=1.0, w_dom=1.0):
+        """d_out: gradient wrt the logits; d_ins / d_dom: device scalars (None -> 1) scaled by the host weights
+        w_ins / w_dom (0 disables a term).  Writes the parameter gradients into the flat gradient buffer."""
+        self.begin_backward()
+        if d_out is None:
+            d_out = ops.zero_(torch.empty((t.emb.shape[0], self.n_classes) + tuple(t.emb.shape[2:]), dtype=torch.float32, device=t.emb.device))
+        d_out = d_out.contiguous()
+        outc = self.outc[0]
+        if not t.shape_prior:
+            E._wgrad(outc, d_out, t.emb)
+            demb, _ = E._dgrad(outc, d_out)
+        else:
+            E._wgrad(outc, d_out, t.fuse)
+            dfuse, _ = E._dgrad(outc, d_out)
+            al = self.attention_layer.layer1
+            d_wb = self.gview(al.weight)
+            self.gview(al.bias)
+            demb, dz_post = ops.attn_fuse_bwd(dfuse, t.z_post, t.emb, t.att, al.weight.data_ptr(), t.coef, d_wb.data_ptr(), True)
+            dlogvar = ops.reparam_bwd(dz_post, t.th.logvar, t.eps)
+            d_relu_z2 = E.teacher_bwd(self.prior_dist, t.th, dz_post, dlogvar)
+            dz2 = ops.relu_mask(d_relu_z2, t.w.z2)
+            gi = d_ins.contiguous() if d_ins is not None else None
+            gd = d_dom.contiguous() if d_dom is not None else None
+            kw = dict(g_off=gi, g_diag=gi, g_dom=gd, w_off=w_ins / 3.0, w_diag=w_ins / 3.0, w_dom=w_dom / 3.0)
+            self._wt_loss_bwd(t.st2, dz2, **kw)
+            E.deepwt_bwd(self.wt_model, t.w, dz2, lambda dz1: self._wt_loss_bwd(t.st1, dz1, **kw))
+        dfeat = E.head_bwd(self.mu, t.mu, demb, (0, 2))
+        dx1 = E.unet_bwd(self, t.unet, dfeat)
+        E.convd_bwd(self.inc, t.inc, dx1, need_dx=False)
+        self.end_backward()

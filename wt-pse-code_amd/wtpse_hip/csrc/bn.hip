@@ -1,0 +1,233 @@
+// Train-/eval-mode BatchNorm2d pieces (nn.BatchNorm2d, eps 1e-5, momentum 0.1, affine — reference
+// algorithms.py:862-864 via ConvD/ConvU/DoubleConv).  The convolution epilogue already produced per-workgroup
+// (sum, sum of squares) partials; these kernels turn them into the per-channel (scale, shift) pair that
+// consumers apply on load, keep the running statistics, and run the two-reduction backward.
+//
+//   forward : y = conv output, mean/var over (B,H,W);  z = act(y * scale + shift), scale = gamma*invstd, shift = beta - mean*scale
+//   backward: dzh = dz * [z > 0];  dbeta = sum dzh;  dgamma = sum dzh * xhat;  dy = k1*dzh + k2*y + k3
+//             k1 = gamma*invstd,  k2 = -gamma*invstd^2*dgamma/N,  k3 = -k1*dbeta/N - k2*mean
+#include "common.h"
+
+// one 64-lane workgroup per channel; partial sums are folded in fp64 in a fixed order
+__global__ __launch_bounds__(64) void bn_finalize_k(const float* __restrict__ part, int nblk, int C, double count,
+                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                    float* __restrict__ rmean, float* __restrict__ rvar,
+                                                    long long* __restrict__ nbt, float momentum, float eps,
+                                                    float* __restrict__ scale_shift, float* __restrict__ save_mean,
+                                                    float* __restrict__ save_invstd) {
+  const int c = blockIdx.x, t = threadIdx.x;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = t; k < nblk; k += 64) {
+    s1 += part[((size_t)k * C + c) * 2];
+    s2 += part[((size_t)k * C + c) * 2 + 1];
+  }
+  for (int m = 1; m < 64; m <<= 1) {
+    s1 += __shfl_xor(s1, m, 64);
+    s2 += __shfl_xor(s2, m, 64);
+  }
+  if (t == 0) {
+    double mean = s1 / count;
+    double var = s2 / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    double invstd = 1.0 / sqrt(var + (double)eps);
+    float sc = (float)(gamma[c] * invstd);
+    scale_shift[2 * c] = sc;
+    scale_shift[2 * c + 1] = (float)(beta[c] - mean * gamma[c] * invstd);
+    save_mean[c] = (float)mean;
+    save_invstd[c] = (float)invstd;
+    if (rmean) {
+      double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+      rmean[c] = (float)((1.0 - momentum) * rmean[c] + momentum * mean);
+      rvar[c] = (float)((1.0 - momentum) * rvar[c] + momentum * unbiased);
+    }
+    if (nbt && c == 0) *nbt += 1;
+  }
+}
+
+__global__ void bn_eval_coeffs_k(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                 const float* __restrict__ rmean, const float* __restrict__ rvar, float eps, int C,
+                                 float* __restrict__ scale_shift) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float invstd = 1.f / sqrtf(rvar[c] + eps);
+  float sc = gamma[c] * invstd;
+  scale_shift[2 * c] = sc;
+  scale_shift[2 * c + 1] = beta[c] - rmean[c] * sc;
+}
+
+// z = act(y*scale[c] + shift[c]); grid = (blocks over HW, B*C)
+template <bool VEC>
+__global__ __launch_bounds__(256) void affine_act_k(const float* __restrict__ y, const float* __restrict__ ss, int relu,
+                                                    int C, int HW, int bpp, float* __restrict__ z) {
+  const int bc = blockIdx.x / bpp, blk = blockIdx.x - bc * bpp, c = bc % C;
+  const float sc = ss ? ss[2 * c] : 1.f, sh = ss ? ss[2 * c + 1] : 0.f;
+  const float lo = relu ? 0.f : -INFINITY;
+  const size_t base = (size_t)bc * HW;
+  if (VEC) {
+    int p = (blk * 256 + threadIdx.x) * 4;
+    if (p >= HW) return;
+    float4 v = *reinterpret_cast<const float4*>(y + base + p);
+    v.x = fmaxf(fmaf(v.x, sc, sh), lo); v.y = fmaxf(fmaf(v.y, sc, sh), lo);
+    v.z = fmaxf(fmaf(v.z, sc, sh), lo); v.w = fmaxf(fmaf(v.w, sc, sh), lo);
+    *reinterpret_cast<float4*>(z + base + p) = v;
+  } else {
+    int p = blk * 256 + threadIdx.x;
+    if (p >= HW) return;
+    z[base + p] = fmaxf(fmaf(y[base + p], sc, sh), lo);
+  }
+}
+
+// partial[(split*C + c)*2 + {0,1}] = sum over this split's elements of (dzh, dzh*xhat); grid = (C, nsplit)
+__global__ __launch_bounds__(256) void bn_bwd_reduce_k(const float* __restrict__ dz, const float* __restrict__ y,
+                                                       const float* __restrict__ ss, int relu,
+                                                       const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                       int B, int C, int HW, float* __restrict__ partial) {
+  __shared__ float sh[2][4];
+  const int c = blockIdx.x, split = blockIdx.y, nsplit = gridDim.y;
+  const float sc = ss[2 * c], sf = ss[2 * c + 1], mu = mean[c], is = invstd[c];
+  float s1 = 0.f, s2 = 0.f;
+  const long long total = (long long)B * HW;
+  for (long long e = (long long)split * 256 + threadIdx.x; e < total; e += (long long)nsplit * 256) {
+    int b = (int)(e / HW);
+    int p = (int)(e - (long long)b * HW);
+    size_t idx = ((size_t)b * C + c) * HW + p;
+    float yv = y[idx], g = dz[idx];
+    if (relu && !(fmaf(yv, sc, sf) > 0.f)) g = 0.f;
+    s1 += g;
+    s2 += g * (yv - mu) * is;
+  }
+  s1 = wave_xor_sum(s1, 32);
+  s2 = wave_xor_sum(s2, 32);
+  if ((threadIdx.x & 63) == 0) {
+    sh[0][threadIdx.x >> 6] = s1;
+    sh[1][threadIdx.x >> 6] = s2;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[((size_t)split * C + c) * 2] = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+    partial[((size_t)split * C + c) * 2 + 1] = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+  }
+}
+
+__global__ __launch_bounds__(64) void bn_bwd_finalize_k(const float* __restrict__ partial, int nsplit, int C, double count,
+                                                        const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                        const float* __restrict__ invstd, float* __restrict__ dgamma,
+                                                        float* __restrict__ dbeta, int accumulate,
+                                                        float* __restrict__ coef) {
+  const int c = blockIdx.x, t = threadIdx.x;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = t; k < nsplit; k += 64) {
+    s1 += partial[((size_t)k * C + c) * 2];
+    s2 += partial[((size_t)k * C + c) * 2 + 1];
+  }
+  for (int m = 1; m < 64; m <<= 1) {
+    s1 += __shfl_xor(s1, m, 64);
+    s2 += __shfl_xor(s2, m, 64);
+  }
+  if (t == 0) {
+    dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
+    dgamma[c] = accumulate ? dgamma[c] + (float)s2 : (float)s2;
+    double k1 = (double)gamma[c] * invstd[c];
+    double k2 = -(double)gamma[c] * invstd[c] * invstd[c] * s2 / count;
+    double k3 = -k1 * s1 / count - k2 * mean[c];
+    coef[3 * c] = (float)k1;
+    coef[3 * c + 1] = (float)k2;
+    coef[3 * c + 2] = (float)k3;
+  }
+}
+
+// dy = k1 * dz*[z>0] + k2*y + k3 ; grid = (blocks over HW, B*C)
+template <bool VEC>
+__global__ __launch_bounds__(256) void bn_bwd_apply_k(const float* __restrict__ dz, const float* __restrict__ y,
+                                                      const float* __restrict__ ss, int relu,
+                                                      const float* __restrict__ coef, int C, int HW, int bpp,
+                                                      float* __restrict__ dy) {
+  const int bc = blockIdx.x / bpp, blk = blockIdx.x - bc * bpp, c = bc % C;
+  const float sc = ss[2 * c], sf = ss[2 * c + 1];
+  const float k1 = coef[3 * c], k2 = coef[3 * c + 1], k3 = coef[3 * c + 2];
+  const size_t base = (size_t)bc * HW;
+  if (VEC) {
+    int p = (blk * 256 + threadIdx.x) * 4;
+    if (p >= HW) return;
+    float4 g = *reinterpret_cast<const float4*>(dz + base + p);
+    float4 v = *reinterpret_cast<const float4*>(y + base + p);
+    float4 o;
+    o.x = fmaf(k1, (relu && !(fmaf(v.x, sc, sf) > 0.f)) ? 0.f : g.x, fmaf(k2, v.x, k3));
+    o.y = fmaf(k1, (relu && !(fmaf(v.y, sc, sf) > 0.f)) ? 0.f : g.y, fmaf(k2, v.y, k3));
+    o.z = fmaf(k1, (relu && !(fmaf(v.z, sc, sf) > 0.f)) ? 0.f : g.z, fmaf(k2, v.z, k3));
+    o.w = fmaf(k1, (relu && !(fmaf(v.w, sc, sf) > 0.f)) ? 0.f : g.w, fmaf(k2, v.w, k3));
+    *reinterpret_cast<float4*>(dy + base + p) = o;
+  } else {
+    int p = blk * 256 + threadIdx.x;
+    if (p >= HW) return;
+    float g = dz[base + p], v = y[base + p];
+    if (relu && !(fmaf(v, sc, sf) > 0.f)) g = 0.f;
+    dy[base + p] = fmaf(k1, g, fmaf(k2, v, k3));
+  }
+}
+
+static inline bool vec_ok(int HW, const void* a, const void* b, const void* c) {
+  return HW % 4 == 0 && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & 15) == 0;
+}
+
+extern "C" int wtpse_bn_finalize(const float* stats_partial, int nblk, int C, long long count, const float* gamma,
+                                 const float* beta, float* running_mean, float* running_var, long long* num_batches,
+                                 float momentum, float eps, float* scale_shift, float* save_mean, float* save_invstd,
+                                 void* stream) {
+  WTPSE_REQUIRE(stats_partial && gamma && beta && scale_shift && save_mean && save_invstd && nblk > 0 && C > 0 && count > 0);
+  WTPSE_REQUIRE((running_mean == nullptr) == (running_var == nullptr));
+  hipLaunchKernelGGL(bn_finalize_k, dim3(C), dim3(64), 0, (hipStream_t)stream, stats_partial, nblk, C, (double)count,
+                     gamma, beta, running_mean, running_var, num_batches, momentum, eps, scale_shift, save_mean,
+                     save_invstd);
+  return wtpse_status();
+}
+
+extern "C" int wtpse_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                                    const float* running_var, float eps, int C, float* scale_shift, void* stream) {
+  WTPSE_REQUIRE(gamma && beta && running_mean && running_var && scale_shift && C > 0);
+  hipLaunchKernelGGL(bn_eval_coeffs_k, dim3(ceil_div(C, 64)), dim3(64), 0, (hipStream_t)stream, gamma, beta,
+                     running_mean, running_var, eps, C, scale_shift);
+  return wtpse_status();
+}
+
+extern "C" int wtpse_affine_act(const float* y, const float* scale_shift, int relu, float* z, int B, int C, int HW,
+                                void* stream) {
+  WTPSE_REQUIRE(y && z && B > 0 && C > 0 && HW > 0);
+  hipStream_t st = (hipStream_t)stream;
+  if (vec_ok(HW, y, z, nullptr))
+    hipLaunchKernelGGL(affine_act_k<true>, dim3(ceil_div(HW, 1024) * B * C), dim3(256), 0, st, y, scale_shift, relu, C, HW, ceil_div(HW, 1024), z);
+  else
+    hipLaunchKernelGGL(affine_act_k<false>, dim3(ceil_div(HW, 256) * B * C), dim3(256), 0, st, y, scale_shift, relu, C, HW, ceil_div(HW, 256), z);
+  return wtpse_status();
+}
+
+extern "C" int wtpse_bn_bwd_nsplit(int B, int C, int HW) {
+  long long per_c = (long long)B * HW;
+  int ns = (int)((per_c + 8191) / 8192);
+  int cap = 2048 / (C > 0 ? C : 1);
+  if (cap < 1) cap = 1;
+  if (ns > cap) ns = cap;
+  if (ns < 1) ns = 1;
+  return ns;
+}
+
+extern "C" int wtpse_bn_bwd(const float* dz, const float* y, const float* scale_shift, int relu, const float* gamma,
+                            const float* save_mean, const float* save_invstd, float* partial, float* coef,
+                            float* dgamma, float* dbeta, int accumulate, float* dy, int B, int C, int HW,
+                            void* stream) {
+  WTPSE_REQUIRE(dz && y && scale_shift && gamma && save_mean && save_invstd && partial && coef && dgamma && dbeta && dy);
+  WTPSE_REQUIRE(B > 0 && C > 0 && HW > 0);
+  hipStream_t st = (hipStream_t)stream;
+  const int ns = wtpse_bn_bwd_nsplit(B, C, HW);
+  hipLaunchKernelGGL(bn_bwd_reduce_k, dim3(C, ns), dim3(256), 0, st, dz, y, scale_shift, relu, save_mean, save_invstd, B,
+                     C, HW, partial);
+  hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(C), dim3(64), 0, st, partial, ns, C, (double)B * HW, gamma, save_mean,
+                     save_invstd, dgamma, dbeta, accumulate, coef);
+  if (vec_ok(HW, dz, y, dy))
+    hipLaunchKernelGGL(bn_bwd_apply_k<true>, dim3(ceil_div(HW, 1024) * B * C), dim3(256), 0, st, dz, y, scale_shift,
+                       relu, coef, C, HW, ceil_div(HW, 1024), dy);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_k<false>, dim3(ceil_div(HW, 256) * B * C), dim3(256), 0, st, dz, y, scale_shift,
+                       relu, coef, C, HW, ceil_div(HW, 256), dy);
+  return wtpse_status();
+}

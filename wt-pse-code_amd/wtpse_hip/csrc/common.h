@@ -1,0 +1,40 @@
+// Shared definitions for the WT-PSE gfx950 kernels.  CDNA4 only: wave = 64 lanes, fp32-input MFMA.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define WTPSE_OK 0
+#define WTPSE_EINVAL (-1)
+
+// Every launcher ends with this: launch errors (bad grid, missing code object) surface as a status code.
+static inline int wtpse_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? WTPSE_OK : (int)e;
+}
+
+#define WTPSE_REQUIRE(cond) \
+  do {                      \
+    if (!(cond)) return WTPSE_EINVAL; \
+  } while (0)
+
+// D = A*B + C on the matrix cores, exact fp32 (k-ordered fma chain).
+//   16x16x4 : lane l holds A[row l&15][k l>>4], B[k l>>4][col l&15]; D reg r -> row (l>>4)*4+r, col l&15
+//   32x32x2 : lane l holds A[row l&31][k l>>5], B[k l>>5][col l&31]; D reg r -> row (r&3)+8*(r>>2)+4*(l>>5), col l&31
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float wave_xor_sum(float v, int mask_hi) {
+  // butterfly over lane-xor masks 1..mask_hi (mask_hi = 8 -> groups of 16 lanes, 16 -> 32, 32 -> 64)
+  for (int m = 1; m <= mask_hi; m <<= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -1,0 +1,522 @@
+// Implicit-GEMM convolution (3x3 pad 1 / 1x1) on the fp32 matrix cores of gfx950, NCHW fp32.
+//
+// Replaces the stock nn.Conv2d dispatches of the reference hot path
+// (algorithms.py:882-888,926-933,404-424,991,1006-1012,1123,1199-1201 and their duplicates in
+// shape_networks.py) — forward, data gradient and weight gradient.
+//
+// GEMM orientation is chosen for NCHW: D[cout][pixel] = sum_k W[cout][k] * X[k][pixel], k = (cin, tap).
+// The MFMA result then has pixels on lanes and output channels in registers, so every store
+// instruction writes runs of contiguous pixels of one channel plane.
+//   * Cout <= 16           : v_mfma_f32_16x16x4_f32, wave tile 16 cout x 64 pixels   (MODE 0)
+//   * Cout multiple of 32  : v_mfma_f32_32x32x2_f32, wave tile 32|64 cout x 64 pixels (MODE 1|2)
+// A workgroup (4 waves) owns a TH x TW = 256-pixel spatial tile of one image and one cout block;
+// input channels are streamed through LDS in chunks (halo tile [KC][TH+2][TW+2] + weight slab
+// [KC*taps][CB]).  Several workgroups per CU overlap one another's load and MFMA phases.
+//
+// Fusions available in the loader/epilogue (all optional):
+//   loader   : virtual channel concat of two inputs (torch.cat at algorithms.py:955,1018 never materialises),
+//              per-channel affine (BatchNorm apply) + ReLU on the way into LDS
+//   epilogue : + bias, ReLU, per-channel (sum, sum of squares) partials for train-mode BatchNorm statistics,
+//              channel split of the result into two tensors (data gradient of a concat)
+// The data gradient is the same kernel run on dY with tap-flipped, transposed weights (see pack kernel).
+#include "common.h"
+
+struct ConvArgs {
+  const float* in0;
+  const float* in1;
+  const float* wp;     // packed weights [CinP][taps][CoutP]
+  const float* bias;   // [Cout] or null
+  const float* pro;    // [Cin][2] (scale, shift) applied to the input on load, or null
+  float* out0;
+  float* out1;
+  float* stats;        // [gridDim.x][Cout][2] or null
+  int B, H, W;
+  int C0, C1, Cin, CinP;
+  int Cout, CoutP, Csplit;
+  int pro_relu;        // bit0: ReLU on in0 after the affine, bit1: on in1
+  int relu_out;
+  int tiles_x, tiles_y;
+};
+
+template <bool P16> struct AccT { typedef f32x16 type; };
+template <> struct AccT<true> { typedef f32x4 type; };
+__device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) { return mfma16(a, b, c); }
+__device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) { return mfma32(a, b, c); }
+
+template <int PE>
+struct PlaneStride {  // smallest S >= PE with S % 32 == 16: the four k-planes a 16x16x4 B-read touches land on disjoint banks
+  static constexpr int value = ((PE - 16 + 31) / 32) * 32 + 16;
+};
+
+template <int KS, int MODE, int TWL>
+__global__ __launch_bounds__(256) void conv_fwd_k(ConvArgs a) {
+  constexpr int TAPS = KS * KS, PAD = KS / 2;
+  constexpr int TW = 1 << TWL, TH = 256 / TW;
+  constexpr int PITCH = TW + 2 * PAD, ROWS = TH + 2 * PAD;
+  constexpr int PE = PITCH * ROWS;
+  constexpr int S = PlaneStride<PE>::value;
+  constexpr bool P16 = (MODE == 0);
+  constexpr int MT = P16 ? 1 : MODE;
+  constexpr int MB = P16 ? 16 : 32;
+  constexpr int CB = MB * MT;
+  constexpr int NT = P16 ? 4 : 2;
+  constexpr int NB = P16 ? 16 : 32;
+  constexpr int KC = P16 ? 16 : 8;
+  constexpr int KQ = P16 ? 4 : 2;
+  constexpr int NACC = P16 ? 4 : 16;
+  constexpr int XS_SZ = KC * S, WS_SZ = KC * TAPS * CB;
+  constexpr int RED_SZ = 4 * CB * 2;
+  __shared__ float smem[(XS_SZ + WS_SZ) > RED_SZ ? (XS_SZ + WS_SZ) : RED_SZ];
+  float* Xs = smem;
+  float* Ws = smem + XS_SZ;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int bx = blockIdx.x;
+  const int tx = bx % a.tiles_x;
+  bx /= a.tiles_x;
+  const int ty = bx % a.tiles_y;
+  const int b = bx / a.tiles_y;
+  const int cout0 = blockIdx.y * CB;
+  const int HW = a.H * a.W;
+
+  int off[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    int p = wave * 64 + nt * NB + (lane & (NB - 1));
+    off[nt] = (p >> TWL) * PITCH + (p & (TW - 1));
+  }
+
+  typename AccT<P16>::type acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < NACC; ++r) acc[mt][nt][r] = 0.f;
+
+  for (int c0 = 0; c0 < a.CinP; c0 += KC) {
+    const int kc = min(KC, a.CinP - c0);
+    __syncthreads();
+    // ---- input halo tile -> LDS (zero padding applies AFTER the fused affine/ReLU, as in the reference graph)
+    for (int e = tid; e < kc * PE; e += 256) {
+      int c = e / PE;
+      int rem = e - c * PE;
+      int r = rem / PITCH;
+      int x = rem - r * PITCH;
+      int gy = ty * TH + r - PAD, gx = tx * TW + x - PAD;
+      int cg = c0 + c;
+      float v = 0.f;
+      if (cg < a.Cin && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+        bool relu;
+        if (cg < a.C0) {
+          v = a.in0[(size_t)(b * a.C0 + cg) * HW + gy * a.W + gx];
+          relu = a.pro_relu & 1;
+        } else {
+          v = a.in1[(size_t)(b * a.C1 + (cg - a.C0)) * HW + gy * a.W + gx];
+          relu = a.pro_relu & 2;
+        }
+        if (a.pro) v = fmaf(v, a.pro[2 * cg], a.pro[2 * cg + 1]);
+        if (relu) v = fmaxf(v, 0.f);
+      }
+      Xs[c * S + rem] = v;
+    }
+    // ---- weight slab -> LDS: rows (cin, tap), CB consecutive output channels each
+    for (int e = tid; e < kc * TAPS * CB; e += 256) {
+      int row = e / CB;
+      int j = e - row * CB;
+      Ws[e] = (cout0 + j < a.CoutP) ? a.wp[(size_t)(c0 * TAPS + row) * a.CoutP + cout0 + j] : 0.f;
+    }
+    __syncthreads();
+    // ---- MFMA
+    const int nq = kc / KQ;
+    for (int q = 0; q < nq; ++q) {
+      const int cl = q * KQ + (lane / NB);
+      const float* xrow = Xs + cl * S;
+      const float* wrow = Ws + cl * TAPS * CB + (lane & (MB - 1));
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t) {
+        const int toff = (t / KS) * PITCH + (t % KS);
+        float av[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) av[mt] = wrow[t * CB + mt * MB];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          float bv = xrow[off[nt] + toff];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mfma(av[mt], bv, acc[mt][nt]);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: bias, ReLU, store (pixels on lanes -> contiguous runs per channel plane), BN partial statistics
+  const bool want_stats = a.stats != nullptr;
+  if (want_stats) __syncthreads();  // everyone is done with Xs/Ws before they are reused for the reduction
+  float* red = smem;                // [4 waves][CB][2]
+  const int C1out = a.Cout - a.Csplit;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+    for (int r = 0; r < NACC; ++r) {
+      int crel = P16 ? ((lane >> 4) * 4 + r) : (mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5));
+      int cout = cout0 + crel;
+      bool cvalid = cout < a.Cout;
+      float bias = (cvalid && a.bias) ? a.bias[cout] : 0.f;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        int p = wave * 64 + nt * NB + (lane & (NB - 1));
+        int gy = ty * TH + (p >> TWL), gx = tx * TW + (p & (TW - 1));
+        float v = acc[mt][nt][r] + bias;
+        if (a.relu_out) v = fmaxf(v, 0.f);
+        if (cvalid && gy < a.H && gx < a.W) {
+          if (cout < a.Csplit)
+            a.out0[(size_t)(b * a.Csplit + cout) * HW + gy * a.W + gx] = v;
+          else
+            a.out1[(size_t)(b * C1out + (cout - a.Csplit)) * HW + gy * a.W + gx] = v;
+          s1 += v;
+          s2 += v * v;
+        }
+      }
+      if (want_stats) {
+        s1 = wave_xor_sum(s1, NB / 2);
+        s2 = wave_xor_sum(s2, NB / 2);
+        if ((lane & (NB - 1)) == 0) {
+          red[(wave * CB + crel) * 2 + 0] = s1;
+          red[(wave * CB + crel) * 2 + 1] = s2;
+        }
+      }
+    }
+  }
+  if (want_stats) {
+    __syncthreads();
+    if (tid < CB * 2) {
+      int crel = tid >> 1;
+      if (cout0 + crel < a.Cout) {
+        float s = red[tid] + red[CB * 2 + tid] + red[2 * CB * 2 + tid] + red[3 * CB * 2 + tid];
+        a.stats[((size_t)blockIdx.x * a.Cout + cout0 + crel) * 2 + (tid & 1)] = s;
+      }
+    }
+  }
+}
+
+template <int KS, int MODE>
+static int launch_fwd(const ConvArgs& a, hipStream_t st) {
+  constexpr int CB = MODE == 0 ? 16 : 32 * MODE;
+  ConvArgs args = a;
+  const bool narrow = a.W <= 16;  // 16x16 tiles for the deepest levels, 8x32 otherwise
+  const int TW = narrow ? 16 : 32, TH = 256 / TW;
+  args.tiles_x = ceil_div(a.W, TW);
+  args.tiles_y = ceil_div(a.H, TH);
+  dim3 grid((unsigned)(a.B * args.tiles_x * args.tiles_y), (unsigned)ceil_div(a.CoutP, CB));
+  if (narrow)
+    hipLaunchKernelGGL((conv_fwd_k<KS, MODE, 4>), grid, dim3(256), 0, st, args);
+  else
+    hipLaunchKernelGGL((conv_fwd_k<KS, MODE, 5>), grid, dim3(256), 0, st, args);
+  return wtpse_status();
+}
+
+extern "C" int wtpse_conv_stats_blocks(int B, int H, int W) {
+  const int TW = W <= 16 ? 16 : 32, TH = 256 / TW;
+  return B * ceil_div(W, TW) * ceil_div(H, TH);
+}
+
+// See include/wtpse_hip.h for the contract.
+extern "C" int wtpse_conv_fwd(const float* in0, int C0, const float* in1, int C1, const float* wpacked,
+                              const float* bias, const float* pro, int pro_relu, float* out0, float* out1,
+                              int Csplit, float* stats, int B, int H, int W, int Cout, int ksize, int relu_out,
+                              void* stream) {
+  WTPSE_REQUIRE(in0 && wpacked && out0 && B > 0 && H > 0 && W > 0 && C0 > 0 && C1 >= 0 && Cout > 0);
+  WTPSE_REQUIRE(ksize == 1 || ksize == 3);
+  WTPSE_REQUIRE((C1 == 0) == (in1 == nullptr));
+  WTPSE_REQUIRE(Csplit > 0 && Csplit <= Cout && ((Csplit == Cout) == (out1 == nullptr)));
+  WTPSE_REQUIRE(!(stats && relu_out));
+  ConvArgs a;
+  a.in0 = in0; a.in1 = in1; a.wp = wpacked; a.bias = bias; a.pro = pro; a.out0 = out0; a.out1 = out1; a.stats = stats;
+  a.B = B; a.H = H; a.W = W; a.C0 = C0; a.C1 = C1; a.Cin = C0 + C1; a.CinP = (a.Cin + 3) & ~3;
+  a.Cout = Cout; a.CoutP = (Cout + 15) & ~15; a.Csplit = Csplit; a.pro_relu = pro_relu; a.relu_out = relu_out;
+  a.tiles_x = a.tiles_y = 0;
+  hipStream_t st = (hipStream_t)stream;
+  const int mode = Cout <= 16 ? 0 : (Cout % 64 == 0 ? 2 : 1);  // ragged channel counts run on the 32-wide path
+  if (ksize == 3) {
+    if (mode == 0) return launch_fwd<3, 0>(a, st);
+    if (mode == 1) return launch_fwd<3, 1>(a, st);
+    return launch_fwd<3, 2>(a, st);
+  }
+  if (mode == 0) return launch_fwd<1, 0>(a, st);
+  if (mode == 1) return launch_fwd<1, 1>(a, st);
+  return launch_fwd<1, 2>(a, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight packing: OIHW -> forward layout wf[CinP][taps][CoutP] (wf[ci][t][co] = w[co][ci][t]) and
+// data-gradient layout wd[CoutP4][taps][CinP16] (wd[co][t][ci] = w[co][ci][taps-1-t]); zero padded.
+// One launch packs every conv of a network: `desc` holds 8 ints per conv:
+//   {w_off, Cout, Cin, taps, wf_off, wd_off, unused, unused}   (offsets in floats)
+__global__ __launch_bounds__(256) void pack_weights_k(const float* __restrict__ params, const int* __restrict__ desc,
+                                                      float* __restrict__ packed) {
+  const int* d = desc + blockIdx.y * 8;
+  const int w_off = d[0], Co = d[1], Ci = d[2], T = d[3], wf_off = d[4], wd_off = d[5];
+  const int CiP4 = (Ci + 3) & ~3, CoP16 = (Co + 15) & ~15;
+  const int CoP4 = (Co + 3) & ~3, CiP16 = (Ci + 15) & ~15;
+  const float* w = params + w_off;
+  const int nf = CiP4 * T * CoP16;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < nf; e += gridDim.x * 256) {
+    int co = e % CoP16;
+    int t = (e / CoP16) % T;
+    int ci = e / (CoP16 * T);
+    packed[wf_off + e] = (co < Co && ci < Ci) ? w[(co * Ci + ci) * T + t] : 0.f;
+  }
+  if (wd_off >= 0) {
+    const int nd = CoP4 * T * CiP16;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < nd; e += gridDim.x * 256) {
+      int ci = e % CiP16;
+      int t = (e / CiP16) % T;
+      int co = e / (CiP16 * T);
+      packed[wd_off + e] = (co < Co && ci < Ci) ? w[(co * Ci + ci) * T + (T - 1 - t)] : 0.f;
+    }
+  }
+}
+
+extern "C" int wtpse_pack_conv_weights(const float* params, const int* desc, int n_desc, float* packed, void* stream) {
+  WTPSE_REQUIRE(params && desc && packed && n_desc > 0);
+  hipLaunchKernelGGL(pack_weights_k, dim3(16, n_desc), dim3(256), 0, (hipStream_t)stream, params, desc, packed);
+  return wtpse_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient: dW[co][ci][t] = sum_{b,y,x} dY[b,co,y,x] * X[b,ci,y+dy-1,x+dx-1]  (GEMM with K = pixels).
+// A workgroup owns (cout block, cin group) and a strided share of the spatial tiles; its 4 waves split each
+// tile's 256 pixels and keep their partial dW in MFMA accumulators across tiles; partials are summed through
+// LDS and written to slab[ky]; wtpse_wgrad_reduce folds the slabs in a fixed order (bitwise reproducible).
+// The N side is a list of (cin, tap) slots, 16|32 per block: slot = nb*NB + j -> cin = slot % cg, tap = slot / cg
+// with cg = min(NB, Cin).  This covers both wide layers (cg = NB: one tap per block) and the 1-/3-/8-/16-channel
+// inputs of the first layers and heads without padding channels.
+struct WgradArgs {
+  const float* dy;
+  const float* x0;
+  const float* x1;
+  const float* pro;
+  float* slab;    // [ksplit][Cout][Cin][taps]
+  float* dbias;   // [ksplit][Cout] or null
+  int B, H, W, C0, C1, Cin, Cout;
+  int pro_relu;
+  int tiles_x, tiles_y, ntiles;
+  int cg, ngroups, nblk;
+};
+
+template <int KS, bool P32, int TWL>
+__global__ __launch_bounds__(256) void conv_wgrad_k(WgradArgs a) {
+  constexpr int TAPS = KS * KS, PAD = KS / 2;
+  constexpr int TW = 1 << TWL, TH = 256 / TW;
+  constexpr int PITCH = TW + 2 * PAD, ROWS = TH + 2 * PAD;
+  constexpr int PE = PITCH * ROWS;
+  constexpr int MB = P32 ? 32 : 16;   // couts per block == cin slots per N block
+  constexpr int KQ = P32 ? 2 : 4;     // pixels per MFMA
+  constexpr int NACC = P32 ? 16 : 4;
+  constexpr int MAXNB = TAPS;         // N blocks per workgroup (ceil(cg*TAPS/MB) <= TAPS)
+  // bank-conflict-free strides: 16-path reads (cout|cin) x 2 pixels per 32-lane group -> stride % 32 == 2;
+  // 32-path reads 32 channels of one pixel -> odd stride
+  constexpr int SA = P32 ? 257 : 258;
+  constexpr int SX = P32 ? (PE | 1) : (((PE - 2 + 31) / 32) * 32 + 2);
+  constexpr int TILE_SZ = MB * SA + MB * SX;
+  constexpr int RED_SZ = P32 ? 4 * 1024 : 4 * MAXNB * 256;
+  __shared__ float smem[TILE_SZ > RED_SZ ? TILE_SZ : RED_SZ];
+  float* Ys = smem;
+  float* Xs = smem + MB * SA;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int group = blockIdx.x % a.ngroups;
+  const int cout0 = (blockIdx.x / a.ngroups) * MB;
+  const int cin0 = group * a.cg;
+  const int HW = a.H * a.W;
+  const int j = lane & (MB - 1), kl = lane / MB;
+
+  int boff[MAXNB];
+#pragma unroll
+  for (int nb = 0; nb < MAXNB; ++nb) {
+    int slot = nb * MB + j;
+    int ci = slot % a.cg, t = slot / a.cg;
+    boff[nb] = (t < TAPS) ? ci * SX + (t / KS) * PITCH + (t % KS) : -1;
+  }
+  typename AccT<!P32>::type acc[MAXNB];
+#pragma unroll
+  for (int nb = 0; nb < MAXNB; ++nb)
+#pragma unroll
+    for (int r = 0; r < NACC; ++r) acc[nb][r] = 0.f;
+  float db = 0.f;
+
+  const int tiles_per_img = a.tiles_x * a.tiles_y;
+  for (int tile = blockIdx.y; tile < a.ntiles; tile += gridDim.y) {
+    const int b = tile / tiles_per_img;
+    const int trem = tile - b * tiles_per_img;
+    const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
+    __syncthreads();
+    // dY tile: [MB couts][256 pixels], zero outside the image / beyond Cout
+    for (int e = tid; e < MB * 256; e += 256) {
+      int c = e >> 8, p = e & 255;
+      int gy = ty * TH + (p >> TWL), gx = tx * TW + (p & (TW - 1));
+      float v = 0.f;
+      if (cout0 + c < a.Cout && gy < a.H && gx < a.W) v = a.dy[(size_t)(b * a.Cout + cout0 + c) * HW + gy * a.W + gx];
+      Ys[c * SA + p] = v;
+    }
+    // X halo tile: [cg cins][ROWS][PITCH] with the same fused affine/ReLU loader as the forward kernel
+    for (int e = tid; e < a.cg * PE; e += 256) {
+      int c = e / PE;
+      int rem = e - c * PE;
+      int r = rem / PITCH;
+      int x = rem - r * PITCH;
+      int gy = ty * TH + r - PAD, gx = tx * TW + x - PAD;
+      int cgl = cin0 + c;
+      float v = 0.f;
+      if (cgl < a.Cin && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+        bool relu;
+        if (cgl < a.C0) {
+          v = a.x0[(size_t)(b * a.C0 + cgl) * HW + gy * a.W + gx];
+          relu = a.pro_relu & 1;
+        } else {
+          v = a.x1[(size_t)(b * a.C1 + (cgl - a.C0)) * HW + gy * a.W + gx];
+          relu = a.pro_relu & 2;
+        }
+        if (a.pro) v = fmaf(v, a.pro[2 * cgl], a.pro[2 * cgl + 1]);
+        if (relu) v = fmaxf(v, 0.f);
+      }
+      Xs[c * SX + rem] = v;
+    }
+    __syncthreads();
+    if (a.dbias && group == 0) {  // bias gradient: plain per-channel sum of the dY tile
+      int c = tid / (256 / MB), part = tid % (256 / MB);
+      constexpr int PER = MB;     // 256 pixels / (256/MB) threads
+      float s = 0.f;
+      for (int i = 0; i < PER; ++i) s += Ys[c * SA + part * PER + i];
+      db += s;
+    }
+    constexpr int STEPS = 64 / KQ;
+    for (int s = 0; s < STEPS; ++s) {
+      const int pbase = wave * 64 + s * KQ;
+      const int rowbase = (pbase >> TWL) * PITCH + (pbase & (TW - 1)) + kl;
+      const float av = Ys[j * SA + pbase + kl];
+#pragma unroll
+      for (int nb = 0; nb < MAXNB; ++nb) {
+        if (nb < a.nblk) {
+          float bv = boff[nb] >= 0 ? Xs[boff[nb] + rowbase] : 0.f;
+          acc[nb] = mfma(av, bv, acc[nb]);
+        }
+      }
+    }
+  }
+
+  // ---- cross-wave reduction through LDS, then slab[ky][co][ci][t]
+  float* slab = a.slab + (size_t)blockIdx.y * a.Cout * a.Cin * TAPS;
+  float* red = smem;
+  if constexpr (!P32) {
+    __syncthreads();
+#pragma unroll
+    for (int nb = 0; nb < MAXNB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[((wave * MAXNB + nb) * 16 + (lane >> 4) * 4 + r) * 16 + j] = acc[nb][r];
+    __syncthreads();
+    for (int e = tid; e < a.nblk * 256; e += 256) {
+      int nb = e >> 8, co = (e >> 4) & 15, jj = e & 15;
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) v += red[((w * MAXNB + nb) * 16 + co) * 16 + jj];
+      int slot = nb * 16 + jj;
+      int ci = slot % a.cg, t = slot / a.cg;
+      if (t < TAPS && cout0 + co < a.Cout && cin0 + ci < a.Cin)
+        slab[((size_t)(cout0 + co) * a.Cin + cin0 + ci) * TAPS + t] = v;
+    }
+  } else {
+#pragma unroll
+    for (int nb = 0; nb < MAXNB; ++nb) {
+      if (nb < a.nblk) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int co = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          red[(wave * 32 + co) * 32 + j] = acc[nb][r];
+        }
+        __syncthreads();
+        for (int e = tid; e < 1024; e += 256) {
+          int co = e >> 5, jj = e & 31;
+          float v = red[e] + red[1024 + e] + red[2048 + e] + red[3072 + e];
+          int slot = nb * 32 + jj;
+          int ci = slot % a.cg, t = slot / a.cg;
+          if (t < TAPS && cout0 + co < a.Cout && cin0 + ci < a.Cin)
+            slab[((size_t)(cout0 + co) * a.Cin + cin0 + ci) * TAPS + t] = v;
+        }
+      }
+    }
+  }
+  if (a.dbias && group == 0) {
+    constexpr int TPC = 256 / MB;  // threads per channel: 16 (P16) or 8 (P32), consecutive lanes
+    db = wave_xor_sum(db, TPC / 2);
+    int c = tid / TPC;
+    if ((tid % TPC) == 0 && cout0 + c < a.Cout) a.dbias[(size_t)blockIdx.y * a.Cout + cout0 + c] = db;
+  }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_k(const float* __restrict__ slab, int ksplit, int n,
+                                                      float* __restrict__ out, int accumulate) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int k = 0; k < ksplit; ++k) s += slab[(size_t)k * n + i];
+  out[i] = accumulate ? out[i] + s : s;
+}
+
+extern "C" int wtpse_wgrad_ksplit(int B, int H, int W, int Cin, int Cout) {
+  const int TW = W <= 16 ? 16 : 32, TH = 256 / TW;
+  const int ntiles = B * ceil_div(W, TW) * ceil_div(H, TH);
+  const bool p32 = Cout > 16;
+  const int MB = p32 ? 32 : 16;
+  const int cg = Cin < MB ? Cin : MB;
+  const int nx = ceil_div(Cout, MB) * ceil_div(Cin, cg);
+  int ks = 1024 / nx;
+  if (ks < 1) ks = 1;
+  if (ks > ntiles) ks = ntiles;
+  return ks;
+}
+
+extern "C" int wtpse_conv_wgrad(const float* dy, const float* x0, int C0, const float* x1, int C1, const float* pro,
+                                int pro_relu, float* slab, float* dbias_slab, int ksplit, float* dw, float* dbias,
+                                int accumulate, int B, int H, int W, int Cout, int ksize, void* stream) {
+  WTPSE_REQUIRE(dy && x0 && slab && dw && B > 0 && H > 0 && W > 0 && C0 > 0 && C1 >= 0 && Cout > 0 && ksplit > 0);
+  WTPSE_REQUIRE(ksize == 1 || ksize == 3);
+  WTPSE_REQUIRE((C1 == 0) == (x1 == nullptr));
+  WTPSE_REQUIRE((dbias == nullptr) == (dbias_slab == nullptr));
+  const bool p32 = Cout > 16;
+  WgradArgs a;
+  a.dy = dy; a.x0 = x0; a.x1 = x1; a.pro = pro; a.slab = slab; a.dbias = dbias_slab;
+  a.B = B; a.H = H; a.W = W; a.C0 = C0; a.C1 = C1; a.Cin = C0 + C1; a.Cout = Cout; a.pro_relu = pro_relu;
+  const int MB = p32 ? 32 : 16;
+  const int taps = ksize * ksize;
+  a.cg = a.Cin < MB ? a.Cin : MB;
+  a.ngroups = ceil_div(a.Cin, a.cg);   // a ragged last group is zero-filled by the loader
+  a.nblk = ceil_div(a.cg * taps, MB);
+  const bool narrow = W <= 16;
+  const int TW = narrow ? 16 : 32, TH = 256 / TW;
+  a.tiles_x = ceil_div(W, TW);
+  a.tiles_y = ceil_div(H, TH);
+  a.ntiles = B * a.tiles_x * a.tiles_y;
+  WTPSE_REQUIRE(ksplit <= a.ntiles);
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)(ceil_div(Cout, MB) * a.ngroups), (unsigned)ksplit);
+#define WG_LAUNCH(KS, P, T) hipLaunchKernelGGL((conv_wgrad_k<KS, P, T>), grid, dim3(256), 0, st, a)
+  if (ksize == 3) {
+    if (p32) { if (narrow) WG_LAUNCH(3, true, 4); else WG_LAUNCH(3, true, 5); }
+    else     { if (narrow) WG_LAUNCH(3, false, 4); else WG_LAUNCH(3, false, 5); }
+  } else {
+    if (p32) { if (narrow) WG_LAUNCH(1, true, 4); else WG_LAUNCH(1, true, 5); }
+    else     { if (narrow) WG_LAUNCH(1, false, 4); else WG_LAUNCH(1, false, 5); }
+  }
+#undef WG_LAUNCH
+  int rc = wtpse_status();
+  if (rc) return rc;
+  const int n = Cout * a.Cin * taps;
+  hipLaunchKernelGGL(wgrad_reduce_k, dim3(ceil_div(n, 256)), dim3(256), 0, st, slab, ksplit, n, dw, accumulate);
+  if (dbias)
+    hipLaunchKernelGGL(wgrad_reduce_k, dim3(ceil_div(Cout, 256)), dim3(256), 0, st, dbias_slab, ksplit, Cout, dbias,
+                       accumulate);
+  return wtpse_status();
+}

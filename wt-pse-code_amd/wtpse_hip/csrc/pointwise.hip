@@ -1,0 +1,584 @@
+// Bandwidth-bound pieces of the WT-PSE step that are not convolutions: pooling / upsampling of the U-Net
+// blocks (algorithms.py:890,901,929,949), the shape-attention fusion (:1126-1129,1243-1248), the
+// reparameterisations (:1068-1075; shape_networks.py:502-510), the caller's losses (Trainer.py:787,842-871;
+// shape_networks.py:596-597), Adam (train.py:120-138), the NaN scrub (shape_networks.py:490-506) and a
+// Philox normal generator for the sampling noise.  All NCHW fp32.
+#include "common.h"
+
+__device__ __forceinline__ float act_in(float v, const float* pro, int c, int relu) {
+  if (pro) v = fmaf(v, pro[2 * c], pro[2 * c + 1]);
+  return relu ? fmaxf(v, 0.f) : v;
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+__device__ __forceinline__ float block_sum(float v, float* sh4) {  // 256 threads
+  v = wave_xor_sum(v, 32);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh4[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return sh4[0] + sh4[1] + sh4[2] + sh4[3];
+}
+
+// ------------------------------------------------------------------------------------------------ MaxPool2d(2)
+__global__ __launch_bounds__(256) void maxpool2_fwd_k(const float* __restrict__ x, const float* __restrict__ pro, int relu,
+                                                      float* __restrict__ out, int C, int H, int W, long long total) {
+  const int Ho = H / 2, Wo = W / 2;
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  int xo = (int)(i % Wo);
+  long long r = i / Wo;
+  int yo = (int)(r % Ho);
+  long long bc = r / Ho;
+  int c = (int)(bc % C);
+  const float* src = x + (size_t)bc * H * W + (size_t)(2 * yo) * W + 2 * xo;
+  float a = act_in(src[0], pro, c, relu), b = act_in(src[1], pro, c, relu);
+  float d = act_in(src[W], pro, c, relu), e = act_in(src[W + 1], pro, c, relu);
+  out[i] = fmaxf(fmaxf(a, b), fmaxf(d, e));
+}
+
+// dx[b,c,y,x] (+)= dout[b,c,y/2,x/2] if (y,x) is the first maximum of its window (row-major scan, as ATen), else 0
+__global__ __launch_bounds__(256) void maxpool2_bwd_k(const float* __restrict__ x, const float* __restrict__ pro, int relu,
+                                                      const float* __restrict__ dout, float* __restrict__ dx,
+                                                      int accumulate, int C, int H, int W, long long total) {
+  const int Ho = H / 2, Wo = W / 2;
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  int xx = (int)(i % W);
+  long long r = i / W;
+  int yy = (int)(r % H);
+  long long bc = r / H;
+  int c = (int)(bc % C);
+  float g = 0.f;
+  int yo = yy >> 1, xo = xx >> 1;
+  if (yo < Ho && xo < Wo) {
+    const float* src = x + (size_t)bc * H * W + (size_t)(2 * yo) * W + 2 * xo;
+    float v[4] = {act_in(src[0], pro, c, relu), act_in(src[1], pro, c, relu), act_in(src[W], pro, c, relu),
+                  act_in(src[W + 1], pro, c, relu)};
+    int am = 0;
+    float m = v[0];
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+      if (v[k] > m || isnan(v[k])) { m = v[k]; am = k; }
+    if (am == (yy & 1) * 2 + (xx & 1)) g = dout[(size_t)bc * Ho * Wo + (size_t)yo * Wo + xo];
+  }
+  dx[i] = accumulate ? dx[i] + g : g;
+}
+
+// ------------------------------------------------------------------------------------------------ bilinear x2 (align_corners=False)
+__device__ __forceinline__ void up_src(int d, int n, int& i0, int& i1, float& l1) {
+  float s = 0.5f * (d + 0.5f) - 0.5f;
+  if (s < 0.f) s = 0.f;
+  i0 = (int)s;
+  i1 = i0 + (i0 < n - 1 ? 1 : 0);
+  l1 = s - (float)i0;
+}
+
+__global__ __launch_bounds__(256) void upsample2x_fwd_k(const float* __restrict__ x, const float* __restrict__ pro, int relu,
+                                                        float* __restrict__ out, int C, int H, int W, long long total) {
+  const int Ho = 2 * H, Wo = 2 * W;
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  int xo = (int)(i % Wo);
+  long long r = i / Wo;
+  int yo = (int)(r % Ho);
+  long long bc = r / Ho;
+  int c = (int)(bc % C);
+  int y0, y1, x0, x1;
+  float ly, lx;
+  up_src(yo, H, y0, y1, ly);
+  up_src(xo, W, x0, x1, lx);
+  const float* src = x + (size_t)bc * H * W;
+  float v00 = act_in(src[y0 * W + x0], pro, c, relu), v01 = act_in(src[y0 * W + x1], pro, c, relu);
+  float v10 = act_in(src[y1 * W + x0], pro, c, relu), v11 = act_in(src[y1 * W + x1], pro, c, relu);
+  // same association as ATen's upsample_bilinear2d: h0*(w0*a + w1*b) + h1*(w0*c + w1*d)
+  out[i] = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+}
+
+__device__ __forceinline__ float up_w(int d, int n, int k) {  // weight of source k in destination d (1-D)
+  int i0, i1;
+  float l1;
+  up_src(d, n, i0, i1, l1);
+  return (i0 == k ? 1.f - l1 : 0.f) + (i1 == k ? l1 : 0.f);
+}
+
+// adjoint of the above: gather over the <=4x4 destination pixels that read source (y,x)
+__global__ __launch_bounds__(256) void upsample2x_bwd_k(const float* __restrict__ dout, float* __restrict__ dx,
+                                                        int accumulate, int H, int W, long long total) {
+  const int Ho = 2 * H, Wo = 2 * W;
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  int xx = (int)(i % W);
+  long long r = i / W;
+  int yy = (int)(r % H);
+  long long bc = r / H;
+  const float* src = dout + (size_t)bc * Ho * Wo;
+  float g = 0.f;
+#pragma unroll
+  for (int dy = -1; dy <= 2; ++dy) {
+    int yo = 2 * yy + dy;
+    if (yo < 0 || yo >= Ho) continue;
+    float wy = up_w(yo, H, yy);
+    if (wy == 0.f) continue;
+    float rowsum = 0.f;
+#pragma unroll
+    for (int dxo = -1; dxo <= 2; ++dxo) {
+      int xo = 2 * xx + dxo;
+      if (xo < 0 || xo >= Wo) continue;
+      float wx = up_w(xo, W, xx);
+      rowsum += wx * src[(size_t)yo * Wo + xo];
+    }
+    g += wy * rowsum;
+  }
+  dx[i] = accumulate ? dx[i] + g : g;
+}
+
+// ------------------------------------------------------------------------------------------------ small elementwise
+__global__ __launch_bounds__(256) void relu_mask_k(const float* __restrict__ dz, const float* __restrict__ ref,
+                                                   float* __restrict__ dy, int accumulate, long long n) {
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float g = ref[i] > 0.f ? dz[i] : 0.f;
+  dy[i] = accumulate ? dy[i] + g : g;
+}
+
+__global__ __launch_bounds__(256) void axpy_k(float* __restrict__ dst, const float* __restrict__ src, float alpha, long long n) {
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = fmaf(alpha, src[i], dst[i]);
+}
+
+// out[j] (+)= sum_r partial[r][j]
+__global__ __launch_bounds__(256) void reduce_rows_k(const float* __restrict__ partial, int rows, int cols,
+                                                     float* __restrict__ out, int accumulate, float scale) {
+  int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= cols) return;
+  double s = 0.0;
+  for (int r = 0; r < rows; ++r) s += partial[(size_t)r * cols + j];
+  float v = (float)s * scale;
+  out[j] = accumulate ? out[j] + v : v;
+}
+
+// ------------------------------------------------------------------------------------------------ shape attention + fusion
+// a_pre = w*z + b ; att = sigmoid(a_pre) ; fuse[c] = coef*emb[c] + att*emb[c] ; mask = att > 0.75
+__global__ __launch_bounds__(256) void attn_fuse_fwd_k(const float* __restrict__ z, const float* __restrict__ wb,
+                                                       const float* __restrict__ emb, float coef, float* __restrict__ att,
+                                                       float* __restrict__ att_pre, float* __restrict__ mask,
+                                                       float* __restrict__ fuse, int CE, int HW, long long total) {
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;  // over B*HW
+  if (i >= total) return;
+  long long b = i / HW;
+  int p = (int)(i - b * HW);
+  float pre = fmaf(wb[0], z[i], wb[1]);
+  float a = sigmoidf_(pre);
+  if (att) att[i] = a;
+  if (att_pre) att_pre[i] = pre;
+  if (mask) mask[i] = a > 0.75f ? 1.f : 0.f;
+  for (int c = 0; c < CE; ++c) {
+    size_t idx = ((size_t)b * CE + c) * HW + p;
+    float e = emb[idx];
+    fuse[idx] = coef * e + a * e;
+  }
+}
+
+// demb = dfuse*(coef+att); datt = sum_c dfuse*emb; dpre = datt*att*(1-att); dz = dpre*w; partial[blk] = (sum dpre*z, sum dpre)
+__global__ __launch_bounds__(256) void attn_fuse_bwd_k(const float* __restrict__ dfuse, const float* __restrict__ z,
+                                                       const float* __restrict__ emb, const float* __restrict__ att,
+                                                       const float* __restrict__ wb, float coef, float* __restrict__ demb,
+                                                       float* __restrict__ dz, float* __restrict__ partial, int CE, int HW,
+                                                       long long total) {
+  __shared__ float sh[4];
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  float dw = 0.f, db = 0.f;
+  if (i < total) {
+    long long b = i / HW;
+    int p = (int)(i - b * HW);
+    float a = att[i];
+    float datt = 0.f;
+    for (int c = 0; c < CE; ++c) {
+      size_t idx = ((size_t)b * CE + c) * HW + p;
+      float g = dfuse[idx];
+      datt = fmaf(g, emb[idx], datt);
+      demb[idx] = g * (coef + a);
+    }
+    float dpre = datt * a * (1.f - a);
+    if (dz) dz[i] = dpre * wb[0];
+    dw = dpre * z[i];
+    db = dpre;
+  }
+  dw = block_sum(dw, sh);
+  db = block_sum(db, sh);
+  if (threadIdx.x == 0) {
+    partial[(size_t)blockIdx.x * 2] = dw;
+    partial[(size_t)blockIdx.x * 2 + 1] = db;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ reparameterisation
+// teacher (algorithms.py:1068-1075): z = mu + exp(logvar/2)*eps
+__global__ __launch_bounds__(256) void reparam_fwd_k(const float* __restrict__ mu, const float* __restrict__ logvar,
+                                                     const float* __restrict__ eps, float* __restrict__ z, long long n) {
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) z[i] = fmaf(expf(logvar[i] * 0.5f), eps[i], mu[i]);
+}
+__global__ __launch_bounds__(256) void reparam_bwd_k(const float* __restrict__ dz, const float* __restrict__ logvar,
+                                                     const float* __restrict__ eps, float* __restrict__ dlogvar, long long n) {
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dlogvar[i] = dz[i] * eps[i] * 0.5f * expf(logvar[i] * 0.5f);
+}
+// student (shape_networks.py:502-510): s = normal(mu, std) ; z = s*std + mu
+__global__ __launch_bounds__(256) void reparam_student_k(const float* __restrict__ mu, const float* __restrict__ std_,
+                                                         const float* __restrict__ eps, float* __restrict__ z, long long n) {
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    float s = fmaf(std_[i], eps[i], mu[i]);
+    z[i] = fmaf(s, std_[i], mu[i]);
+  }
+}
+__global__ __launch_bounds__(256) void exp_half_k(const float* __restrict__ logvar, float* __restrict__ std_, long long n) {
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) std_[i] = expf(logvar[i] * 0.5f);
+}
+
+// NaN scrub (shape_networks.py:490-492): if ANY element is NaN, nan_to_num the whole tensor — no host sync:
+// pass 1 raises a device flag, pass 2 is a no-op unless the flag is up.
+__global__ __launch_bounds__(256) void nan_flag_k(const float* __restrict__ x, long long n, int* __restrict__ flag) {
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  bool bad = i < n && isnan(x[i]);
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+__global__ __launch_bounds__(256) void nan_scrub_k(float* __restrict__ x, long long n, const int* __restrict__ flag) {
+  if (*flag == 0) return;
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float v = x[i];
+  if (isnan(v)) v = 0.f;
+  else if (isinf(v)) v = v > 0.f ? 3.4028234663852886e38f : -3.4028234663852886e38f;
+  x[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------------ losses
+// BCELoss(sigmoid(x), t), mean (Trainer.py:19,787) — per-block partial sums
+__global__ __launch_bounds__(256) void bce_sigmoid_fwd_k(const float* __restrict__ x, const float* __restrict__ t, long long n,
+                                                         float* __restrict__ partial) {
+  __shared__ float sh[4];
+  float acc = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    float s = sigmoidf_(x[i]);
+    float l1 = fmaxf(logf(s), -100.f), l0 = fmaxf(logf(1.f - s), -100.f);
+    acc -= t[i] * l1 + (1.f - t[i]) * l0;
+  }
+  acc = block_sum(acc, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+__global__ __launch_bounds__(256) void bce_sigmoid_bwd_k(const float* __restrict__ x, const float* __restrict__ t,
+                                                         const float* g, float w, long long n, float* __restrict__ dx) {
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float s = sigmoidf_(x[i]);
+  float q = s * (1.f - s);
+  float up = (g ? *g : 1.f) * w / (float)n;
+  dx[i] = up * (s - t[i]) / fmaxf(q, 1e-12f) * q;
+}
+// binary_cross_entropy_with_logits(x*m, t, pos_weight) (Trainer.py:868-871)
+__global__ __launch_bounds__(256) void bce_logits_pw_fwd_k(const float* __restrict__ x, const float* __restrict__ m,
+                                                           const float* __restrict__ t, const float* __restrict__ pw,
+                                                           long long n, float* __restrict__ partial) {
+  __shared__ float sh[4];
+  const float pos = *pw;
+  float acc = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    float xi = x[i] * m[i], ti = t[i];
+    float lw = 1.f + (pos - 1.f) * ti;
+    acc += (1.f - ti) * xi + lw * (log1pf(expf(-fabsf(xi))) + fmaxf(-xi, 0.f));
+  }
+  acc = block_sum(acc, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+__global__ __launch_bounds__(256) void bce_logits_pw_bwd_k(const float* __restrict__ x, const float* __restrict__ m,
+                                                           const float* __restrict__ t, const float* __restrict__ pw,
+                                                           const float* g, float w, long long n, float* __restrict__ dx) {
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float xi = x[i] * m[i], ti = t[i];
+  float lw = 1.f + (*pw - 1.f) * ti;
+  float up = (g ? *g : 1.f) * w / (float)n;
+  dx[i] = up * ((1.f - ti) + lw * (sigmoidf_(xi) - 1.f)) * m[i];
+}
+// sums[0] = sum a ; sums[1] = sum a*b  (pos_weight = sums[0]/sums[1], Trainer.py:865)
+__global__ __launch_bounds__(256) void sum2_k(const float* __restrict__ a, const float* __restrict__ b, long long n,
+                                              float* __restrict__ partial) {
+  __shared__ float sh[4];
+  float s0 = 0.f, s1 = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    s0 += a[i];
+    s1 += a[i] * b[i];
+  }
+  s0 = block_sum(s0, sh);
+  s1 = block_sum(s1, sh);
+  if (threadIdx.x == 0) {
+    partial[(size_t)blockIdx.x * 2] = s0;
+    partial[(size_t)blockIdx.x * 2 + 1] = s1;
+  }
+}
+__global__ void pos_weight_k(const float* __restrict__ sums, float* __restrict__ pw) {
+  float v = sums[0] / sums[1];
+  *pw = (isinf(v) || isnan(v)) ? 1.f : v;
+}
+// MSE mean (shape_networks.py:596-597)
+__global__ __launch_bounds__(256) void mse_fwd_k(const float* __restrict__ a, const float* __restrict__ b, long long n,
+                                                 float* __restrict__ partial) {
+  __shared__ float sh[4];
+  float acc = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    float d = a[i] - b[i];
+    acc = fmaf(d, d, acc);
+  }
+  acc = block_sum(acc, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+__global__ __launch_bounds__(256) void mse_bwd_k(const float* __restrict__ a, const float* __restrict__ b, const float* g,
+                                                 float w, long long n, float* __restrict__ da) {
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) da[i] = (g ? *g : 1.f) * w * 2.f * (a[i] - b[i]) / (float)n;
+}
+// od_pred = sigmoid(logit) > 0.75 ; roi = (image + 1) * od_pred - 1  (Trainer.py:842-853)
+__global__ __launch_bounds__(256) void roi_k(const float* __restrict__ image, const float* __restrict__ logit,
+                                             float* __restrict__ roi, float* __restrict__ od_pred, int C, int HW,
+                                             long long total) {
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;  // over B*HW
+  if (i >= total) return;
+  long long b = i / HW;
+  int p = (int)(i - b * HW);
+  float m = sigmoidf_(logit[i]) > 0.75f ? 1.f : 0.f;
+  od_pred[i] = m;
+  for (int c = 0; c < C; ++c) {
+    size_t idx = ((size_t)b * C + c) * HW + p;
+    roi[idx] = (image[idx] + 1.f) * m - 1.f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ Adam (torch.optim.Adam semantics, no weight decay / amsgrad)
+__global__ __launch_bounds__(256) void adam_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                              float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
+                                              float bc1, float bc2_sqrt) {
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float gi = g[i];
+  float mi = b1 * m[i] + (1.f - b1) * gi;
+  float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+  m[i] = mi;
+  v[i] = vi;
+  float denom = sqrtf(vi) / bc2_sqrt + eps;
+  p[i] -= (lr / bc1) * (mi / denom);
+}
+
+// ------------------------------------------------------------------------------------------------ Philox4x32-10 -> N(0,1)
+__device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0, uint32_t k1) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+  uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+  uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+  uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+  c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+}
+// element i of the stream (seed, offset) depends only on (seed, offset + i/4): any sharding of the rows
+// over ranks reproduces the single-device stream when each rank passes its global element offset
+__global__ __launch_bounds__(256) void randn_k(float* __restrict__ out, long long n, unsigned long long seed,
+                                               unsigned long long offset) {
+  long long q = (long long)blockIdx.x * 256 + threadIdx.x;  // one Philox block = 4 normals
+  long long base = q * 4;
+  if (base >= n) return;
+  unsigned long long ctr = offset / 4 + (unsigned long long)q;
+  uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0, c3 = 0;
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c0, c1, c2, c3, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  const float S = 2.3283064365386963e-10f;  // 2^-32
+  float u0 = ((float)c0 + 0.5f) * S, u1 = ((float)c1 + 0.5f) * S, u2 = ((float)c2 + 0.5f) * S, u3 = ((float)c3 + 0.5f) * S;
+  if (u0 >= 1.f) u0 = 0.99999994f;
+  if (u2 >= 1.f) u2 = 0.99999994f;
+  float r0 = sqrtf(-2.f * logf(u0)), r1 = sqrtf(-2.f * logf(u2));
+  float zv[4] = {r0 * cosf(6.283185307179586f * u1), r0 * sinf(6.283185307179586f * u1),
+                 r1 * cosf(6.283185307179586f * u3), r1 * sinf(6.283185307179586f * u3)};
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (base + k < n) out[base + k] = zv[k];
+}
+
+// ================================================================================================ C ABI
+#define GRID1(n) dim3((unsigned)(((n) + 255) / 256))
+#define ST ((hipStream_t)stream)
+static inline unsigned red_blocks(long long n) {
+  long long b = (n + 256 * 16 - 1) / (256 * 16);
+  if (b > 1024) b = 1024;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+extern "C" int wtpse_reduce_blocks(long long n) { return (int)red_blocks(n); }
+
+extern "C" int wtpse_maxpool2_fwd(const float* x, const float* pro, int relu, float* out, int B, int C, int H, int W, void* stream) {
+  WTPSE_REQUIRE(x && out && B > 0 && C > 0 && H >= 2 && W >= 2);
+  long long total = (long long)B * C * (H / 2) * (W / 2);
+  hipLaunchKernelGGL(maxpool2_fwd_k, GRID1(total), dim3(256), 0, ST, x, pro, relu, out, C, H, W, total);
+  return wtpse_status();
+}
+extern "C" int wtpse_maxpool2_bwd(const float* x, const float* pro, int relu, const float* dout, float* dx, int accumulate,
+                                  int B, int C, int H, int W, void* stream) {
+  WTPSE_REQUIRE(x && dout && dx && B > 0 && C > 0 && H >= 2 && W >= 2);
+  long long total = (long long)B * C * H * W;
+  hipLaunchKernelGGL(maxpool2_bwd_k, GRID1(total), dim3(256), 0, ST, x, pro, relu, dout, dx, accumulate, C, H, W, total);
+  return wtpse_status();
+}
+extern "C" int wtpse_upsample2x_fwd(const float* x, const float* pro, int relu, float* out, int B, int C, int H, int W, void* stream) {
+  WTPSE_REQUIRE(x && out && B > 0 && C > 0 && H > 0 && W > 0);
+  long long total = (long long)B * C * H * W * 4;
+  hipLaunchKernelGGL(upsample2x_fwd_k, GRID1(total), dim3(256), 0, ST, x, pro, relu, out, C, H, W, total);
+  return wtpse_status();
+}
+extern "C" int wtpse_upsample2x_bwd(const float* dout, float* dx, int accumulate, int B, int C, int H, int W, void* stream) {
+  WTPSE_REQUIRE(dout && dx && B > 0 && C > 0 && H > 0 && W > 0);
+  long long total = (long long)B * C * H * W;
+  hipLaunchKernelGGL(upsample2x_bwd_k, GRID1(total), dim3(256), 0, ST, dout, dx, accumulate, H, W, total);
+  return wtpse_status();
+}
+extern "C" int wtpse_relu_mask(const float* dz, const float* ref, float* dy, int accumulate, long long n, void* stream) {
+  WTPSE_REQUIRE(dz && ref && dy && n > 0);
+  hipLaunchKernelGGL(relu_mask_k, GRID1(n), dim3(256), 0, ST, dz, ref, dy, accumulate, n);
+  return wtpse_status();
+}
+extern "C" int wtpse_axpy(float* dst, const float* src, float alpha, long long n, void* stream) {
+  WTPSE_REQUIRE(dst && src && n > 0);
+  hipLaunchKernelGGL(axpy_k, GRID1(n), dim3(256), 0, ST, dst, src, alpha, n);
+  return wtpse_status();
+}
+extern "C" int wtpse_reduce_rows(const float* partial, int rows, int cols, float* out, int accumulate, float scale, void* stream) {
+  WTPSE_REQUIRE(partial && out && rows > 0 && cols > 0);
+  hipLaunchKernelGGL(reduce_rows_k, GRID1(cols), dim3(256), 0, ST, partial, rows, cols, out, accumulate, scale);
+  return wtpse_status();
+}
+extern "C" int wtpse_zero(void* p, long long nbytes, void* stream) {
+  WTPSE_REQUIRE(p && nbytes >= 0);
+  hipError_t e = hipMemsetAsync(p, 0, (size_t)nbytes, ST);
+  return e == hipSuccess ? WTPSE_OK : (int)e;
+}
+extern "C" int wtpse_attn_fuse_fwd(const float* z, const float* wb, const float* emb, float coef, float* att, float* att_pre,
+                                   float* mask, float* fuse, int B, int CE, int HW, void* stream) {
+  WTPSE_REQUIRE(z && wb && emb && fuse && B > 0 && CE > 0 && HW > 0);
+  long long total = (long long)B * HW;
+  hipLaunchKernelGGL(attn_fuse_fwd_k, GRID1(total), dim3(256), 0, ST, z, wb, emb, coef, att, att_pre, mask, fuse, CE, HW, total);
+  return wtpse_status();
+}
+// partial must hold 2*ceil(B*HW/256) floats; d_wb[2] receives (dw, db)
+extern "C" int wtpse_attn_fuse_bwd(const float* dfuse, const float* z, const float* emb, const float* att, const float* wb,
+                                   float coef, float* demb, float* dz, float* partial, float* d_wb, int accumulate, int B,
+                                   int CE, int HW, void* stream) {
+  WTPSE_REQUIRE(dfuse && z && emb && att && wb && demb && partial && d_wb && B > 0 && CE > 0 && HW > 0);
+  long long total = (long long)B * HW;
+  unsigned nb = (unsigned)((total + 255) / 256);
+  hipLaunchKernelGGL(attn_fuse_bwd_k, dim3(nb), dim3(256), 0, ST, dfuse, z, emb, att, wb, coef, demb, dz, partial, CE, HW, total);
+  hipLaunchKernelGGL(reduce_rows_k, dim3(1), dim3(256), 0, ST, partial, (int)nb, 2, d_wb, accumulate, 1.f);
+  return wtpse_status();
+}
+extern "C" int wtpse_reparam_fwd(const float* mu, const float* logvar, const float* eps, float* z, long long n, void* stream) {
+  WTPSE_REQUIRE(mu && logvar && eps && z && n > 0);
+  hipLaunchKernelGGL(reparam_fwd_k, GRID1(n), dim3(256), 0, ST, mu, logvar, eps, z, n);
+  return wtpse_status();
+}
+extern "C" int wtpse_reparam_bwd(const float* dz, const float* logvar, const float* eps, float* dlogvar, long long n, void* stream) {
+  WTPSE_REQUIRE(dz && logvar && eps && dlogvar && n > 0);
+  hipLaunchKernelGGL(reparam_bwd_k, GRID1(n), dim3(256), 0, ST, dz, logvar, eps, dlogvar, n);
+  return wtpse_status();
+}
+extern "C" int wtpse_exp_half(const float* logvar, float* std_, long long n, void* stream) {
+  WTPSE_REQUIRE(logvar && std_ && n > 0);
+  hipLaunchKernelGGL(exp_half_k, GRID1(n), dim3(256), 0, ST, logvar, std_, n);
+  return wtpse_status();
+}
+extern "C" int wtpse_reparam_student(const float* mu, const float* std_, const float* eps, float* z, long long n, void* stream) {
+  WTPSE_REQUIRE(mu && std_ && eps && z && n > 0);
+  hipLaunchKernelGGL(reparam_student_k, GRID1(n), dim3(256), 0, ST, mu, std_, eps, z, n);
+  return wtpse_status();
+}
+// flag: one device int, zeroed here; the tensor is scrubbed only if a NaN was seen
+extern "C" int wtpse_nan_scrub(float* x, long long n, int* flag, void* stream) {
+  WTPSE_REQUIRE(x && flag && n > 0);
+  hipError_t e = hipMemsetAsync(flag, 0, sizeof(int), ST);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(nan_flag_k, GRID1(n), dim3(256), 0, ST, x, n, flag);
+  hipLaunchKernelGGL(nan_scrub_k, GRID1(n), dim3(256), 0, ST, x, n, flag);
+  return wtpse_status();
+}
+extern "C" int wtpse_bce_sigmoid_fwd(const float* x, const float* t, long long n, float* partial, float* loss, void* stream) {
+  WTPSE_REQUIRE(x && t && partial && loss && n > 0);
+  unsigned nb = red_blocks(n);
+  hipLaunchKernelGGL(bce_sigmoid_fwd_k, dim3(nb), dim3(256), 0, ST, x, t, n, partial);
+  hipLaunchKernelGGL(reduce_rows_k, dim3(1), dim3(256), 0, ST, partial, (int)nb, 1, loss, 0, 1.f / (float)n);
+  return wtpse_status();
+}
+extern "C" int wtpse_bce_sigmoid_bwd(const float* x, const float* t, const float* g, float w, long long n, float* dx, void* stream) {
+  WTPSE_REQUIRE(x && t && dx && n > 0);
+  hipLaunchKernelGGL(bce_sigmoid_bwd_k, GRID1(n), dim3(256), 0, ST, x, t, g, w, n, dx);
+  return wtpse_status();
+}
+// pos_weight from the global batch: pw = sum(mask)/sum(mask*t), 1 if inf/nan. sums[2], pw[1] device scalars
+extern "C" int wtpse_pos_weight(const float* mask, const float* t, long long n, float* partial, float* sums, float* pw, void* stream) {
+  WTPSE_REQUIRE(mask && t && partial && sums && pw && n > 0);
+  unsigned nb = red_blocks(n);
+  hipLaunchKernelGGL(sum2_k, dim3(nb), dim3(256), 0, ST, mask, t, n, partial);
+  hipLaunchKernelGGL(reduce_rows_k, dim3(1), dim3(256), 0, ST, partial, (int)nb, 2, sums, 0, 1.f);
+  hipLaunchKernelGGL(pos_weight_k, dim3(1), dim3(1), 0, ST, sums, pw);
+  return wtpse_status();
+}
+extern "C" int wtpse_pos_weight_from_sums(const float* sums, float* pw, void* stream) {
+  WTPSE_REQUIRE(sums && pw);
+  hipLaunchKernelGGL(pos_weight_k, dim3(1), dim3(1), 0, ST, sums, pw);
+  return wtpse_status();
+}
+extern "C" int wtpse_bce_logits_pw_fwd(const float* x, const float* mask, const float* t, const float* pw, long long n,
+                                       float* partial, float* loss, void* stream) {
+  WTPSE_REQUIRE(x && mask && t && pw && partial && loss && n > 0);
+  unsigned nb = red_blocks(n);
+  hipLaunchKernelGGL(bce_logits_pw_fwd_k, dim3(nb), dim3(256), 0, ST, x, mask, t, pw, n, partial);
+  hipLaunchKernelGGL(reduce_rows_k, dim3(1), dim3(256), 0, ST, partial, (int)nb, 1, loss, 0, 1.f / (float)n);
+  return wtpse_status();
+}
+extern "C" int wtpse_bce_logits_pw_bwd(const float* x, const float* mask, const float* t, const float* pw, const float* g,
+                                       float w, long long n, float* dx, void* stream) {
+  WTPSE_REQUIRE(x && mask && t && pw && dx && n > 0);
+  hipLaunchKernelGGL(bce_logits_pw_bwd_k, GRID1(n), dim3(256), 0, ST, x, mask, t, pw, g, w, n, dx);
+  return wtpse_status();
+}
+extern "C" int wtpse_mse_fwd(const float* a, const float* b, long long n, float* partial, float* loss, void* stream) {
+  WTPSE_REQUIRE(a && b && partial && loss && n > 0);
+  unsigned nb = red_blocks(n);
+  hipLaunchKernelGGL(mse_fwd_k, dim3(nb), dim3(256), 0, ST, a, b, n, partial);
+  hipLaunchKernelGGL(reduce_rows_k, dim3(1), dim3(256), 0, ST, partial, (int)nb, 1, loss, 0, 1.f / (float)n);
+  return wtpse_status();
+}
+extern "C" int wtpse_mse_bwd(const float* a, const float* b, const float* g, float w, long long n, float* da, void* stream) {
+  WTPSE_REQUIRE(a && b && da && n > 0);
+  hipLaunchKernelGGL(mse_bwd_k, GRID1(n), dim3(256), 0, ST, a, b, g, w, n, da);
+  return wtpse_status();
+}
+extern "C" int wtpse_roi(const float* image, const float* logit, float* roi, float* od_pred, int B, int C, int HW, void* stream) {
+  WTPSE_REQUIRE(image && logit && roi && od_pred && B > 0 && C > 0 && HW > 0);
+  long long total = (long long)B * HW;
+  hipLaunchKernelGGL(roi_k, GRID1(total), dim3(256), 0, ST, image, logit, roi, od_pred, C, HW, total);
+  return wtpse_status();
+}
+extern "C" int wtpse_adam(float* p, const float* g, float* m, float* v, long long n, double lr, double beta1, double beta2,
+                          double eps, int step, void* stream) {
+  WTPSE_REQUIRE(p && g && m && v && n > 0 && step >= 1);
+  float bc1 = (float)(1.0 - pow(beta1, (double)step));
+  float bc2s = (float)sqrt(1.0 - pow(beta2, (double)step));
+  hipLaunchKernelGGL(adam_k, GRID1(n), dim3(256), 0, ST, p, g, m, v, n, (float)lr, (float)beta1, (float)beta2, (float)eps, bc1,
+                     bc2s);
+  return wtpse_status();
+}
+extern "C" int wtpse_randn(float* out, long long n, unsigned long long seed, unsigned long long offset, void* stream) {
+  WTPSE_REQUIRE(out && n > 0 && offset % 4 == 0);
+  hipLaunchKernelGGL(randn_k, GRID1((n + 3) / 4), dim3(256), 0, ST, out, n, seed, offset);
+  return wtpse_status();
+}

@@ -1,0 +1,552 @@
+"""Host-side engine of the WT-PSE hot path on MI355X.
+
+* Parameter containers reproduce the reference's ``state_dict`` key names so its checkpoints load.
+* A root network (``HipNet``) keeps ALL its parameters in one flat device buffer (``nn.Parameter``s are views),
+  one flat gradient buffer (``.grad``s are views), and one packed-weight buffer in the kernels' layouts, refreshed
+  by a single launch whenever the parameters change.  Flat buffers make the optimiser step one kernel and the
+  data-parallel gradient exchange one RCCL all-reduce per network.
+* Forward and backward of every block are explicit schedules of C-ABI calls (ops.py) with a small tape; torch
+  autograd only sees one Function per ``update()`` (algorithms.py / shape_networks.py).
+
+Reference blocks mirrored here: ConvD / ConvU (algorithms.py:877-962), DoubleConv (:398-413), DeepWT / DoubleConvWT
+(:416-428,1080-1117), ShapeVariationalDist_y_x (:979-1075), attention_layer (:1120-1129), heads (:1006-1012,1199-1201).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+# ================================================================================================ parameter containers
+class ConvP(nn.Module):
+    """weight [Cout,Cin,k,k] + bias [Cout], initialised like nn.Conv2d (kaiming_uniform(a=sqrt(5)))."""
+
+    def __init__(self, cin, cout, k):
+        super().__init__()
+        self.cin, self.cout, self.k = cin, cout, k
+        self.weight = nn.Parameter(torch.empty(cout, cin, k, k))
+        self.bias = nn.Parameter(torch.empty(cout))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        bound = 1.0 / math.sqrt(cin * k * k)
+        nn.init.uniform_(self.bias, -bound, bound)
+        self.wf_off = self.wd_off = -1
+
+
+class BNP(nn.Module):
+    """nn.BatchNorm2d state: weight, bias, running_mean, running_var, num_batches_tracked."""
+
+    def __init__(self, c):
+        super().__init__()
+        self.c = c
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+
+class Seq(nn.Module):
+    """Children under the numeric names nn.Sequential would give them (activations occupy the gaps)."""
+
+    def __init__(self, **children):
+        super().__init__()
+        for name, mod in children.items():
+            self.add_module(name.lstrip("_"), mod)
+
+    def __getitem__(self, i):
+        return getattr(self, str(i))
+
+
+class ConvDBlock(nn.Module):
+    def __init__(self, cin, c, first=False):
+        super().__init__()
+        self.first = first
+        self.conv1, self.bn1 = ConvP(cin, c, 3), BNP(c)
+        self.conv2, self.bn2 = ConvP(c, c, 3), BNP(c)
+        self.conv3, self.bn3 = ConvP(c, c, 3), BNP(c)
+
+
+class ConvUBlock(nn.Module):
+    def __init__(self, planes, first=False):
+        super().__init__()
+        self.first = first
+        if not first:
+            self.conv1, self.bn1 = ConvP(2 * planes, planes, 3), BNP(planes)
+        self.conv2, self.bn2 = ConvP(planes, planes // 2, 1), BNP(planes // 2)
+        self.conv3, self.bn3 = ConvP(planes, planes, 3), BNP(planes)
+
+
+class DoubleConvWTP(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.double_conv = Seq(_0=ConvP(cin, cout, 3), _2=ConvP(cout, cout, 3))
+
+
+class DeepWTP(nn.Module):
+    """DeepWT (algorithms.py:1080-1117): 3->16->16, ReLU, 16->16->16; returns [z1, z2, relu(z2)].
+    relu(z2) is never materialised: consumers take z2 with ReLU-on-load."""
+
+    def __init__(self, cin=3, c=16):
+        super().__init__()
+        self.DoubleConv = DoubleConvWTP(cin, c)
+        self.DoubleConv2 = DoubleConvWTP(c, c)
+
+    def forward(self, x):
+        self._root.ensure_ready(repack=True)
+        t = deepwt_fwd(self, x.detach().to(torch.float32).contiguous(), want_tape=False)
+        return [t.z1, t.z2, ops.affine_act(t.z2, None, True)]
+
+
+class DoubleConvP(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.double_conv = Seq(_0=ConvP(cin, cout, 3), _1=BNP(cout), _3=ConvP(cout, cout, 3), _4=BNP(cout))
+
+
+def head_p(n=16, n_classes=1):
+    return Seq(_0=ConvP(2 * n, 2 * n, 1), _2=ConvP(2 * n, 8, 1), _4=ConvP(8, n_classes, 1))
+
+
+class UNetBody(nn.Module):
+    """down1-4 / up1-4 shared by the segmentation net, the teacher and the student."""
+
+    def _make_body(self, n=16):
+        self.down1 = ConvDBlock(n, 2 * n)
+        self.down2 = ConvDBlock(2 * n, 4 * n)
+        self.down3 = ConvDBlock(4 * n, 8 * n)
+        self.down4 = ConvDBlock(8 * n, 16 * n)
+        self.up1 = ConvUBlock(16 * n, first=True)
+        self.up2 = ConvUBlock(8 * n)
+        self.up3 = ConvUBlock(4 * n)
+        self.up4 = ConvUBlock(2 * n)
+
+
+class AttentionP(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.layer1 = ConvP(1, 1, 1)
+
+    def forward(self, x):
+        """attention_layer.forward (algorithms.py:1126-1129) -> (sigmoid(conv(x)), conv(x))."""
+        root = self.layer1._root
+        root.ensure_ready(repack=True)
+        dummy = x.new_zeros((x.shape[0], 1, x.shape[2], x.shape[3]))
+        att, pre, _, _ = ops.attn_fuse_fwd(x.contiguous(), self.layer1.weight.data_ptr(), dummy, 0.0, True, True, False)
+        return att, pre
+
+
+class TeacherP(UNetBody):
+    """ShapeVariationalDist_y_x with whitening=True (algorithms.py:979-1075)."""
+
+    def __init__(self, n=16):
+        super().__init__()
+        self.inc = DoubleConvP(1, n)
+        self.fusion = Seq(_0=ConvP(2 * n, n, 1))
+        self._make_body(n)
+        self.mu_prior = head_p(n)
+        self.logvar_prior = head_p(n)
+
+    def sample_forward(self, inputs, mask=None, training=True):
+        """(z, mu) in training, mu otherwise; `inputs` = W[-1] = relu(z2) materialised by the caller."""
+        root = self.fusion[0]._root
+        root.ensure_ready(repack=True)
+        t = teacher_fwd(self, inputs.contiguous(), False, mask.contiguous(), self.training, want_logvar=training,
+                        want_tape=False)
+        if not training:
+            return t.mu
+        eps = root.next_noise(t.mu.shape)
+        return ops.reparam_fwd(t.mu, t.logvar, eps), t.mu
+
+
+# ================================================================================================ root network
+class HipNet(nn.Module):
+    """Root of a parameter tree: owns the flat parameter / gradient / packed-weight buffers."""
+
+    def _finish_init(self):
+        object.__setattr__(self, "_flat", None)
+        object.__setattr__(self, "_gflat", None)
+        object.__setattr__(self, "_gwork", None)
+        object.__setattr__(self, "_packed", None)
+        object.__setattr__(self, "_packed_version", -1)
+        object.__setattr__(self, "_desc", None)
+        object.__setattr__(self, "_touched", [])
+        object.__setattr__(self, "_noise_queue", [])
+        object.__setattr__(self, "_noise_seed", 0x5eed)
+        object.__setattr__(self, "_noise_counter", 0)
+        object.__setattr__(self, "_dp", None)
+        object.__setattr__(self, "_flag", None)
+        object.__setattr__(self, "_packed_valid", False)
+        object.__setattr__(self, "_attach_grads", True)
+        self._convs = [m for m in self.modules() if isinstance(m, ConvP)]
+        for m in self.modules():
+            if isinstance(m, (ConvP, BNP, AttentionP, TeacherP, DeepWTP)):
+                object.__setattr__(m, "_root", self)
+        off = 0
+        for c in self._convs:
+            t = c.k * c.k
+            c.wf_off = off
+            off += ((c.cin + 3) & ~3) * t * ((c.cout + 15) & ~15)
+            c.wd_off = off
+            off += ((c.cout + 3) & ~3) * t * ((c.cin + 15) & ~15)
+        self._packed_size = off
+
+    # ---- flat storage --------------------------------------------------------------------------------------
+    def _is_flat(self):
+        f = self._flat
+        if f is None:
+            return False
+        p0 = next(self.parameters())
+        return p0.device == f.device and p0.data_ptr() == f.data_ptr() and all(
+            p.data_ptr() == f.data_ptr() + 4 * o for p, o in zip(self.parameters(), self._offsets))
+
+    def _flatten(self):
+        params = list(self.parameters())
+        dev = params[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("the WT-PSE MI355X path runs in device memory only: move the module to a HIP device "
+                               "(`.to('cuda')`); there is no CPU fallback")
+        total = sum(p.numel() for p in params)
+        flat = torch.empty(total, dtype=torch.float32, device=dev)
+        offsets, off = [], 0
+        with torch.no_grad():
+            for p in params:
+                n = p.numel()
+                flat[off:off + n].copy_(p.detach().reshape(-1).to(dev, torch.float32))
+                p.data = flat[off:off + n].view(p.shape)
+                p.grad = None
+                offsets.append(off)
+                off += n
+        object.__setattr__(self, "_flat", flat)
+        object.__setattr__(self, "_offsets", offsets)
+        object.__setattr__(self, "_pindex", {id(p): i for i, p in enumerate(params)})
+        object.__setattr__(self, "_gflat", torch.zeros(total, dtype=torch.float32, device=dev))
+        object.__setattr__(self, "_gwork", None)
+        object.__setattr__(self, "_packed", torch.empty(self._packed_size, dtype=torch.float32, device=dev))
+        desc = []
+        for c in self._convs:
+            desc += [self._offsets[self._pindex[id(c.weight)]], c.cout, c.cin, c.k * c.k, c.wf_off, c.wd_off, 0, 0]
+        object.__setattr__(self, "_desc", torch.tensor(desc, dtype=torch.int32).to(dev))
+        object.__setattr__(self, "_packed_version", -1)
+        object.__setattr__(self, "_flag", torch.zeros(1, dtype=torch.int32, device=dev))
+        for b in self.buffers():
+            if b.device != dev:
+                raise RuntimeError("parameters and buffers live on different devices")
+
+    def ensure_ready(self, repack=False):
+        """Flatten on first use / after `.to()`; refresh the packed weights.  `nn.Parameter.data` views do not share a
+        version counter with the flat buffer, so a foreign optimiser's in-place step cannot be detected: public entry
+        points (update / predict) repack unconditionally (one ~20 us launch) unless the step harness, which owns the
+        optimiser, vouches for the packed copy through `_packed_valid`."""
+        if not self._is_flat():
+            self._flatten()
+        if self._packed_version < 0 or (repack and not self._packed_valid):
+            ops.lib().call("wtpse_pack_conv_weights", self._flat.data_ptr(), self._desc.data_ptr(), len(self._convs),
+                           self._packed.data_ptr(), ops.stream_ptr())
+            object.__setattr__(self, "_packed_version", 1)
+
+    def invalidate_packed(self):
+        object.__setattr__(self, "_packed_version", -1)
+
+    def packed_ptr(self, off):
+        return self._packed.data_ptr() + 4 * off
+
+    def flat_params(self):
+        self.ensure_ready()
+        return self._flat
+
+    def flat_grads(self):
+        self.ensure_ready()
+        return self._gflat
+
+    def param_offset(self, p):
+        return self._offsets[self._pindex[id(p)]]
+
+    # ---- gradients -----------------------------------------------------------------------------------------
+    def begin_backward(self):
+        """Choose the buffer this backward writes into: the attached flat gradient when every .grad is None
+        (the normal zero_grad(set_to_none=True) flow), a work buffer otherwise (accumulation semantics)."""
+        self._touched.clear()
+        clean = all(p.grad is None for p in self.parameters())
+        if clean:
+            object.__setattr__(self, "_gtarget", self._gflat)
+        else:
+            if self._gwork is None:
+                object.__setattr__(self, "_gwork", torch.zeros_like(self._gflat))
+            object.__setattr__(self, "_gtarget", self._gwork)
+
+    def gview(self, p):
+        """View of the current gradient target for parameter p; marks p as reached by this backward."""
+        i = self._pindex[id(p)]
+        self._touched.append(p)
+        off = self._offsets[i]
+        return self._gtarget[off:off + p.numel()]
+
+    def end_backward(self):
+        if self._dp is not None:
+            self._dp.allreduce_grads(self, self._gtarget)
+        direct = self._gtarget is self._gflat
+        if direct and not self._attach_grads:   # the step harness reads the flat buffer itself
+            self._touched.clear()
+            return
+        for p in self._touched:
+            off = self._offsets[self._pindex[id(p)]]
+            g = self._gtarget[off:off + p.numel()].view(p.shape)
+            if direct:
+                p.grad = g
+            elif p.grad is None:
+                p.grad = g.clone()
+            else:
+                ops.axpy(p.grad, g.contiguous(), 1.0) if p.grad.is_contiguous() else p.grad.add_(g)
+        self._touched.clear()
+
+    # ---- sampling noise --------------------------------------------------------------------------------------
+    def set_noise(self, tensors):
+        """Inject the standard-normal draws of the next sampling calls (parity tests); [] returns to Philox."""
+        object.__setattr__(self, "_noise_queue", list(tensors))
+
+    def seed_noise(self, seed):
+        object.__setattr__(self, "_noise_seed", int(seed))
+        object.__setattr__(self, "_noise_counter", 0)
+
+    def next_noise(self, shape):
+        if self._noise_queue:
+            e = self._noise_queue.pop(0)
+            assert tuple(e.shape) == tuple(shape), (e.shape, shape)
+            return e.to(self._flat.device, torch.float32).contiguous()
+        n = 1
+        for s in shape:
+            n *= int(s)
+        n4 = (n + 3) & ~3
+        off = self._noise_counter
+        row_off = 0
+        if self._dp is not None:   # global row index so that any sharding reproduces the 1-GPU stream
+            n4, row_off = self._dp.noise_span(shape)
+        object.__setattr__(self, "_noise_counter", off + n4)
+        return ops.randn(shape, self._flat.device, self._noise_seed, off + row_off)
+
+
+# ================================================================================================ block schedules
+class Tape:
+    """Attribute bag holding what a block's backward needs."""
+    pass
+
+
+def _conv(layer, x0, x1=None, pro_relu=0, relu_out=False, want_stats=False):
+    root = layer._root
+    y, _, stats = ops.conv_fwd(x0, x1, root.packed_ptr(layer.wf_off), layer.bias, layer.cout, layer.k, None, pro_relu,
+                               relu_out, want_stats)
+    return y, stats
+
+
+def _dgrad(layer, dy, split=None):
+    root = layer._root
+    return ops.conv_fwd(dy, None, root.packed_ptr(layer.wd_off), None, layer.cin, layer.k, None, 0, False, False, split)[:2]
+
+
+def _wgrad(layer, dy, x0, x1=None, pro_relu=0, with_bias=True):
+    root = layer._root
+    dw = root.gview(layer.weight)
+    db = root.gview(layer.bias) if with_bias else None
+    ops.conv_wgrad(dy, x0, x1, layer.k, dw, db, None, pro_relu, False)
+
+
+# ---- conv + BatchNorm (+ReLU), activations materialised ------------------------------------------------------
+def convbn_fwd(conv, bn, x0, x1, relu, training, pro_relu=0, want_tape=True):
+    root = conv._root
+    if training:
+        y, stats = _conv(conv, x0, x1, pro_relu, False, True)
+        B, _, H, W = y.shape
+        if root._dp is not None and root._dp.bn_sync:
+            stats, count = root._dp.sync_bn_stats(stats, B * H * W)
+        else:
+            count = B * H * W
+        ss, mean, invstd = ops.bn_finalize(stats, count, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                           bn.num_batches_tracked)
+    else:
+        y, _ = _conv(conv, x0, x1, pro_relu, False, False)
+        ss = ops.bn_eval_coeffs(bn.weight, bn.bias, bn.running_mean, bn.running_var)
+        mean = invstd = None
+    z = ops.affine_act(y, ss, relu)
+    if not want_tape:
+        return z, None
+    t = Tape()
+    t.x0, t.x1, t.pro_relu, t.y, t.ss, t.mean, t.invstd, t.relu = x0, x1, pro_relu, y, ss, mean, invstd, relu
+    return z, t
+
+
+def convbn_bwd(conv, bn, t, dz, need_dx=True):
+    """-> (dx0, dx1): gradients wrt the inputs AS LOADED (i.e. after a ReLU-on-load, if any)."""
+    root = conv._root
+    if root._dp is not None and root._dp.bn_sync:
+        dy = root._dp.bn_bwd_synced(dz, t, bn, root)
+    else:
+        dy = ops.bn_bwd(dz, t.y, t.ss, t.relu, bn.weight, t.mean, t.invstd, root.gview(bn.weight), root.gview(bn.bias))
+    # the conv bias in front of a train-mode BatchNorm has an exactly-zero gradient (sum of dy over the batch
+    # vanishes); the reference carries rounding noise there. It is left at 0.
+    _wgrad(conv, dy, t.x0, t.x1, t.pro_relu, with_bias=False)
+    if not need_dx:
+        return None, None
+    split = t.x0.shape[1] if t.x1 is not None else None
+    return _dgrad(conv, dy, split)
+
+
+# ---- ConvD (algorithms.py:897-917) ---------------------------------------------------------------------------
+def convd_fwd(blk, x, x_relu, training, want_tape=True):
+    t = Tape()
+    t.x, t.x_relu = x, x_relu
+    h = x if blk.first else ops.maxpool2_fwd(x, None, x_relu)
+    a, t.c1 = convbn_fwd(blk.conv1, blk.bn1, h, None, False, training, pro_relu=(1 if (blk.first and x_relu) else 0),
+                         want_tape=want_tape)
+    b, t.c2 = convbn_fwd(blk.conv2, blk.bn2, a, None, True, training, want_tape=want_tape)
+    c, t.c3 = convbn_fwd(blk.conv3, blk.bn3, b, None, True, training, want_tape=want_tape)
+    return c, t
+
+
+def convd_bwd(blk, t, dz, dx_accum=None, need_dx=True):
+    """dx_accum: existing gradient buffer of x (skip connection) to accumulate into, or None."""
+    d, _ = convbn_bwd(blk.conv3, blk.bn3, t.c3, dz)
+    d, _ = convbn_bwd(blk.conv2, blk.bn2, t.c2, d)
+    d, _ = convbn_bwd(blk.conv1, blk.bn1, t.c1, d, need_dx=need_dx)
+    if not need_dx:
+        return None
+    if blk.first:
+        if dx_accum is not None:
+            ops.axpy(dx_accum, d)
+            return dx_accum
+        return d
+    return ops.maxpool2_bwd(t.x, d, dx_accum, dx_accum is not None, None, t.x_relu)
+
+
+# ---- ConvU (algorithms.py:941-962) ---------------------------------------------------------------------------
+def convu_fwd(blk, x, prev, prev_relu, training, want_tape=True):
+    t = Tape()
+    if not blk.first:
+        x, t.c1 = convbn_fwd(blk.conv1, blk.bn1, x, None, True, training, want_tape=want_tape)
+    u = ops.upsample2x_fwd(x)
+    y, t.c2 = convbn_fwd(blk.conv2, blk.bn2, u, None, True, training, want_tape=want_tape)
+    out, t.c3 = convbn_fwd(blk.conv3, blk.bn3, prev, y, True, training, pro_relu=(1 if prev_relu else 0),
+                           want_tape=want_tape)
+    return out, t
+
+
+def convu_bwd(blk, t, dout):
+    """-> (dx, dprev); dprev is wrt prev as loaded."""
+    dprev, dy = convbn_bwd(blk.conv3, blk.bn3, t.c3, dout)
+    du, _ = convbn_bwd(blk.conv2, blk.bn2, t.c2, dy)
+    dx = ops.upsample2x_bwd(du)
+    if not blk.first:
+        dx, _ = convbn_bwd(blk.conv1, blk.bn1, t.c1, dx)
+    return dx, dprev
+
+
+# ---- U-Net body ------------------------------------------------------------------------------------------------
+def unet_fwd(net, x1, x1_relu, training, want_tape=True):
+    t = Tape()
+    x2, t.d1 = convd_fwd(net.down1, x1, x1_relu, training, want_tape)
+    x3, t.d2 = convd_fwd(net.down2, x2, False, training, want_tape)
+    x4, t.d3 = convd_fwd(net.down3, x3, False, training, want_tape)
+    x5, t.d4 = convd_fwd(net.down4, x4, False, training, want_tape)
+    x, t.u1 = convu_fwd(net.up1, x5, x4, False, training, want_tape)
+    x, t.u2 = convu_fwd(net.up2, x, x3, False, training, want_tape)
+    x, t.u3 = convu_fwd(net.up3, x, x2, False, training, want_tape)
+    x, t.u4 = convu_fwd(net.up4, x, x1, x1_relu, training, want_tape)
+    return x, t
+
+
+def unet_bwd(net, t, dfeat, need_dx1=True):
+    """-> gradient wrt x1 as loaded (None if not needed)."""
+    d, g1 = convu_bwd(net.up4, t.u4, dfeat)
+    d, g2 = convu_bwd(net.up3, t.u3, d)
+    d, g3 = convu_bwd(net.up2, t.u2, d)
+    g5, g4 = convu_bwd(net.up1, t.u1, d)
+    convd_bwd(net.down4, t.d4, g5, g4)
+    convd_bwd(net.down3, t.d3, g4, g3)
+    convd_bwd(net.down2, t.d2, g3, g2)
+    convd_bwd(net.down1, t.d1, g2, g1)
+    return g1 if need_dx1 else None
+
+
+# ---- 1x1 heads: conv, ReLU, conv, ReLU, conv (algorithms.py:1006-1012) / conv, ReLU, conv (:1199-1200) -------------
+def head_fwd(seq, x, idxs, want_tape=True):
+    t = Tape()
+    t.x, t.acts = x, []
+    h = x
+    for n, i in enumerate(idxs):
+        last = n == len(idxs) - 1
+        h, _ = _conv(seq[i], h, None, 0, not last, False)
+        t.acts.append(h)
+    return h, t
+
+
+def head_bwd(seq, t, d, idxs):
+    for n in reversed(range(len(idxs))):
+        layer = seq[idxs[n]]
+        inp = t.x if n == 0 else t.acts[n - 1]
+        if n != len(idxs) - 1:
+            d = ops.relu_mask(d, t.acts[n])
+        _wgrad(layer, d, inp)
+        d, _ = _dgrad(layer, d)
+    return d
+
+
+# ---- DeepWT (algorithms.py:1091-1117) -----------------------------------------------------------------------------
+def deepwt_fwd(wt, x, want_tape=True):
+    t = Tape()
+    a, b = wt.DoubleConv.double_conv, wt.DoubleConv2.double_conv
+    t.x = x
+    t.h1, _ = _conv(a[0], x, None, 0, True)
+    t.z1, _ = _conv(a[2], t.h1)
+    t.h2, _ = _conv(b[0], t.z1, None, 1, True)     # ReLU(z1) on load
+    t.z2, _ = _conv(b[2], t.h2)
+    return t
+
+
+def deepwt_bwd(wt, t, dz2, dz1_extra=None):
+    """dz2: total gradient wrt z2 (raw).  dz1_extra(dz1): callback adding the WT-loss gradient of z1 in place."""
+    a, b = wt.DoubleConv.double_conv, wt.DoubleConv2.double_conv
+    _wgrad(b[2], dz2, t.h2)
+    d, _ = _dgrad(b[2], dz2)
+    d = ops.relu_mask(d, t.h2)
+    _wgrad(b[0], d, t.z1, None, 1)
+    d, _ = _dgrad(b[0], d)
+    dz1 = ops.relu_mask(d, t.z1)
+    if dz1_extra is not None:
+        dz1_extra(dz1)
+    _wgrad(a[2], dz1, t.h1)
+    d, _ = _dgrad(a[2], dz1)
+    d = ops.relu_mask(d, t.h1)
+    _wgrad(a[0], d, t.x)
+
+
+# ---- teacher: ShapeVariationalDist_y_x (algorithms.py:1014-1033,1055-1075) ---------------------------------------------
+def teacher_fwd(tn, feat, feat_relu, mask, training, want_logvar=True, want_tape=True):
+    """feat: z2 (feat_relu=True: ReLU on load) or an already-activated tensor."""
+    t = Tape()
+    inc = tn.inc.double_conv
+    m1, t.i0 = convbn_fwd(inc[0], inc[1], mask, None, True, training, want_tape=want_tape)
+    m2, t.i3 = convbn_fwd(inc[3], inc[4], m1, None, True, training, want_tape=want_tape)
+    t.m2, t.feat, t.feat_relu = m2, feat, feat_relu
+    t.xf, _ = _conv(tn.fusion[0], m2, feat, 2 if feat_relu else 0, True)
+    fmap, t.unet = unet_fwd(tn, t.xf, False, training, want_tape)
+    t.mu, t.hmu = head_fwd(tn.mu_prior, fmap, (0, 2, 4), want_tape)
+    if want_logvar:
+        t.logvar, t.hlv = head_fwd(tn.logvar_prior, fmap, (0, 2, 4), want_tape)
+    return t
+
+
+def teacher_bwd(tn, t, dmu, dlogvar):
+    """-> gradient wrt feat as loaded (i.e. wrt relu(z2) when feat_relu)."""
+    d = head_bwd(tn.mu_prior, t.hmu, dmu, (0, 2, 4))
+    if dlogvar is not None:
+        d2 = head_bwd(tn.logvar_prior, t.hlv, dlogvar, (0, 2, 4))
+        ops.axpy(d, d2)
+    dxf = unet_bwd(tn, t.unet, d)
+    dxf = ops.relu_mask(dxf, t.xf)
+    _wgrad(tn.fusion[0], dxf, t.m2, t.feat, 2 if t.feat_relu else 0)
+    dm2, dfeat = _dgrad(tn.fusion[0], dxf, split=t.m2.shape[1])
+    inc = tn.inc.double_conv
+    dm1, _ = convbn_bwd(inc[3], inc[4], t.i3, dm2)
+    convbn_bwd(inc[0], inc[1], t.i0, dm1, need_dx=False)
+    return dfeat

@@ -1,0 +1,340 @@
+"""Thin host wrappers over the C ABI (include/wtpse_hip.h): allocate outputs/scratch with torch (device
+memory + stream plumbing only) and launch on torch's current HIP stream.  No arithmetic happens here."""
+import torch
+
+from .lib import lib
+
+_WS = {}
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _chk(t, name="tensor"):
+    if t is None:
+        return
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise ValueError("%s must be a contiguous fp32 tensor in device memory (got %s, %s, contiguous=%s)"
+                         % (name, t.device, t.dtype, t.is_contiguous()))
+
+
+def workspace(tag, nfloats, device):
+    """Persistent scratch, one buffer per (device, tag), grown on demand (single-stream use)."""
+    key = (str(device), tag)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nfloats:
+        buf = torch.empty(max(int(nfloats), 1024), dtype=torch.float32, device=device)
+        _WS[key] = buf
+    return buf
+
+
+# ----------------------------------------------------------------------------------------------- convolution
+def conv_fwd(in0, in1, wpacked_ptr, bias, cout, ksize, pro=None, pro_relu=0, relu_out=False, want_stats=False,
+             split=None):
+    """-> (out0, out1 or None, stats or None).  `wpacked_ptr` is a raw device pointer into the packed-weight buffer."""
+    _chk(in0, "in0"); _chk(in1, "in1"); _chk(pro, "pro")
+    B, C0, H, W = in0.shape
+    C1 = 0 if in1 is None else in1.shape[1]
+    L = lib()
+    if split is None:
+        out0 = torch.empty((B, cout, H, W), dtype=torch.float32, device=in0.device)
+        out1 = None
+        csplit = cout
+    else:
+        csplit = int(split)
+        out0 = torch.empty((B, csplit, H, W), dtype=torch.float32, device=in0.device)
+        out1 = torch.empty((B, cout - csplit, H, W), dtype=torch.float32, device=in0.device)
+    stats = None
+    if want_stats:
+        nblk = L.query("wtpse_conv_stats_blocks", B, H, W)
+        stats = torch.empty((nblk, cout, 2), dtype=torch.float32, device=in0.device)
+    L.call("wtpse_conv_fwd", ptr(in0), C0, ptr(in1), C1, wpacked_ptr, ptr(bias), ptr(pro), int(pro_relu), ptr(out0),
+           ptr(out1), csplit, ptr(stats), B, H, W, cout, ksize, int(relu_out), stream_ptr())
+    return out0, out1, stats
+
+
+def conv_wgrad(dy, x0, x1, ksize, dw, dbias, pro=None, pro_relu=0, accumulate=False):
+    """dw / dbias are views into the flat gradient buffer ([Cout,Cin,k,k] / [Cout] or None)."""
+    _chk(dy, "dy"); _chk(x0, "x0"); _chk(x1, "x1")
+    B, cout, H, W = dy.shape
+    C0 = x0.shape[1]
+    C1 = 0 if x1 is None else x1.shape[1]
+    cin = C0 + C1
+    L = lib()
+    ks = L.query("wtpse_wgrad_ksplit", B, H, W, cin, cout)
+    slab = workspace("wgrad_slab", ks * cout * cin * ksize * ksize, dy.device)
+    dbs = workspace("wgrad_dbias", ks * cout, dy.device) if dbias is not None else None
+    L.call("wtpse_conv_wgrad", ptr(dy), ptr(x0), C0, ptr(x1), C1, ptr(pro), int(pro_relu), ptr(slab), ptr(dbs), ks,
+           ptr(dw), ptr(dbias), int(accumulate), B, H, W, cout, ksize, stream_ptr())
+
+
+# ----------------------------------------------------------------------------------------------- batch norm
+def bn_finalize(stats, count, gamma, beta, rmean, rvar, nbt, momentum=0.1, eps=1e-5):
+    nblk, C, _ = stats.shape
+    dev = stats.device
+    ss = torch.empty((C, 2), dtype=torch.float32, device=dev)
+    mean = torch.empty((C,), dtype=torch.float32, device=dev)
+    invstd = torch.empty((C,), dtype=torch.float32, device=dev)
+    lib().call("wtpse_bn_finalize", ptr(stats), nblk, C, int(count), ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar),
+               ptr(nbt), float(momentum), float(eps), ptr(ss), ptr(mean), ptr(invstd), stream_ptr())
+    return ss, mean, invstd
+
+
+def bn_eval_coeffs(gamma, beta, rmean, rvar, eps=1e-5):
+    C = gamma.numel()
+    ss = torch.empty((C, 2), dtype=torch.float32, device=gamma.device)
+    lib().call("wtpse_bn_eval_coeffs", ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), float(eps), C, ptr(ss), stream_ptr())
+    return ss
+
+
+def affine_act(y, ss, relu):
+    _chk(y, "y")
+    B, C, H, W = y.shape
+    z = torch.empty_like(y)
+    lib().call("wtpse_affine_act", ptr(y), ptr(ss), int(relu), ptr(z), B, C, H * W, stream_ptr())
+    return z
+
+
+def bn_bwd(dz, y, ss, relu, gamma, mean, invstd, dgamma, dbeta, accumulate=False):
+    _chk(dz, "dz"); _chk(y, "y")
+    B, C, H, W = y.shape
+    L = lib()
+    ns = L.query("wtpse_bn_bwd_nsplit", B, C, H * W)
+    partial = workspace("bn_bwd_partial", ns * C * 2, y.device)
+    coef = workspace("bn_bwd_coef", C * 3, y.device)
+    dy = torch.empty_like(y)
+    L.call("wtpse_bn_bwd", ptr(dz), ptr(y), ptr(ss), int(relu), ptr(gamma), ptr(mean), ptr(invstd), ptr(partial),
+           ptr(coef), ptr(dgamma), ptr(dbeta), int(accumulate), ptr(dy), B, C, H * W, stream_ptr())
+    return dy
+
+
+# ----------------------------------------------------------------------------------------------- WT loss
+class WtLossState:
+    __slots__ = ("z", "gram", "offdiag", "diag", "dmmd_dv", "losses", "v", "B", "HW", "D", "n", "margin")
+
+
+def wt_loss_fwd(z, domain_num, per_domain, margin=0.0, eps=1e-5, losses_out=None):
+    """-> WtLossState; st.losses = device [3] = (ins_offdiag, ins_diag, domain)."""
+    _chk(z, "z")
+    B, C, H, W = z.shape
+    HW = H * W
+    dev = z.device
+    L = lib()
+    S = L.query("wtpse_wt_split", B, HW, 0)
+    R = domain_num * per_domain
+    st = WtLossState()
+    partial = workspace("wt_partial", B * S * 256, dev)
+    st.gram = torch.empty((B, 256), dtype=torch.float32, device=dev)
+    st.v = torch.empty((B, 120), dtype=torch.float32, device=dev)
+    st.offdiag = torch.empty((B,), dtype=torch.float32, device=dev)
+    st.diag = torch.empty((B,), dtype=torch.float32, device=dev)
+    rowval = torch.empty((max(R, 1),), dtype=torch.float64, device=dev)
+    st.dmmd_dv = torch.empty((max(R, 1), 120), dtype=torch.float32, device=dev)
+    st.losses = losses_out if losses_out is not None else torch.empty((3,), dtype=torch.float32, device=dev)
+    L.call("wtpse_wt_loss_fwd", ptr(z), B, C, HW, float(eps), float(margin), int(domain_num), int(per_domain),
+           ptr(partial), ptr(st.gram), ptr(st.v), ptr(st.offdiag), ptr(st.diag), ptr(rowval), ptr(st.dmmd_dv),
+           ptr(st.losses), stream_ptr())
+    st.z, st.B, st.HW, st.D, st.n, st.margin = z, B, HW, domain_num, per_domain, float(margin)
+    return st
+
+
+def wt_loss_bwd(st, dz, accumulate, g_off=None, g_diag=None, g_dom=None, w_off=1.0, w_diag=1.0, w_dom=1.0):
+    _chk(dz, "dz")
+    Mws = workspace("wt_M", st.B * 256, dz.device)
+    lib().call("wtpse_wt_loss_bwd", ptr(st.z), st.B, 16, st.HW, st.margin, st.D, st.n, ptr(st.gram), ptr(st.offdiag),
+               ptr(st.diag), ptr(st.dmmd_dv), ptr(g_off), ptr(g_diag), ptr(g_dom), float(w_off), float(w_diag),
+               float(w_dom), ptr(Mws), ptr(dz), int(accumulate), stream_ptr())
+
+
+def wt_combine(losses, den, mode, out=None):
+    """losses [nmaps,3] -> out[4] = (ins_total, ins_off, ins_diag, dom); mode 1 = student accumulator quirk."""
+    if out is None:
+        out = torch.empty((4,), dtype=torch.float32, device=losses.device)
+    lib().call("wtpse_wt_combine", ptr(losses), losses.shape[0], float(den), int(mode), ptr(out), stream_ptr())
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- pooling etc.
+def maxpool2_fwd(x, pro=None, relu=False):
+    _chk(x, "x")
+    B, C, H, W = x.shape
+    out = torch.empty((B, C, H // 2, W // 2), dtype=torch.float32, device=x.device)
+    lib().call("wtpse_maxpool2_fwd", ptr(x), ptr(pro), int(relu), ptr(out), B, C, H, W, stream_ptr())
+    return out
+
+
+def maxpool2_bwd(x, dout, dx, accumulate, pro=None, relu=False):
+    B, C, H, W = x.shape
+    if dx is None:
+        dx = torch.empty_like(x)
+        accumulate = False
+    lib().call("wtpse_maxpool2_bwd", ptr(x), ptr(pro), int(relu), ptr(dout), ptr(dx), int(accumulate), B, C, H, W,
+               stream_ptr())
+    return dx
+
+
+def upsample2x_fwd(x, pro=None, relu=False):
+    _chk(x, "x")
+    B, C, H, W = x.shape
+    out = torch.empty((B, C, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
+    lib().call("wtpse_upsample2x_fwd", ptr(x), ptr(pro), int(relu), ptr(out), B, C, H, W, stream_ptr())
+    return out
+
+
+def upsample2x_bwd(dout):
+    _chk(dout, "dout")
+    B, C, Ho, Wo = dout.shape
+    dx = torch.empty((B, C, Ho // 2, Wo // 2), dtype=torch.float32, device=dout.device)
+    lib().call("wtpse_upsample2x_bwd", ptr(dout), ptr(dx), 0, B, C, Ho // 2, Wo // 2, stream_ptr())
+    return dx
+
+
+def relu_mask(dz, ref, out=None, accumulate=False):
+    _chk(dz, "dz"); _chk(ref, "ref")
+    if out is None:
+        out = torch.empty_like(dz)
+        accumulate = False
+    lib().call("wtpse_relu_mask", ptr(dz), ptr(ref), ptr(out), int(accumulate), dz.numel(), stream_ptr())
+    return out
+
+
+def axpy(dst, src, alpha=1.0):
+    lib().call("wtpse_axpy", ptr(dst), ptr(src), float(alpha), dst.numel(), stream_ptr())
+    return dst
+
+
+def zero_(t):
+    lib().call("wtpse_zero", ptr(t), t.numel() * t.element_size(), stream_ptr())
+    return t
+
+
+# ----------------------------------------------------------------------------------------------- attention / sampling
+def attn_fuse_fwd(z, wb_ptr, emb, coef, want_att=True, want_pre=False, want_mask=False):
+    _chk(z, "z"); _chk(emb, "emb")
+    B, CE, H, W = emb.shape
+    att = torch.empty_like(z) if want_att else None
+    pre = torch.empty_like(z) if want_pre else None
+    mask = torch.empty_like(z) if want_mask else None
+    fuse = torch.empty_like(emb)
+    lib().call("wtpse_attn_fuse_fwd", ptr(z), wb_ptr, ptr(emb), float(coef), ptr(att), ptr(pre), ptr(mask), ptr(fuse),
+               B, CE, H * W, stream_ptr())
+    return att, pre, mask, fuse
+
+
+def attn_fuse_bwd(dfuse, z, emb, att, wb_ptr, coef, d_wb_ptr, want_dz=True, accumulate=False):
+    B, CE, H, W = emb.shape
+    demb = torch.empty_like(emb)
+    dz = torch.empty_like(z) if want_dz else None
+    nb = (B * H * W + 255) // 256
+    partial = workspace("attn_partial", 2 * nb, emb.device)
+    lib().call("wtpse_attn_fuse_bwd", ptr(dfuse), ptr(z), ptr(emb), ptr(att), wb_ptr, float(coef), ptr(demb), ptr(dz),
+               ptr(partial), d_wb_ptr, int(accumulate), B, CE, H * W, stream_ptr())
+    return demb, dz
+
+
+def reparam_fwd(mu, logvar, eps):
+    z = torch.empty_like(mu)
+    lib().call("wtpse_reparam_fwd", ptr(mu), ptr(logvar), ptr(eps), ptr(z), mu.numel(), stream_ptr())
+    return z
+
+
+def reparam_bwd(dz, logvar, eps):
+    dlv = torch.empty_like(dz)
+    lib().call("wtpse_reparam_bwd", ptr(dz), ptr(logvar), ptr(eps), ptr(dlv), dz.numel(), stream_ptr())
+    return dlv
+
+
+def reparam_student(mu, logvar, eps, flag):
+    std = torch.empty_like(mu)
+    lib().call("wtpse_exp_half", ptr(logvar), ptr(std), mu.numel(), stream_ptr())
+    nan_scrub_(std, flag)
+    z = torch.empty_like(mu)
+    lib().call("wtpse_reparam_student", ptr(mu), ptr(std), ptr(eps), ptr(z), mu.numel(), stream_ptr())
+    return z
+
+
+def nan_scrub_(x, flag):
+    lib().call("wtpse_nan_scrub", ptr(x), x.numel(), flag.data_ptr(), stream_ptr())
+    return x
+
+
+def randn(shape, device, seed, offset=0):
+    out = torch.empty(shape, dtype=torch.float32, device=device)
+    lib().call("wtpse_randn", ptr(out), out.numel(), int(seed) & 0xFFFFFFFFFFFFFFFF, int(offset), stream_ptr())
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- losses / optimiser
+def _red_ws(n, device, mult=1):
+    nb = lib().query("wtpse_reduce_blocks", n)
+    return workspace("loss_partial", nb * mult, device)
+
+
+def bce_sigmoid_fwd(x, t):
+    loss = torch.empty((), dtype=torch.float32, device=x.device)
+    lib().call("wtpse_bce_sigmoid_fwd", ptr(x), ptr(t), x.numel(), ptr(_red_ws(x.numel(), x.device)), ptr(loss), stream_ptr())
+    return loss
+
+
+def bce_sigmoid_bwd(x, t, g=None, w=1.0):
+    dx = torch.empty_like(x)
+    lib().call("wtpse_bce_sigmoid_bwd", ptr(x), ptr(t), ptr(g), float(w), x.numel(), ptr(dx), stream_ptr())
+    return dx
+
+
+def pos_weight_sums(mask, t):
+    """device [2] = (sum mask, sum mask*t) of THIS rank's rows (all-reduce before pos_weight_from_sums under DP)."""
+    sums = torch.empty((2,), dtype=torch.float32, device=mask.device)
+    pw = torch.empty((), dtype=torch.float32, device=mask.device)
+    lib().call("wtpse_pos_weight", ptr(mask), ptr(t), mask.numel(), ptr(_red_ws(mask.numel(), mask.device, 2)), ptr(sums),
+               ptr(pw), stream_ptr())
+    return sums, pw
+
+
+def pos_weight_from_sums(sums):
+    pw = torch.empty((), dtype=torch.float32, device=sums.device)
+    lib().call("wtpse_pos_weight_from_sums", ptr(sums), ptr(pw), stream_ptr())
+    return pw
+
+
+def bce_logits_pw_fwd(x, mask, t, pw):
+    loss = torch.empty((), dtype=torch.float32, device=x.device)
+    lib().call("wtpse_bce_logits_pw_fwd", ptr(x), ptr(mask), ptr(t), ptr(pw), x.numel(), ptr(_red_ws(x.numel(), x.device)),
+               ptr(loss), stream_ptr())
+    return loss
+
+
+def bce_logits_pw_bwd(x, mask, t, pw, g=None, w=1.0):
+    dx = torch.empty_like(x)
+    lib().call("wtpse_bce_logits_pw_bwd", ptr(x), ptr(mask), ptr(t), ptr(pw), ptr(g), float(w), x.numel(), ptr(dx), stream_ptr())
+    return dx
+
+
+def mse_fwd(a, b, out=None):
+    loss = out if out is not None else torch.empty((), dtype=torch.float32, device=a.device)
+    lib().call("wtpse_mse_fwd", ptr(a), ptr(b), a.numel(), ptr(_red_ws(a.numel(), a.device)), ptr(loss), stream_ptr())
+    return loss
+
+
+def mse_bwd(a, b, g=None, w=1.0):
+    da = torch.empty_like(a)
+    lib().call("wtpse_mse_bwd", ptr(a), ptr(b), ptr(g), float(w), a.numel(), ptr(da), stream_ptr())
+    return da
+
+
+def roi(image, logit):
+    B, C, H, W = image.shape
+    out = torch.empty_like(image)
+    od = torch.empty_like(logit)
+    lib().call("wtpse_roi", ptr(image), ptr(logit), ptr(out), ptr(od), B, C, H * W, stream_ptr())
+    return out, od
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step):
+    lib().call("wtpse_adam", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
+               int(step), stream_ptr())

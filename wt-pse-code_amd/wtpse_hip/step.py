@@ -1,0 +1,111 @@
+"""The training step: counterpart of the body of the reference's hot loop (Trainer.py:766-914).
+
+One `TrainStep.step()` = the four `update()` calls A-D, their four backward passes and four Adam steps over the
+four networks of train.py:91-138, in the reference's order:
+
+    A  seg-net OD   : BCELoss(sigmoid(out), target_od) + gm_i*ins + gm_d*dom            (Trainer.py:779-805)
+    B  shape-net OD : kd + gm_i*ins_total + gm_d*dom                                     (:810-825)
+       ROI          : od_pred = sigmoid(out) > 0.75 ; roi = (image+1)*od_pred - 1       (:842-853)
+    C  seg-net OC   : BCEWithLogits(out*od_pred, target_oc, pos_weight) + wt terms       (:856-892)
+    D  shape-net OC : as B on the ROI                                                    (:894-914)
+
+Differences from the reference loop that cannot change a result: no per-iteration `.item()` host syncs or
+tensorboard scalars (losses stay on the device), fused Adam over the flat parameter buffer instead of ~390
+per-tensor updates, and the dead work listed in shape_networks.py's header is skipped.
+"""
+import torch
+
+from . import ops
+
+
+class FlatAdam:
+    """torch.optim.Adam(lr, betas, eps=1e-8, weight_decay=0) over a network's flat buffers: one launch per step."""
+
+    def __init__(self, net, lr=5e-4, betas=(0.9, 0.99), eps=1e-8):
+        self.net, self.lr, self.betas, self.eps = net, lr, betas, eps
+        self.t = 0
+        self.m = self.v = None
+
+    def step(self):
+        net = self.net
+        p, g = net.flat_params(), net.flat_grads()
+        if self.m is None:
+            self.m = ops.zero_(torch.empty_like(p))
+            self.v = ops.zero_(torch.empty_like(p))
+        self.t += 1
+        ops.adam_step(p, g, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.t)
+        net.invalidate_packed()
+        net.ensure_ready()
+
+
+class TrainStep:
+    def __init__(self, model_od, shape_od, model_oc, shape_oc, hparams, lr=5e-4, betas=(0.9, 0.99), dp=None):
+        self.hp = hparams
+        self.full = bool(hparams['whitening'])
+        self.nets = [model_od, model_oc] + ([shape_od, shape_oc] if self.full else [])
+        self.model_od, self.shape_od, self.model_oc, self.shape_oc = model_od, shape_od, model_oc, shape_oc
+        self.dp = dp
+        for n in self.nets:
+            n.train()
+            n.ensure_ready(repack=True)
+            object.__setattr__(n, "_packed_valid", True)     # this harness owns the optimiser and repacks after each step
+            object.__setattr__(n, "_attach_grads", False)
+            object.__setattr__(n, "_dp", dp)
+        if dp is not None:
+            dp.broadcast_params(self.nets)
+        self.opt = {id(n): FlatAdam(n, lr, betas) for n in self.nets}
+
+    def _seg_call(self, model, x, target, noise, od_pred):
+        """forward + loss + backward + Adam of one segmentation network; -> (logits, losses dict of device scalars)."""
+        gi, gd = float(self.hp['instance_wt_gm']), float(self.hp['domain_wt_gm'])
+        if noise is not None:
+            model.set_noise([noise])
+        res, tape = model._forward_update(x, target, x, want_tape=True)
+        out = res[0]
+        if od_pred is None:
+            loss = ops.bce_sigmoid_fwd(out, target)
+            d_out = ops.bce_sigmoid_bwd(out, target)
+        else:
+            sums, pw = ops.pos_weight_sums(od_pred, target)
+            if self.dp is not None:
+                pw = ops.pos_weight_from_sums(self.dp.allreduce_sum(sums))
+            loss = ops.bce_logits_pw_fwd(out, od_pred, target, pw)
+            d_out = ops.bce_logits_pw_bwd(out, od_pred, target, pw)
+        model._backward_update(tape, d_out, None, None, w_ins=gi, w_dom=gd)
+        self.opt[id(model)].step()
+        r = {"seg": loss}
+        if self.full:
+            r["ins"], r["dom"] = res[2][0], res[2][3]
+        return out, r
+
+    def _shape_call(self, shape, model, x, target):
+        gi, gd = float(self.hp['instance_wt_gm']), float(self.hp['domain_wt_gm'])
+        r = None
+        for _ in range(int(self.hp['multi-turn'])):
+            scal, tape = shape._forward_update(model, x, target, want_tape=True)
+            shape._backward_update(tape, None, None, None, None, w_kd=1.0, w_off=gi, w_diag=gi, w_dom=gd)
+            self.opt[id(shape)].step()
+            r = {"kd": scal[0], "ins_total": scal[1], "ins_off": scal[2], "ins_diag": scal[3], "dom": scal[4]}
+        return r
+
+    def step(self, image, target_od, target_oc, noise=None):
+        """image [B,3,H,W] in [-1,1], targets [B,1,H,W] in {0,1}; all device fp32, rows domain-major.
+        noise: optional {'a': eps, 'c': eps} standard-normal [B,1,H,W] (parity runs); default Philox.
+        Returns {name: 0-dim device tensor}; nothing is synchronised with the host."""
+        noise = noise or {}
+        image = image.contiguous()
+        out, ra = self._seg_call(self.model_od, image, target_od, noise.get("a"), None)
+        res = {"seg_od": ra["seg"]}
+        if self.full:
+            res.update(ins_od=ra["ins"], dom_od=ra["dom"])
+            rb = self._shape_call(self.shape_od, self.model_od, image, target_od)
+            res.update(kd_od=rb["kd"], ins_shape_od=rb["ins_total"], ins_ij_od=rb["ins_off"], ins_ii_od=rb["ins_diag"],
+                       dom_shape_od=rb["dom"])
+        roi, od_pred = ops.roi(image, out)
+        out_oc, rc = self._seg_call(self.model_oc, roi, target_oc, noise.get("c"), od_pred)
+        res["seg_oc"] = rc["seg"]
+        if self.full:
+            res.update(ins_oc=rc["ins"], dom_oc=rc["dom"])
+            rd = self._shape_call(self.shape_oc, self.model_oc, roi, target_oc)
+            res.update(kd_oc=rd["kd"], ins_shape_oc=rd["ins_total"], dom_shape_oc=rd["dom"])
+        return res
