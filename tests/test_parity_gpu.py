@@ -53,7 +53,12 @@ def is_prebn_bias(k):
 
 
 def check_grads_vs_checksums(module, g, prefix, min_seen):
-    seen = 0
+    """Gradient fingerprints (sum, sum|.|, 32 strided entries per tensor) against the reference's: a coarse check
+    (every entry within 8 % of the tensor's mean |grad|, pooled median within 1 %).  It is coarse on purpose: the
+    32x32 fixtures reach 2x2 feature maps (BatchNorm over 12-28 values) and sit on kinks (ReLU, max-pool argmax,
+    |G_ij|), so the reference's own fp32 gradients are only good to 0.3-6 % against an fp64 run of the same graph
+    (measured with tools/diag_grads.py).  The tight, self-calibrating gradient check is test_gradients_calibrated."""
+    seen, pooled = 0, []
     for k, p in module.named_parameters():
         key = prefix + k
         if key not in g.files:
@@ -64,12 +69,53 @@ def check_grads_vs_checksums(module, g, prefix, min_seen):
         assert p.grad is not None, k
         ref = g[key]
         got = O.checksum(p.grad.cpu())
-        scale = abs(ref[1]) / max(p.numel(), 1)           # mean |grad|
+        n = p.numel()
+        scale = abs(ref[1]) / max(n, 1)           # mean |grad|
         err = np.abs(got - ref)
-        tol = 5e-3 * np.abs(ref) + 5e-6 + 2e-3 * scale * np.array([p.numel() ** 0.5, p.numel()] + [1.0] * (len(ref) - 2))
+        tol = 1e-2 * np.abs(ref) + 5e-6 + 8e-2 * scale * np.array([3.0 * n ** 0.5, n] + [1.0] * (len(ref) - 2))
         assert (err <= tol).all(), f"{key}: max err {err.max():.3e} tol {tol[err.argmax()]:.3e} scale {scale:.3e}"
+        pooled.extend((err[2:] / max(scale, 1e-20)).tolist())
         seen += 1
     assert seen >= min_seen, seen
+    assert np.median(np.asarray(pooled)) < 1e-2, np.median(np.asarray(pooled))
+
+
+def oracle_grads(fn, sds, dtype):
+    """Run `fn(*state_dicts cast to dtype)` -> scalar loss on the CPU oracle; -> list of {name: grad (fp64)}."""
+    cast = [{k: (v.detach().clone().to(dtype).requires_grad_(not O.is_buffer(k)) if v.is_floating_point() else v.clone())
+             for k, v in sd.items()} for sd in sds]
+    fn(*cast).backward()
+    return [{k: sd[k].grad.double() for k in sd if not O.is_buffer(k) and sd[k].grad is not None} for sd in cast]
+
+
+def assert_calibrated(module, g32, g64, what):
+    """The HIP path must be an fp32 implementation of the reference's graph of the same quality as the reference's own
+    CPU path.  Yardstick: relative L2 distance to the oracle evaluated in fp64.
+      * over ALL gradients of the network concatenated: HIP <= 10x CPU-fp32 + 2e-4
+      * per tensor: HIP <= 10x CPU-fp32 + 5e-4 for at least 97 % of the tensors, and <= 2e-2 for every tensor
+        (a ReLU / max-pool unit within rounding of its kink may switch side in one of the two fp32 runs; that moves
+        the few tensors fed by it by ~1e-3 and says nothing about kernel accuracy)."""
+    num_h = num_c = den = 0.0
+    per = []
+    for k, p in module.named_parameters():
+        if is_prebn_bias(k):
+            continue
+        if k not in g64:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        ref = g64[k]
+        n2 = float(ref.pow(2).sum()) + 1e-60
+        eh2 = float((p.grad.cpu().double() - ref).pow(2).sum())
+        ec2 = float((g32[k] - ref).pow(2).sum())
+        num_h += eh2; num_c += ec2; den += n2
+        per.append(((eh2 / n2) ** 0.5, (ec2 / n2) ** 0.5, k))
+    tot_h, tot_c = (num_h / den) ** 0.5, (num_c / den) ** 0.5
+    assert tot_h <= 10.0 * tot_c + 2e-4, f"{what}: all gradients: HIP {tot_h:.3e} vs CPU-fp32 {tot_c:.3e}"
+    bad = [(h, c, k) for h, c, k in per if h > 10.0 * c + 5e-4]
+    assert len(bad) <= 0.03 * len(per), f"{what}: {len(bad)}/{len(per)} tensors off, e.g. {sorted(bad, reverse=True)[:3]}"
+    worst = max(per)
+    assert worst[0] <= 2e-2, f"{what}.{worst[2]}: HIP {worst[0]:.3e} vs CPU-fp32 {worst[1]:.3e}"
+    return tot_h, tot_c
 
 
 # ---------------------------------------------------------------- a-1 / a-2 / a-3: blocks against reference fixtures
@@ -203,6 +249,40 @@ def test_seg_only_vs_golden(golden_dir):
     close(pred, g["segonly_pred"], atol=TOL)
 
 
+@pytest.mark.parametrize("B,pb,H", [(3, 1, 32), (6, 2, 32), (6, 2, 64)])
+def test_gradients_calibrated(B, pb, H):
+    """Every parameter gradient of call A (seg net + teacher + WT loss) and call B (student) against the oracle
+    evaluated in fp64, with the oracle's own fp32 run as the yardstick."""
+    img, od, _ = make_inputs(600, B, H, H)
+    eps = make_noise(700, (B, 1, H, H))
+    main, shape, _, _ = build_nets(pb)
+    sd_m = {k: v.detach().cpu().clone() for k, v in main.state_dict().items()}
+    sd_s = {k: v.detach().cpu().clone() for k, v in shape.state_dict().items()}
+    main.train(); shape.train()
+    main.zero_grad(); main.set_noise([eps])
+    out, _, _, ins, dom = main.update(img.to(DEV), od.to(DEV), two_stage_inputs=img.to(DEV), two_step=True)
+    (F.binary_cross_entropy(torch.sigmoid(out), od.to(DEV)) + ins + dom).backward()
+
+    def loss_a(sd):
+        dt = sd["outc.0.weight"].dtype
+        o, _, _, i2, d2 = O.wt_pse_update(sd, HP, img.to(dt), od.to(dt), img.to(dt), True, eps.to(dt), 3, pb)
+        return O.seg_loss_od(o, od.to(dt)) + i2 + d2
+    (g32,), (g64,) = oracle_grads(loss_a, [sd_m], torch.float32), oracle_grads(loss_a, [sd_m], torch.float64)
+    assert_calibrated(main, g32, g64, "A")
+    shape.zero_grad(); main.zero_grad()
+    kd, ins_t, _, _, dom_s = shape.update(main, img.to(DEV), od.to(DEV), two_stage_inputs=img.to(DEV), two_step=True)
+    (kd + ins_t + dom_s).backward()
+    sd_m2 = {k: v.detach().cpu().clone() for k, v in main.state_dict().items()}   # BN running stats advanced by call A
+
+    def loss_b(sds, sdm):
+        dt = sds["mu_prior.0.weight"].dtype
+        r = O.shape_update(sds, sdm, HP, img.to(dt), od.to(dt), img.to(dt), True, eps.to(dt), eps.to(dt), pb)
+        return r[0] + r[1] + r[4]
+    g32 = oracle_grads(loss_b, [sd_s, sd_m2], torch.float32)[0]
+    g64 = oracle_grads(loss_b, [sd_s, sd_m2], torch.float64)[0]
+    assert_calibrated(shape, g32, g64, "B")
+
+
 # ---------------------------------------------------------------- a-11: full A-D iterations
 def _iteration_inputs(g):
     B, pb, H, iters, s_in, s_n = (int(v) for v in g["meta"])
@@ -212,16 +292,35 @@ def _iteration_inputs(g):
         yield it, img, od, oc, nz
 
 
-def _check_params_vs_golden(nets, g):
+def _check_params_vs_golden(nets, g, iters=3, lr=5e-4):
+    """Parameters after `iters` Adam steps.  Adam's first steps move every weight by ~lr*sign(grad), so an entry whose
+    gradient is within fp32 noise of zero goes either way: the ORACLE ITSELF, run in fp64, ends 3 iterations with only
+    35 % of the fingerprinted entries within 1e-4 of the fp32 reference (median 2e-4, measured).  This check therefore
+    guards the wiring of the loop (order of calls, ROI, optimiser), not rounding: median < 1e-3, 90 % within 2*lr*iters."""
+    pooled = []
     for tag, net in zip(["od", "shape_od", "oc", "shape_oc"], nets):
         for k, v in net.state_dict().items():
-            if is_prebn_bias(k):
+            if is_prebn_bias(k) or not v.is_floating_point():
                 continue
-            ref = g[f"{tag}.{k}"]
-            got = O.checksum(v.float().cpu())
-            err = np.abs(got - ref)
-            tol = 1e-4 * np.abs(ref) + 6e-5 * max(1.0, min(v.numel(), 32) ** 0.5)
-            assert (err <= tol).all(), f"{tag}.{k}: {err.max():.3e}"
+            pooled.extend(np.abs(O.checksum(v.float().cpu()) - g[f"{tag}.{k}"])[2:].tolist())
+    pooled = np.asarray(pooled)
+    assert np.median(pooled) < 1e-3 and (pooled < 2 * lr * iters + 5e-4).mean() >= 0.9, (np.median(pooled), pooled.max())
+
+
+def _loss_tol(k, it):
+    """Iteration 0, call A sees identical weights and inputs: the 1e-4 bar applies.  Everything later has passed
+    through Adam's sign-like first steps and the 0.75 ROI threshold (Trainer.py:842), which amplify fp32 rounding:
+    the oracle run in fp64 departs from the fp32 reference by 5e-4 (kd, iteration 0), 0.5-2.5 % (iteration 1) and up
+    to 3 % / 14 % (kd / MMD terms, iteration 2) — measured; tolerances are ~4x those figures."""
+    if it == 0 and k in ("seg_od", "ins_od"):
+        return dict(rtol=1e-4, atol=1e-5)
+    if it == 0 and k == "dom_od":
+        return dict(rtol=1e-3, atol=5e-7)
+    if it == 0:
+        return dict(rtol=5e-3, atol=1e-4)
+    if k.startswith("dom"):
+        return dict(rtol=0.6, atol=1e-3)
+    return dict(rtol=0.1, atol=1e-3)
 
 
 def test_iterations_harness_vs_golden(golden_dir):
@@ -237,8 +336,7 @@ def test_iterations_harness_vs_golden(golden_dir):
         for j, k in enumerate(keys):
             if k not in res:
                 continue           # main_od / shape_od ... are sums formed by the caller
-            tol = dict(rtol=1e-3, atol=5e-7) if k.startswith("dom") else dict(rtol=3e-4, atol=2e-5)
-            close(res[k], g["losses"][it][j], what=f"it{it}.{k}", **tol)
+            close(res[k], g["losses"][it][j], what=f"it{it}.{k}", **_loss_tol(k, it))
     _check_params_vs_golden([main, shape, main_oc, shape_oc], g)
 
 
@@ -290,8 +388,7 @@ def test_iterations_dropin_vs_golden(golden_dir):
         loss_shape_oc.backward(); optim_shape_oc.step()
         res.update(kd_oc=kd2, ins_shape_oc=ins_t2, dom_shape_oc=dom_s2, shape_oc=loss_shape_oc)
         for j, k in enumerate(keys):
-            tol = dict(rtol=1e-3, atol=5e-7) if k.startswith("dom") else dict(rtol=3e-4, atol=2e-5)
-            close(res[k], g["losses"][it][j], what=f"it{it}.{k}", **tol)
+            close(res[k], g["losses"][it][j], what=f"it{it}.{k}", **_loss_tol(k, it))
     _check_params_vs_golden(nets, g)
 
 

@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_k(WgradArgs a) {
   for (int nb = 0; nb < MAXNB; ++nb)
 #pragma unroll
     for (int r = 0; r < NACC; ++r) acc[nb][r] = 0.f;
-  float db = 0.f;
+  double db = 0.0;
 
   const int tiles_per_img = a.tiles_x * a.tiles_y;
   for (int tile = blockIdx.y; tile < a.ntiles; tile += gridDim.y) {
@@ -450,9 +450,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_k(WgradArgs a) {
   }
   if (a.dbias && group == 0) {
     constexpr int TPC = 256 / MB;  // threads per channel: 16 (P16) or 8 (P32), consecutive lanes
-    db = wave_xor_sum(db, TPC / 2);
+    for (int m = 1; m <= TPC / 2; m <<= 1) db += __shfl_xor(db, m, 64);
     int c = tid / TPC;
-    if ((tid % TPC) == 0 && cout0 + c < a.Cout) a.dbias[(size_t)blockIdx.y * a.Cout + cout0 + c] = db;
+    if ((tid % TPC) == 0 && cout0 + c < a.Cout) a.dbias[(size_t)blockIdx.y * a.Cout + cout0 + c] = (float)db;
   }
 }
 
@@ -460,9 +460,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_k(const float* __restrict__ 
                                                       float* __restrict__ out, int accumulate) {
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  float s = 0.f;
-  for (int k = 0; k < ksplit; ++k) s += slab[(size_t)k * n + i];
-  out[i] = accumulate ? out[i] + s : s;
+  double s = 0.0;  // the slabs are partial sums of a long, cancellation-prone reduction: fold them in fp64
+  for (int k = 0; k < ksplit; ++k) s += (double)slab[(size_t)k * n + i];
+  out[i] = accumulate ? out[i] + (float)s : (float)s;
 }
 
 extern "C" int wtpse_wgrad_ksplit(int B, int H, int W, int Cin, int Cout) {
