@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void conv_fwd_k(ConvArgs a) {
   constexpr int NACC = P16 ? 4 : 16;
   constexpr int XS_SZ = KC * S, WS_SZ = KC * TAPS * CB;
   constexpr int RED_SZ = 4 * CB * 2;
-  __shared__ float smem[(XS_SZ + WS_SZ) > RED_SZ ? (XS_SZ + WS_SZ) : RED_SZ];
+  __shared__ __attribute__((aligned(16))) float smem[(XS_SZ + WS_SZ) > RED_SZ ? (XS_SZ + WS_SZ) : RED_SZ];
   float* Xs = smem;
   float* Ws = smem + XS_SZ;
 
@@ -86,6 +86,19 @@ __global__ __launch_bounds__(256) void conv_fwd_k(ConvArgs a) {
     off[nt] = (p >> TWL) * PITCH + (p & (TW - 1));
   }
 
+  // halo-tile positions owned by this thread (fixed for the whole kernel): LDS offset within a channel plane and
+  // offset within a global channel plane (-1: zero padding / outside the image)
+  constexpr int NPOS = (PE + 255) / 256;
+  int lpos[NPOS], gpos[NPOS];
+#pragma unroll
+  for (int i = 0; i < NPOS; ++i) {
+    int p = tid + 256 * i;
+    int r = p / PITCH, x = p - r * PITCH;
+    int gy = ty * TH + r - PAD, gx = tx * TW + x - PAD;
+    lpos[i] = p < PE ? p : -1;
+    gpos[i] = (p < PE && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? gy * a.W + gx : -1;
+  }
+
   typename AccT<P16>::type acc[MT][NT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
@@ -94,37 +107,59 @@ __global__ __launch_bounds__(256) void conv_fwd_k(ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < NACC; ++r) acc[mt][nt][r] = 0.f;
 
+  constexpr int CB4 = CB / 4;
+  constexpr int NW = (KC * TAPS * CB4 + 255) / 256;
+  const float* px0 = a.in0 + (size_t)b * a.C0 * HW;
+  const float* px1 = a.in1 ? a.in1 + ((ptrdiff_t)b * a.C1 - a.C0) * (ptrdiff_t)HW : a.in0;
   for (int c0 = 0; c0 < a.CinP; c0 += KC) {
     const int kc = min(KC, a.CinP - c0);
     __syncthreads();
-    // ---- input halo tile -> LDS (zero padding applies AFTER the fused affine/ReLU, as in the reference graph)
-    for (int e = tid; e < kc * PE; e += 256) {
-      int c = e / PE;
-      int rem = e - c * PE;
-      int r = rem / PITCH;
-      int x = rem - r * PITCH;
-      int gy = ty * TH + r - PAD, gx = tx * TW + x - PAD;
-      int cg = c0 + c;
-      float v = 0.f;
-      if (cg < a.Cin && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
-        bool relu;
-        if (cg < a.C0) {
-          v = a.in0[(size_t)(b * a.C0 + cg) * HW + gy * a.W + gx];
-          relu = a.pro_relu & 1;
-        } else {
-          v = a.in1[(size_t)(b * a.C1 + (cg - a.C0)) * HW + gy * a.W + gx];
-          relu = a.pro_relu & 2;
-        }
-        if (a.pro) v = fmaf(v, a.pro[2 * cg], a.pro[2 * cg + 1]);
-        if (relu) v = fmaxf(v, 0.f);
-      }
-      Xs[c * S + rem] = v;
+    // ---- issue every global load of this chunk before the first LDS store (memory-level parallelism:
+    //      up to KC*NPOS + NW independent loads in flight per lane), then transform + store
+    float xv[KC][NPOS];
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+      const int cg = c0 + c;
+      const bool has = c < kc && cg < a.Cin;
+      const float* base = cg < a.C0 ? px0 : px1;   // px1 is pre-biased by -C0 planes: one index formula for both inputs
+#pragma unroll
+      for (int i = 0; i < NPOS; ++i) xv[c][i] = (has && gpos[i] >= 0) ? base[cg * HW + gpos[i]] : 0.f;
     }
-    // ---- weight slab -> LDS: rows (cin, tap), CB consecutive output channels each
-    for (int e = tid; e < kc * TAPS * CB; e += 256) {
-      int row = e / CB;
-      int j = e - row * CB;
-      Ws[e] = (cout0 + j < a.CoutP) ? a.wp[(size_t)(c0 * TAPS + row) * a.CoutP + cout0 + j] : 0.f;
+    float4 wv[NW];
+    const int n4 = kc * TAPS * CB4;
+#pragma unroll
+    for (int it = 0; it < NW; ++it) {
+      const int e4 = tid + 256 * it;
+      const int row = e4 / CB4, j4 = e4 - row * CB4;
+      wv[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e4 < n4 && cout0 + j4 * 4 < a.CoutP)
+        wv[it] = *reinterpret_cast<const float4*>(a.wp + (size_t)(c0 * TAPS + row) * a.CoutP + cout0 + j4 * 4);
+    }
+    // zero padding applies AFTER the fused affine/ReLU, as in the reference graph
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+      const int cg = c0 + c;
+      if (c < kc) {
+        float sc = 1.f, sh = 0.f;
+        if (a.pro && cg < a.Cin) { sc = a.pro[2 * cg]; sh = a.pro[2 * cg + 1]; }
+        const bool relu = cg < a.C0 ? (a.pro_relu & 1) : (a.pro_relu & 2);
+#pragma unroll
+        for (int i = 0; i < NPOS; ++i) {
+          if (lpos[i] >= 0) {
+            float v = xv[c][i];
+            if (gpos[i] >= 0) {
+              v = fmaf(v, sc, sh);
+              if (relu) v = fmaxf(v, 0.f);
+            }
+            Xs[c * S + lpos[i]] = v;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NW; ++it) {
+      const int e4 = tid + 256 * it;
+      if (e4 < n4) *reinterpret_cast<float4*>(Ws + e4 * 4) = wv[it];
     }
     __syncthreads();
     // ---- MFMA
@@ -133,19 +168,21 @@ __global__ __launch_bounds__(256) void conv_fwd_k(ConvArgs a) {
       const int cl = q * KQ + (lane / NB);
       const float* xrow = Xs + cl * S;
       const float* wrow = Ws + cl * TAPS * CB + (lane & (MB - 1));
+      float av[TAPS][MT], bv[TAPS][NT];
 #pragma unroll
       for (int t = 0; t < TAPS; ++t) {
         const int toff = (t / KS) * PITCH + (t % KS);
-        float av[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) av[mt] = wrow[t * CB + mt * MB];
+        for (int mt = 0; mt < MT; ++mt) av[t][mt] = wrow[t * CB + mt * MB];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          float bv = xrow[off[nt] + toff];
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mfma(av[mt], bv, acc[mt][nt]);
-        }
+        for (int nt = 0; nt < NT; ++nt) bv[t][nt] = xrow[off[nt] + toff];
       }
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mfma(av[t][mt], bv[t][nt], acc[mt][nt]);
     }
   }
 
@@ -305,7 +342,7 @@ struct WgradArgs {
   int cg, ngroups, nblk;
 };
 
-template <int KS, bool P32, int TWL>
+template <int KS, bool P32, int TWL, int NBLK>
 __global__ __launch_bounds__(256) void conv_wgrad_k(WgradArgs a) {
   constexpr int TAPS = KS * KS, PAD = KS / 2;
   constexpr int TW = 1 << TWL, TH = 256 / TW;
@@ -314,7 +351,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_k(WgradArgs a) {
   constexpr int MB = P32 ? 32 : 16;   // couts per block == cin slots per N block
   constexpr int KQ = P32 ? 2 : 4;     // pixels per MFMA
   constexpr int NACC = P32 ? 16 : 4;
-  constexpr int MAXNB = TAPS;         // N blocks per workgroup (ceil(cg*TAPS/MB) <= TAPS)
+  constexpr int MAXNB = NBLK;         // N blocks per workgroup: ceil(cg*TAPS/MB) rounded up to an instantiated count
   // bank-conflict-free strides: 16-path reads (cout|cin) x 2 pixels per 32-lane group -> stride % 32 == 2;
   // 32-path reads 32 channels of one pixel -> odd stride
   constexpr int SA = P32 ? 257 : 258;
@@ -337,7 +374,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_k(WgradArgs a) {
   for (int nb = 0; nb < MAXNB; ++nb) {
     int slot = nb * MB + j;
     int ci = slot % a.cg, t = slot / a.cg;
-    boff[nb] = (t < TAPS) ? ci * SX + (t / KS) * PITCH + (t % KS) : -1;
+    // slots past the last tap read a valid address and accumulate garbage that is never stored: no branch in the MFMA loop
+    boff[nb] = (t < TAPS) ? ci * SX + (t / KS) * PITCH + (t % KS) : 0;
   }
   typename AccT<!P32>::type acc[MAXNB];
 #pragma unroll
@@ -352,36 +390,63 @@ __global__ __launch_bounds__(256) void conv_wgrad_k(WgradArgs a) {
     const int trem = tile - b * tiles_per_img;
     const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
     __syncthreads();
-    // dY tile: [MB couts][256 pixels], zero outside the image / beyond Cout
-    for (int e = tid; e < MB * 256; e += 256) {
-      int c = e >> 8, p = e & 255;
-      int gy = ty * TH + (p >> TWL), gx = tx * TW + (p & (TW - 1));
-      float v = 0.f;
-      if (cout0 + c < a.Cout && gy < a.H && gx < a.W) v = a.dy[(size_t)(b * a.Cout + cout0 + c) * HW + gy * a.W + gx];
-      Ys[c * SA + p] = v;
-    }
-    // X halo tile: [cg cins][ROWS][PITCH] with the same fused affine/ReLU loader as the forward kernel
-    for (int e = tid; e < a.cg * PE; e += 256) {
-      int c = e / PE;
-      int rem = e - c * PE;
-      int r = rem / PITCH;
-      int x = rem - r * PITCH;
+    // ---- tile loads, batched: every global load of a phase is issued before the first LDS store
+    // dY tile [MB couts][256 pixels] (this thread: pixel `tid` of every channel), zero outside the image / beyond Cout
+    const int gyp = ty * TH + (tid >> TWL), gxp = tx * TW + (tid & (TW - 1));
+    const int ypos = (gyp < a.H && gxp < a.W) ? gyp * a.W + gxp : -1;
+    // X halo tile [cg cins][ROWS][PITCH] with the same fused affine/ReLU as the forward loader
+    constexpr int NPOS = (PE + 255) / 256;
+    int lpos[NPOS], gpos[NPOS];
+#pragma unroll
+    for (int i = 0; i < NPOS; ++i) {
+      int p = tid + 256 * i;
+      int r = p / PITCH, x = p - r * PITCH;
       int gy = ty * TH + r - PAD, gx = tx * TW + x - PAD;
-      int cgl = cin0 + c;
-      float v = 0.f;
-      if (cgl < a.Cin && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
-        bool relu;
-        if (cgl < a.C0) {
-          v = a.x0[(size_t)(b * a.C0 + cgl) * HW + gy * a.W + gx];
-          relu = a.pro_relu & 1;
-        } else {
-          v = a.x1[(size_t)(b * a.C1 + (cgl - a.C0)) * HW + gy * a.W + gx];
-          relu = a.pro_relu & 2;
-        }
-        if (a.pro) v = fmaf(v, a.pro[2 * cgl], a.pro[2 * cgl + 1]);
-        if (relu) v = fmaxf(v, 0.f);
+      lpos[i] = p < PE ? p : -1;
+      gpos[i] = (p < PE && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? gy * a.W + gx : -1;
+    }
+#pragma unroll
+    for (int g = 0; g < MB / 16; ++g) {
+      float yv[16];
+      float xv[16][NPOS];
+      const float* pdy = a.dy + (size_t)b * a.Cout * HW;
+      const float* px0 = a.x0 + (size_t)b * a.C0 * HW;
+      const float* px1 = a.x1 ? a.x1 + ((ptrdiff_t)b * a.C1 - a.C0) * (ptrdiff_t)HW : a.x0;   // pre-biased by -C0 planes
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const int co = cout0 + g * 16 + c;
+        yv[c] = (co < a.Cout && ypos >= 0) ? pdy[co * HW + ypos] : 0.f;
       }
-      Xs[c * SX + rem] = v;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const int cl = g * 16 + c, cgl = cin0 + cl;
+        const bool has = cl < a.cg && cgl < a.Cin;
+        const float* base = cgl < a.C0 ? px0 : px1;
+#pragma unroll
+        for (int i = 0; i < NPOS; ++i) xv[c][i] = (has && gpos[i] >= 0) ? base[cgl * HW + gpos[i]] : 0.f;
+      }
+#pragma unroll
+      for (int c = 0; c < 16; ++c) Ys[(g * 16 + c) * SA + tid] = yv[c];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const int cl = g * 16 + c, cgl = cin0 + cl;
+        if (cl < a.cg) {
+          float sc = 1.f, sh = 0.f;
+          if (a.pro && cgl < a.Cin) { sc = a.pro[2 * cgl]; sh = a.pro[2 * cgl + 1]; }
+          const bool relu = cgl < a.C0 ? (a.pro_relu & 1) : (a.pro_relu & 2);
+#pragma unroll
+          for (int i = 0; i < NPOS; ++i) {
+            if (lpos[i] >= 0) {
+              float v = xv[c][i];
+              if (gpos[i] >= 0) {
+                v = fmaf(v, sc, sh);
+                if (relu) v = fmaxf(v, 0.f);
+              }
+              Xs[cl * SX + lpos[i]] = v;
+            }
+          }
+        }
+      }
     }
     __syncthreads();
     if (a.dbias && group == 0) {  // bias gradient: plain per-channel sum of the dY tile
@@ -392,17 +457,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_k(WgradArgs a) {
       db += s;
     }
     constexpr int STEPS = 64 / KQ;
+#pragma unroll 4
     for (int s = 0; s < STEPS; ++s) {
       const int pbase = wave * 64 + s * KQ;
       const int rowbase = (pbase >> TWL) * PITCH + (pbase & (TW - 1)) + kl;
       const float av = Ys[j * SA + pbase + kl];
+      float bv[MAXNB];
 #pragma unroll
-      for (int nb = 0; nb < MAXNB; ++nb) {
-        if (nb < a.nblk) {
-          float bv = boff[nb] >= 0 ? Xs[boff[nb] + rowbase] : 0.f;
-          acc[nb] = mfma(av, bv, acc[nb]);
-        }
-      }
+      for (int nb = 0; nb < MAXNB; ++nb) bv[nb] = Xs[boff[nb] + rowbase];
+#pragma unroll
+      for (int nb = 0; nb < MAXNB; ++nb) acc[nb] = mfma(av, bv[nb], acc[nb]);
     }
   }
 
@@ -416,7 +480,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_k(WgradArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) red[((wave * MAXNB + nb) * 16 + (lane >> 4) * 4 + r) * 16 + j] = acc[nb][r];
     __syncthreads();
-    for (int e = tid; e < a.nblk * 256; e += 256) {
+    for (int e = tid; e < MAXNB * 256; e += 256) {
       int nb = e >> 8, co = (e >> 4) & 15, jj = e & 15;
       float v = 0.f;
 #pragma unroll
@@ -429,7 +493,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_k(WgradArgs a) {
   } else {
 #pragma unroll
     for (int nb = 0; nb < MAXNB; ++nb) {
-      if (nb < a.nblk) {
+      {
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -456,13 +520,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_k(WgradArgs a) {
   }
 }
 
+// out[i] (+)= sum_k slab[k][i]: 32 outputs x 8 k-slices per workgroup, fp64 accumulation (the slabs are partial sums of
+// a long, cancellation-prone reduction), fixed order -> bitwise reproducible
 __global__ __launch_bounds__(256) void wgrad_reduce_k(const float* __restrict__ slab, int ksplit, int n,
                                                       float* __restrict__ out, int accumulate) {
-  int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  double s = 0.0;  // the slabs are partial sums of a long, cancellation-prone reduction: fold them in fp64
-  for (int k = 0; k < ksplit; ++k) s += (double)slab[(size_t)k * n + i];
-  out[i] = accumulate ? out[i] + (float)s : (float)s;
+  __shared__ double sh[8][32];
+  const int j = threadIdx.x & 31, kq = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + j;
+  double s = 0.0;
+  if (i < n)
+    for (int k = kq; k < ksplit; k += 8) s += (double)slab[(size_t)k * n + i];
+  sh[kq][j] = s;
+  __syncthreads();
+  if (kq == 0 && i < n) {
+    double t = sh[0][j] + sh[1][j] + sh[2][j] + sh[3][j] + sh[4][j] + sh[5][j] + sh[6][j] + sh[7][j];
+    out[i] = accumulate ? out[i] + (float)t : (float)t;
+  }
 }
 
 extern "C" int wtpse_wgrad_ksplit(int B, int H, int W, int Cin, int Cout) {
@@ -472,7 +545,7 @@ extern "C" int wtpse_wgrad_ksplit(int B, int H, int W, int Cin, int Cout) {
   const int MB = p32 ? 32 : 16;
   const int cg = Cin < MB ? Cin : MB;
   const int nx = ceil_div(Cout, MB) * ceil_div(Cin, cg);
-  int ks = 1024 / nx;
+  int ks = 512 / nx;   // ~2 workgroups per CU (LDS-limited residency of the 32-wide path)
   if (ks < 1) ks = 1;
   if (ks > ntiles) ks = ntiles;
   return ks;
@@ -502,21 +575,26 @@ extern "C" int wtpse_conv_wgrad(const float* dy, const float* x0, int C0, const 
   WTPSE_REQUIRE(ksplit <= a.ntiles);
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((unsigned)(ceil_div(Cout, MB) * a.ngroups), (unsigned)ksplit);
-#define WG_LAUNCH(KS, P, T) hipLaunchKernelGGL((conv_wgrad_k<KS, P, T>), grid, dim3(256), 0, st, a)
+  // instantiated N-block counts: 3x3 -> {1, 2, 5, 9}, 1x1 -> {1}
+  const int nb_inst = ksize == 1 ? 1 : (a.nblk <= 1 ? 1 : a.nblk <= 2 ? 2 : a.nblk <= 5 ? 5 : 9);
+#define WG_LAUNCH(KS, P, T, N) hipLaunchKernelGGL((conv_wgrad_k<KS, P, T, N>), grid, dim3(256), 0, st, a)
+#define WG_TW(KS, P, N) do { if (narrow) WG_LAUNCH(KS, P, 4, N); else WG_LAUNCH(KS, P, 5, N); } while (0)
+#define WG_NB(KS, P) do { if (nb_inst == 1) WG_TW(KS, P, 1); else if (nb_inst == 2) WG_TW(KS, P, 2); \
+                          else if (nb_inst == 5) WG_TW(KS, P, 5); else WG_TW(KS, P, 9); } while (0)
   if (ksize == 3) {
-    if (p32) { if (narrow) WG_LAUNCH(3, true, 4); else WG_LAUNCH(3, true, 5); }
-    else     { if (narrow) WG_LAUNCH(3, false, 4); else WG_LAUNCH(3, false, 5); }
+    if (p32) WG_NB(3, true); else WG_NB(3, false);
   } else {
-    if (p32) { if (narrow) WG_LAUNCH(1, true, 4); else WG_LAUNCH(1, true, 5); }
-    else     { if (narrow) WG_LAUNCH(1, false, 4); else WG_LAUNCH(1, false, 5); }
+    if (p32) WG_TW(1, true, 1); else WG_TW(1, false, 1);
   }
+#undef WG_NB
+#undef WG_TW
 #undef WG_LAUNCH
   int rc = wtpse_status();
   if (rc) return rc;
   const int n = Cout * a.Cin * taps;
-  hipLaunchKernelGGL(wgrad_reduce_k, dim3(ceil_div(n, 256)), dim3(256), 0, st, slab, ksplit, n, dw, accumulate);
+  hipLaunchKernelGGL(wgrad_reduce_k, dim3(ceil_div(n, 32)), dim3(256), 0, st, slab, ksplit, n, dw, accumulate);
   if (dbias)
-    hipLaunchKernelGGL(wgrad_reduce_k, dim3(ceil_div(Cout, 256)), dim3(256), 0, st, dbias_slab, ksplit, Cout, dbias,
+    hipLaunchKernelGGL(wgrad_reduce_k, dim3(ceil_div(Cout, 32)), dim3(256), 0, st, dbias_slab, ksplit, Cout, dbias,
                        accumulate);
   return wtpse_status();
 }
