@@ -62,6 +62,14 @@ int wtpse_bn_bwd(const float* dz, const float* y, const float* scale_shift, int 
                  const float* save_mean, const float* save_invstd, float* partial, float* coef, float* dgamma,
                  float* dbeta, int accumulate, float* dy, int B, int C, int HW, void* stream);
 int wtpse_bn_bwd_nsplit(int B, int C, int HW);
+/* Synchronised BatchNorm (data parallel, statistics over the global batch): the backward in two halves around the
+ * caller's all-reduce of sums[C][2].  dgamma/dbeta receive this rank's share; dy uses the global sums and count. */
+int wtpse_bn_bwd_reduce(const float* dz, const float* y, const float* scale_shift, int relu, const float* save_mean,
+                        const float* save_invstd, float* partial, float* sums_local, int B, int C, int HW, void* stream);
+int wtpse_bn_bwd_apply(const float* dz, const float* y, const float* scale_shift, int relu, const float* gamma,
+                       const float* save_mean, const float* save_invstd, const float* sums_local, const float* sums_global,
+                       long long count_global, float* coef, float* dgamma, float* dbeta, int accumulate, float* dy, int B,
+                       int C, int HW, void* stream);
 
 /* ---- WT (whitening) loss: compute_whitening_loss + compute_MMD (algorithms.py:1277-1309,59-121;
  *      shape_networks.py:561-594,240-309) ------------------------------------------------------------------------ */
@@ -71,6 +79,12 @@ int wtpse_wt_loss_fwd(const float* z, int B, int C, int HW, float eps, float mar
                       float* partial, float* gram, float* v, float* offdiag, float* diag, double* rowval,
                       float* dmmd_dv, float* losses, void* stream);
 int wtpse_wt_split(int B, int HW, int* chunk_out);
+/* The two halves of wtpse_wt_loss_fwd (data parallel: all-gather of v and wtpse_mmd_fwd on the global rows in between).
+ * wtpse_wt_final: losses[0..1] = this rank's share of the instance means (divided by Bnorm), losses[2] = sum(rowval). */
+int wtpse_wt_gram_fwd(const float* z, int B, int C, int HW, float eps, float* partial, float* gram, float* v, float* offdiag,
+                      float* diag, void* stream);
+int wtpse_wt_final(const float* offdiag, const float* diag, int B, int Bnorm, float margin, const double* rowval, int R,
+                   float* losses, void* stream);
 /* dz (+)= d(w_off*g_off*ins_off + w_diag*g_diag*ins_diag + w_dom*g_dom*dom)/dz.  g_*: device scalars (NULL = 1).
  * Mws: [B][256] scratch. */
 int wtpse_wt_loss_bwd(const float* z, int B, int C, int HW, float margin, int domain_num, int per_domain,

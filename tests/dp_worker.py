@@ -1,0 +1,89 @@
+"""Worker processes for the data-parallel tests (spawned by test_dp_host.py / test_dp_gpu.py)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "wt-pse-code_amd"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def _init(rank, world, port):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+
+def host_logic(rank, world, port, out_dir):
+    """CPU + gloo: sharding maps, domain-major all-gather, flat-gradient averaging."""
+    import torch
+    import torch.distributed as dist
+    from wtpse_hip.dp import DataParallel, local_rows
+    _init(rank, world, port)
+    dp = DataParallel(world, rank, torch.device("cpu"), bn_sync=True)
+    D, n_g = 3, 4
+    n_l = n_g // world
+    glob = torch.arange(D * n_g * 5, dtype=torch.float32).reshape(D * n_g, 5)          # row r = [5r .. 5r+4]
+    mine = local_rows(n_g, D, world, rank)
+    local = torch.cat([glob[mine], torch.full((1, 5), -1.0)])                            # + one unused tail row
+    gathered = dp.gather_domain_major(local, n_l, D)
+    ok_gather = torch.equal(gathered, glob)
+    g = torch.full((1000,), float(rank + 1))
+    dp.allreduce_grads(None, g)
+    ok_mean = torch.allclose(g, torch.full((1000,), (world + 1) / 2.0))
+    s = dp.allreduce_sum(torch.tensor([1.0, 2.0]) * (rank + 1))
+    ok_sum = torch.allclose(s, torch.tensor([1.0, 2.0]) * world * (world + 1) / 2)
+    torch.save({"gather": ok_gather, "mean": ok_mean, "sum": ok_sum, "rows": mine}, os.path.join(out_dir, "r%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def gpu_exact(rank, world, port, out_dir, B_g, pb_g, H):
+    """GPU (all ranks share cuda:0, gloo transport): calls A and B in exact mode; dumps the averaged flat gradients."""
+    import torch
+    import torch.distributed as dist
+    from wtpse_hip import ops
+    from wtpse_hip.dp import DataParallel, local_rows
+    from oracle.inputs import make_inputs, make_noise
+    from test_parity_gpu import build_nets, HP
+    _init(rank, world, port)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dp = DataParallel(world, rank, dev, bn_sync=True)
+    n_l = pb_g // world
+    rows = local_rows(pb_g, 3, world, rank)
+    img, od, _ = make_inputs(600, B_g, H, H)
+    eps = make_noise(700, (B_g, 1, H, H))
+    main, shape, _, _ = build_nets(n_l)
+    for n in (main, shape):
+        n.train()
+        n.ensure_ready(repack=True)
+        object.__setattr__(n, "_dp", dp)
+    x, m = img[rows].to(dev).contiguous(), od[rows].to(dev).contiguous()
+    main.set_noise([eps[rows]])
+    res, tape = main._forward_update(x, m, x, want_tape=True)
+    out, _, scal = res
+    d_out = ops.bce_sigmoid_bwd(out, m)
+    main._backward_update(tape, d_out, None, None, w_ins=1.0, w_dom=1.0)
+    g_main = main.flat_grads().detach().cpu().clone()
+    scal_main = scal.detach().cpu().clone()
+    s2, tape2 = shape._forward_update(main, x, m, want_tape=True)
+    shape._backward_update(tape2, None, None, None, None)
+    g_shape = shape.flat_grads().detach().cpu().clone()
+    # sampling noise from the global Philox stream (no injection): rows must equal the 1-GPU draw
+    main.seed_noise(99)
+    nz = main.next_noise((len(rows), 1, H, H)).cpu()
+    torch.save({"g_main": g_main, "g_shape": g_shape, "scal_main": scal_main, "scal_shape": s2.detach().cpu(),
+                "out": out.detach().cpu(), "rows": rows, "noise": nz,
+                "bufs": {k: v.detach().cpu().clone() for k, v in main.named_buffers()}}, os.path.join(out_dir, "r%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    fn, rank, world, port, out_dir = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+    if fn == "host":
+        host_logic(rank, world, port, out_dir)
+    else:
+        gpu_exact(rank, world, port, out_dir, *[int(a) for a in sys.argv[6:9]])

@@ -109,11 +109,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_k(const float* __restrict__
   }
 }
 
+// `global_sums` (optional, [C][2]): the same two sums over ALL ranks' elements (synchronised BatchNorm); the dy
+// coefficients then use them together with the global `count`, while dgamma/dbeta keep this rank's share (the
+// parameter-gradient all-reduce adds the shares up).  `sums_out` (optional) receives this rank's folded sums.
 __global__ __launch_bounds__(64) void bn_bwd_finalize_k(const float* __restrict__ partial, int nsplit, int C, double count,
                                                         const float* __restrict__ gamma, const float* __restrict__ mean,
                                                         const float* __restrict__ invstd, float* __restrict__ dgamma,
                                                         float* __restrict__ dbeta, int accumulate,
-                                                        float* __restrict__ coef) {
+                                                        float* __restrict__ coef, const float* __restrict__ global_sums,
+                                                        float* __restrict__ sums_out) {
   const int c = blockIdx.x, t = threadIdx.x;
   double s1 = 0.0, s2 = 0.0;
   for (int k = t; k < nsplit; k += 64) {
@@ -125,8 +129,19 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_k(const float* __restrict_
     s2 += __shfl_xor(s2, m, 64);
   }
   if (t == 0) {
-    dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
-    dgamma[c] = accumulate ? dgamma[c] + (float)s2 : (float)s2;
+    if (sums_out) {
+      sums_out[2 * c] = (float)s1;
+      sums_out[2 * c + 1] = (float)s2;
+    }
+    if (dbeta) {
+      dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
+      dgamma[c] = accumulate ? dgamma[c] + (float)s2 : (float)s2;
+    }
+    if (!coef) return;
+    if (global_sums) {
+      s1 = global_sums[2 * c];
+      s2 = global_sums[2 * c + 1];
+    }
     double k1 = (double)gamma[c] * invstd[c];
     double k2 = -(double)gamma[c] * invstd[c] * invstd[c] * s2 / count;
     double k3 = -k1 * s1 / count - k2 * mean[c];
@@ -222,7 +237,42 @@ extern "C" int wtpse_bn_bwd(const float* dz, const float* y, const float* scale_
   hipLaunchKernelGGL(bn_bwd_reduce_k, dim3(C, ns), dim3(256), 0, st, dz, y, scale_shift, relu, save_mean, save_invstd, B,
                      C, HW, partial);
   hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(C), dim3(64), 0, st, partial, ns, C, (double)B * HW, gamma, save_mean,
-                     save_invstd, dgamma, dbeta, accumulate, coef);
+                     save_invstd, dgamma, dbeta, accumulate, coef, (const float*)nullptr, (float*)nullptr);
+  if (vec_ok(HW, dz, y, dy))
+    hipLaunchKernelGGL(bn_bwd_apply_k<true>, dim3(ceil_div(HW, 1024) * B * C), dim3(256), 0, st, dz, y, scale_shift,
+                       relu, coef, C, HW, ceil_div(HW, 1024), dy);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_k<false>, dim3(ceil_div(HW, 256) * B * C), dim3(256), 0, st, dz, y, scale_shift,
+                       relu, coef, C, HW, ceil_div(HW, 256), dy);
+  return wtpse_status();
+}
+
+// Synchronised BatchNorm backward in two halves around the caller's all-reduce of `sums` ([C][2]):
+//   wtpse_bn_bwd_reduce : this rank's (sum dzh, sum dzh*xhat) -> sums_local
+//   wtpse_bn_bwd_apply  : dgamma/dbeta from sums_local, dy from sums_global and the global element count
+extern "C" int wtpse_bn_bwd_reduce(const float* dz, const float* y, const float* scale_shift, int relu,
+                                   const float* save_mean, const float* save_invstd, float* partial, float* sums_local,
+                                   int B, int C, int HW, void* stream) {
+  WTPSE_REQUIRE(dz && y && scale_shift && save_mean && save_invstd && partial && sums_local && B > 0 && C > 0 && HW > 0);
+  hipStream_t st = (hipStream_t)stream;
+  const int ns = wtpse_bn_bwd_nsplit(B, C, HW);
+  hipLaunchKernelGGL(bn_bwd_reduce_k, dim3(C, ns), dim3(256), 0, st, dz, y, scale_shift, relu, save_mean, save_invstd, B,
+                     C, HW, partial);
+  hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(C), dim3(64), 0, st, partial, ns, C, 1.0, (const float*)nullptr, save_mean,
+                     save_invstd, (float*)nullptr, (float*)nullptr, 0, (float*)nullptr, (const float*)nullptr, sums_local);
+  return wtpse_status();
+}
+
+extern "C" int wtpse_bn_bwd_apply(const float* dz, const float* y, const float* scale_shift, int relu, const float* gamma,
+                                  const float* save_mean, const float* save_invstd, const float* sums_local,
+                                  const float* sums_global, long long count_global, float* coef, float* dgamma,
+                                  float* dbeta, int accumulate, float* dy, int B, int C, int HW, void* stream) {
+  WTPSE_REQUIRE(dz && y && scale_shift && gamma && save_mean && save_invstd && sums_local && sums_global && coef && dgamma &&
+                dbeta && dy && B > 0 && C > 0 && HW > 0 && count_global > 0);
+  hipStream_t st = (hipStream_t)stream;
+  // sums_local viewed as a 1-slab partial: [1][C][2]
+  hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(C), dim3(64), 0, st, sums_local, 1, C, (double)count_global, gamma, save_mean,
+                     save_invstd, dgamma, dbeta, accumulate, coef, sums_global, (float*)nullptr);
   if (vec_ok(HW, dz, y, dy))
     hipLaunchKernelGGL(bn_bwd_apply_k<true>, dim3(ceil_div(HW, 1024) * B * C), dim3(256), 0, st, dz, y, scale_shift,
                        relu, coef, C, HW, ceil_div(HW, 1024), dy);

@@ -137,8 +137,9 @@ __global__ __launch_bounds__(128) void mmd_rows_k(const float* __restrict__ v, i
 }
 
 // losses[0] = ins_off, [1] = ins_diag, [2] = dom
+// Bnorm: the batch size the two instance means divide by (the global batch under data parallelism)
 __global__ __launch_bounds__(256) void wt_final_k(const float* __restrict__ offdiag, const float* __restrict__ diag, int B,
-                                                  float margin, const double* __restrict__ rowval, int R,
+                                                  int Bnorm, float margin, const double* __restrict__ rowval, int R,
                                                   float* __restrict__ losses) {
   __shared__ double sh[3][4];
   const int t = threadIdx.x;
@@ -160,8 +161,8 @@ __global__ __launch_bounds__(256) void wt_final_k(const float* __restrict__ offd
   }
   __syncthreads();
   if (t == 0) {
-    losses[0] = (float)((sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3]) / B);
-    losses[1] = (float)((sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3]) / B);
+    losses[0] = (float)((sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3]) / Bnorm);
+    losses[1] = (float)((sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3]) / Bnorm);
     losses[2] = (float)(sh[2][0] + sh[2][1] + sh[2][2] + sh[2][3]);
   }
 }
@@ -293,7 +294,7 @@ extern "C" int wtpse_wt_loss_fwd(const float* z, int B, int C, int HW, float eps
     hipLaunchKernelGGL(gram_partial_k<false>, dim3(B * S), dim3(256), 0, st, z, HW, S, chunk, partial);
   hipLaunchKernelGGL(gram_finalize_k, dim3(B), dim3(256), 0, st, partial, S, HW, eps, gram, v, offdiag, diag);
   hipLaunchKernelGGL(mmd_rows_k, dim3(R), dim3(128), R * sizeof(double), st, v, domain_num, per_domain, rowval, dmmd_dv);
-  hipLaunchKernelGGL(wt_final_k, dim3(1), dim3(256), 0, st, offdiag, diag, B, margin, rowval, R, losses);
+  hipLaunchKernelGGL(wt_final_k, dim3(1), dim3(256), 0, st, offdiag, diag, B, B, margin, rowval, R, losses);
   return wtpse_status();
 }
 
@@ -315,6 +316,32 @@ extern "C" int wtpse_wt_loss_bwd(const float* z, int B, int C, int HW, float mar
     int bpi = ceil_div(HW, 256);
     hipLaunchKernelGGL(gram_bwd_k<false>, dim3(B * bpi), dim3(256), 0, st, z, Mws, HW, bpi, accumulate, dz);
   }
+  return wtpse_status();
+}
+
+// The two halves of wtpse_wt_loss_fwd, for the data-parallel path (all-gather of v between them):
+//   wtpse_wt_gram_fwd : z -> gram, v, offdiag, diag of this rank's images
+//   wtpse_wt_final    : losses[0..1] = this rank's share of the instance means (divide by Bnorm = global batch),
+//                       losses[2] = sum(rowval[0..R)) (the MMD of the gathered rows, from wtpse_mmd_fwd)
+extern "C" int wtpse_wt_gram_fwd(const float* z, int B, int C, int HW, float eps, float* partial, float* gram, float* v,
+                                 float* offdiag, float* diag, void* stream) {
+  WTPSE_REQUIRE(z && partial && gram && v && offdiag && diag && C == WT_C && B > 0 && HW > 1);
+  hipStream_t st = (hipStream_t)stream;
+  int chunk;
+  const int S = wtpse_wt_split(B, HW, &chunk);
+  const bool vec = (HW % 4 == 0) && (((uintptr_t)z & 15) == 0);
+  if (vec)
+    hipLaunchKernelGGL(gram_partial_k<true>, dim3(B * S), dim3(256), 0, st, z, HW, S, chunk, partial);
+  else
+    hipLaunchKernelGGL(gram_partial_k<false>, dim3(B * S), dim3(256), 0, st, z, HW, S, chunk, partial);
+  hipLaunchKernelGGL(gram_finalize_k, dim3(B), dim3(256), 0, st, partial, S, HW, eps, gram, v, offdiag, diag);
+  return wtpse_status();
+}
+
+extern "C" int wtpse_wt_final(const float* offdiag, const float* diag, int B, int Bnorm, float margin, const double* rowval,
+                              int R, float* losses, void* stream) {
+  WTPSE_REQUIRE(offdiag && diag && rowval && losses && B > 0 && Bnorm >= B && R >= 0);
+  hipLaunchKernelGGL(wt_final_k, dim3(1), dim3(256), 0, (hipStream_t)stream, offdiag, diag, B, Bnorm, margin, rowval, R, losses);
   return wtpse_status();
 }
 

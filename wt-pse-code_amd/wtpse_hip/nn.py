@@ -315,16 +315,16 @@ class HipNet(nn.Module):
             e = self._noise_queue.pop(0)
             assert tuple(e.shape) == tuple(shape), (e.shape, shape)
             return e.to(self._flat.device, torch.float32).contiguous()
+        off = self._noise_counter
+        if self._dp is not None:   # exact mode: one global stream indexed by global row (any sharding reproduces G = 1)
+            eps, used = self._dp.noise(tuple(int(v) for v in shape), self._noise_seed, off)
+            object.__setattr__(self, "_noise_counter", off + used)
+            return eps
         n = 1
         for s in shape:
             n *= int(s)
-        n4 = (n + 3) & ~3
-        off = self._noise_counter
-        row_off = 0
-        if self._dp is not None:   # global row index so that any sharding reproduces the 1-GPU stream
-            n4, row_off = self._dp.noise_span(shape)
-        object.__setattr__(self, "_noise_counter", off + n4)
-        return ops.randn(shape, self._flat.device, self._noise_seed, off + row_off)
+        object.__setattr__(self, "_noise_counter", off + ((n + 3) & ~3))
+        return ops.randn(shape, self._flat.device, self._noise_seed, off)
 
 
 # ================================================================================================ block schedules

@@ -67,7 +67,7 @@ class TrainStep:
             d_out = ops.bce_sigmoid_bwd(out, target)
         else:
             sums, pw = ops.pos_weight_sums(od_pred, target)
-            if self.dp is not None:
+            if self.dp is not None and self.dp.exact:      # pos_weight over the global batch (Trainer.py:865)
                 pw = ops.pos_weight_from_sums(self.dp.allreduce_sum(sums))
             loss = ops.bce_logits_pw_fwd(out, od_pred, target, pw)
             d_out = ops.bce_logits_pw_bwd(out, od_pred, target, pw)
