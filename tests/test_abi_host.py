@@ -1,0 +1,83 @@
+"""CPU-side checks of the boundary: the C-ABI library builds/loads and exports every symbol include/wtpse_hip.h
+declares (no compute call is made without a GPU); the drop-in modules expose the reference's names, signatures and
+state_dict keys; the product path fails loudly instead of falling back to the CPU."""
+import ctypes
+import inspect
+import os
+
+import pytest
+import torch
+
+from test_oracle_golden import main_template, shape_template
+from oracle.wtpse_cpu import DEFAULT_HPARAMS as HP
+
+
+def test_library_exports_every_declared_symbol():
+    from wtpse_hip import build
+    from wtpse_hip.lib import lib, parse_header, LIB_PATH
+    build.build()                                   # no-op when up to date
+    protos = parse_header()
+    assert len(protos) >= 40
+    dll = ctypes.CDLL(LIB_PATH)
+    for name in protos:
+        assert hasattr(dll, name), name
+    assert set(lib().protos) == set(protos)
+    # sizing helpers are host-only and may be called without a GPU
+    L = lib()
+    assert L.query("wtpse_conv_stats_blocks", 32, 256, 256) == 32 * 32 * 8
+    assert L.query("wtpse_wgrad_ksplit", 32, 256, 256, 32, 32) == 512
+    assert L.query("wtpse_wt_split", 32, 65536, 0) >= 1
+    # argument validation happens before any launch
+    assert L.raw("wtpse_conv_fwd")(0, 16, 0, 0, 0, 0, 0, 0, 0, 0, 16, 0, 1, 8, 8, 16, 3, 0, 0) == -1
+
+
+def test_dropin_surface_matches_reference():
+    import algorithms
+    import shape_networks
+    assert algorithms.get_algorithm_class("WT_PSE") is algorithms.WT_PSE
+    with pytest.raises(NotImplementedError):
+        algorithms.get_algorithm_class("nope")
+    sig = inspect.signature(algorithms.WT_PSE.__init__)
+    assert list(sig.parameters)[1:] == ["n_channels", "n_classes", "hparams", "device", "two_step", "per_domain_batch",
+                                        "source_domain_num", "feature_dim", "bilinear"]
+    assert list(inspect.signature(algorithms.WT_PSE.update).parameters)[1:] == [
+        "inputs", "mask", "step", "plot_show", "two_stage_inputs", "sp_mask", "two_step"]
+    assert list(inspect.signature(algorithms.WT_PSE.predict).parameters)[1:] == ["learn_x_network", "inputs_all"]
+    assert list(inspect.signature(shape_networks.ShapeVariationalDist_x.__init__).parameters)[1:] == [
+        "hparams", "device", "n_classes", "number_source_domain", "batch_size"]
+    assert list(inspect.signature(shape_networks.ShapeVariationalDist_x.update).parameters)[1:] == [
+        "main_network", "inputs", "mask", "step", "plot_show", "two_stage_inputs", "two_step"]
+    m = algorithms.WT_PSE(n_channels=3, n_classes=1, hparams=HP, device="cpu", two_step=False, per_domain_batch=2,
+                          source_domain_num=3)
+    s = shape_networks.ShapeVariationalDist_x(HP, "cpu", n_classes=1, number_source_domain=3, batch_size=2)
+    for mod, tmpl in ((m, main_template()), (s, shape_template())):
+        sd = mod.state_dict()
+        assert list(sd.keys()) == list(tmpl.keys()) or set(sd.keys()) == set(tmpl.keys())
+        for k, v in sd.items():
+            assert tuple(v.shape) == tuple(tmpl[k].shape), k
+    m0 = algorithms.WT_PSE(3, 1, dict(HP, whitening=False, shape_prior=False), "cpu", False)
+    assert set(m0.state_dict().keys()) == set(main_template(False).keys())
+    # attributes other objects reach into
+    for attr in ("wt_model", "prior_dist", "attention_layer"):
+        assert hasattr(m, attr)
+    assert hasattr(m.prior_dist, "sample_forward") and hasattr(s, "sample_forward") and hasattr(s, "wt_model")
+
+
+def test_no_cpu_fallback():
+    import algorithms
+    m = algorithms.WT_PSE(3, 1, HP, "cpu", False, per_domain_batch=1)
+    x = torch.zeros(3, 3, 32, 32)
+    with pytest.raises(RuntimeError):
+        m.update(x, torch.zeros(3, 1, 32, 32), two_stage_inputs=x, two_step=True)
+    with pytest.raises(NotImplementedError):
+        algorithms.WT_PSE(3, 1, dict(HP, whitening=False), "cpu", False)      # mixed setting: broken in the reference too
+
+
+def test_product_never_imports_oracle():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "wt-pse-code_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, os.path.join(dirpath, f)
