@@ -109,21 +109,29 @@ __global__ __launch_bounds__(256) void conv_fwd_k(ConvArgs a) {
 
   constexpr int CB4 = CB / 4;
   constexpr int NW = (KC * TAPS * CB4 + 255) / 256;
-  const float* px0 = a.in0 + (size_t)b * a.C0 * HW;
-  const float* px1 = a.in1 ? a.in1 + ((ptrdiff_t)b * a.C1 - a.C0) * (ptrdiff_t)HW : a.in0;
+  const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(a.in0 + (size_t)b * a.C0 * HW, (unsigned)a.C0 * HW * 4u);
+  const __amdgpu_buffer_rsrc_t rs1 = a.in1 ? make_rsrc(a.in1 + (size_t)b * a.C1 * HW, (unsigned)a.C1 * HW * 4u) : rs0;
+  unsigned voff[NPOS];
+#pragma unroll
+  for (int i = 0; i < NPOS; ++i) voff[i] = gpos[i] >= 0 ? (unsigned)gpos[i] * 4u : BUF_OOB;
+  const bool any_pro = a.pro != nullptr || a.pro_relu != 0;
   for (int c0 = 0; c0 < a.CinP; c0 += KC) {
     const int kc = min(KC, a.CinP - c0);
     __syncthreads();
     // ---- issue every global load of this chunk before the first LDS store (memory-level parallelism:
     //      up to KC*NPOS + NW independent loads in flight per lane), then transform + store
+    // a chunk never straddles the two inputs (C0 % KC == 0 is checked on the host); channels past Cin re-read a
+    // valid plane (their packed weight rows are zero), so the unrolled load block has no per-channel conditionals
+    const bool first = c0 < a.C0;
+    const __amdgpu_buffer_rsrc_t rs = first ? rs0 : rs1;
+    const int cbase = first ? c0 : c0 - a.C0;
+    const int cmax = (first ? a.C0 : a.C1) - 1;
     float xv[KC][NPOS];
 #pragma unroll
     for (int c = 0; c < KC; ++c) {
-      const int cg = c0 + c;
-      const bool has = c < kc && cg < a.Cin;
-      const float* base = cg < a.C0 ? px0 : px1;   // px1 is pre-biased by -C0 planes: one index formula for both inputs
+      const unsigned soff = (unsigned)min(cbase + c, cmax) * (unsigned)HW * 4u;
 #pragma unroll
-      for (int i = 0; i < NPOS; ++i) xv[c][i] = (has && gpos[i] >= 0) ? base[cg * HW + gpos[i]] : 0.f;
+      for (int i = 0; i < NPOS; ++i) xv[c][i] = buf_load(rs, voff[i], soff);
     }
     float4 wv[NW];
     const int n4 = kc * TAPS * CB4;
@@ -136,26 +144,25 @@ __global__ __launch_bounds__(256) void conv_fwd_k(ConvArgs a) {
         wv[it] = *reinterpret_cast<const float4*>(a.wp + (size_t)(c0 * TAPS + row) * a.CoutP + cout0 + j4 * 4);
     }
     // zero padding applies AFTER the fused affine/ReLU, as in the reference graph
+    if (any_pro) {
+      const bool relu = first ? (a.pro_relu & 1) : (a.pro_relu & 2);
 #pragma unroll
-    for (int c = 0; c < KC; ++c) {
-      const int cg = c0 + c;
-      if (c < kc) {
-        float sc = 1.f, sh = 0.f;
-        if (a.pro && cg < a.Cin) { sc = a.pro[2 * cg]; sh = a.pro[2 * cg + 1]; }
-        const bool relu = cg < a.C0 ? (a.pro_relu & 1) : (a.pro_relu & 2);
+      for (int c = 0; c < KC; ++c) {
+        const int cg = min(c0 + c, a.Cin - 1);
+        const float sc = a.pro ? a.pro[2 * cg] : 1.f, sh = a.pro ? a.pro[2 * cg + 1] : 0.f;
 #pragma unroll
         for (int i = 0; i < NPOS; ++i) {
-          if (lpos[i] >= 0) {
-            float v = xv[c][i];
-            if (gpos[i] >= 0) {
-              v = fmaf(v, sc, sh);
-              if (relu) v = fmaxf(v, 0.f);
-            }
-            Xs[c * S + lpos[i]] = v;
-          }
+          float v = fmaf(xv[c][i], sc, sh);
+          if (relu) v = fmaxf(v, 0.f);
+          xv[c][i] = gpos[i] >= 0 ? v : 0.f;
         }
       }
     }
+#pragma unroll
+    for (int c = 0; c < KC; ++c)
+#pragma unroll
+      for (int i = 0; i < NPOS; ++i)
+        if (lpos[i] >= 0) Xs[c * S + lpos[i]] = xv[c][i];
 #pragma unroll
     for (int it = 0; it < NW; ++it) {
       const int e4 = tid + 256 * it;
@@ -268,6 +275,7 @@ extern "C" int wtpse_conv_fwd(const float* in0, int C0, const float* in1, int C1
   WTPSE_REQUIRE((C1 == 0) == (in1 == nullptr));
   WTPSE_REQUIRE(Csplit > 0 && Csplit <= Cout && ((Csplit == Cout) == (out1 == nullptr)));
   WTPSE_REQUIRE(!(stats && relu_out));
+  WTPSE_REQUIRE(C1 == 0 || C0 % 16 == 0);   // a channel chunk must not straddle the two inputs
   ConvArgs a;
   a.in0 = in0; a.in1 = in1; a.wp = wpacked; a.bias = bias; a.pro = pro; a.out0 = out0; a.out1 = out1; a.stats = stats;
   a.B = B; a.H = H; a.W = W; a.C0 = C0; a.C1 = C1; a.Cin = C0 + C1; a.CinP = (a.Cin + 3) & ~3;
@@ -342,8 +350,10 @@ struct WgradArgs {
   int cg, ngroups, nblk;
 };
 
+// __launch_bounds__(256, 2): two workgroups per CU (2 waves per SIMD) so that one loads while the other runs MFMAs;
+// the 9 x 16 accumulators of the 32-wide path leave ~110 VGPRs for staging
 template <int KS, bool P32, int TWL, int NBLK>
-__global__ __launch_bounds__(256) void conv_wgrad_k(WgradArgs a) {
+__global__ __launch_bounds__(256, 2) void conv_wgrad_k(WgradArgs a) {
   constexpr int TAPS = KS * KS, PAD = KS / 2;
   constexpr int TW = 1 << TWL, TH = 256 / TW;
   constexpr int PITCH = TW + 2 * PAD, ROWS = TH + 2 * PAD;
@@ -368,6 +378,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_k(WgradArgs a) {
   const int cin0 = group * a.cg;
   const int HW = a.H * a.W;
   const int j = lane & (MB - 1), kl = lane / MB;
+  const bool any_pro = a.pro != nullptr || a.pro_relu != 0;
 
   int boff[MAXNB];
 #pragma unroll
@@ -409,44 +420,50 @@ __global__ __launch_bounds__(256) void conv_wgrad_k(WgradArgs a) {
     for (int g = 0; g < MB / 16; ++g) {
       float yv[16];
       float xv[16][NPOS];
-      const float* pdy = a.dy + (size_t)b * a.Cout * HW;
-      const float* px0 = a.x0 + (size_t)b * a.C0 * HW;
-      const float* px1 = a.x1 ? a.x1 + ((ptrdiff_t)b * a.C1 - a.C0) * (ptrdiff_t)HW : a.x0;   // pre-biased by -C0 planes
+      const __amdgpu_buffer_rsrc_t rsy = make_rsrc(a.dy + (size_t)b * a.Cout * HW, (unsigned)a.Cout * HW * 4u);
+      // a cin group never straddles the two inputs (C0 % cg == 0 is checked on the host); channels past the tensor
+      // re-read a valid plane: what they accumulate is never stored
+      // each 16-channel half of a cin group lies in ONE of the two inputs (C0 % 16 == 0 is checked on the host)
+      const int ch0 = cin0 + g * 16;
+      const bool xfirst = ch0 < a.C0 || a.x1 == nullptr;
+      const int xbase = xfirst ? ch0 : ch0 - a.C0;
+      const int xmax = (xfirst ? a.C0 : a.C1) - 1;
+      const __amdgpu_buffer_rsrc_t rsx = xfirst ? make_rsrc(a.x0 + (size_t)b * a.C0 * HW, (unsigned)a.C0 * HW * 4u)
+                                                : make_rsrc(a.x1 + (size_t)b * a.C1 * HW, (unsigned)a.C1 * HW * 4u);
+      const unsigned yoff = ypos >= 0 ? (unsigned)ypos * 4u : BUF_OOB;
+      unsigned voff[NPOS];
+#pragma unroll
+      for (int i = 0; i < NPOS; ++i) voff[i] = gpos[i] >= 0 ? (unsigned)gpos[i] * 4u : BUF_OOB;
+#pragma unroll
+      for (int c = 0; c < 16; ++c)
+        yv[c] = buf_load(rsy, yoff, (unsigned)min(cout0 + g * 16 + c, a.Cout - 1) * (unsigned)HW * 4u);
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
-        const int co = cout0 + g * 16 + c;
-        yv[c] = (co < a.Cout && ypos >= 0) ? pdy[co * HW + ypos] : 0.f;
+        const unsigned soff = (unsigned)min(xbase + c, xmax) * (unsigned)HW * 4u;
+#pragma unroll
+        for (int i = 0; i < NPOS; ++i) xv[c][i] = buf_load(rsx, voff[i], soff);
       }
+      if (any_pro) {
+        const bool relu = xfirst ? (a.pro_relu & 1) : (a.pro_relu & 2);
 #pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        const int cl = g * 16 + c, cgl = cin0 + cl;
-        const bool has = cl < a.cg && cgl < a.Cin;
-        const float* base = cgl < a.C0 ? px0 : px1;
+        for (int c = 0; c < 16; ++c) {
+          const int cgl = min(cin0 + g * 16 + c, a.Cin - 1);
+          const float sc = a.pro ? a.pro[2 * cgl] : 1.f, sh = a.pro ? a.pro[2 * cgl + 1] : 0.f;
 #pragma unroll
-        for (int i = 0; i < NPOS; ++i) xv[c][i] = (has && gpos[i] >= 0) ? base[cgl * HW + gpos[i]] : 0.f;
+          for (int i = 0; i < NPOS; ++i) {
+            float v = fmaf(xv[c][i], sc, sh);
+            if (relu) v = fmaxf(v, 0.f);
+            xv[c][i] = gpos[i] >= 0 ? v : 0.f;
+          }
+        }
       }
 #pragma unroll
       for (int c = 0; c < 16; ++c) Ys[(g * 16 + c) * SA + tid] = yv[c];
 #pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        const int cl = g * 16 + c, cgl = cin0 + cl;
-        if (cl < a.cg) {
-          float sc = 1.f, sh = 0.f;
-          if (a.pro && cgl < a.Cin) { sc = a.pro[2 * cgl]; sh = a.pro[2 * cgl + 1]; }
-          const bool relu = cgl < a.C0 ? (a.pro_relu & 1) : (a.pro_relu & 2);
+      for (int c = 0; c < 16; ++c)
 #pragma unroll
-          for (int i = 0; i < NPOS; ++i) {
-            if (lpos[i] >= 0) {
-              float v = xv[c][i];
-              if (gpos[i] >= 0) {
-                v = fmaf(v, sc, sh);
-                if (relu) v = fmaxf(v, 0.f);
-              }
-              Xs[cl * SX + lpos[i]] = v;
-            }
-          }
-        }
-      }
+        for (int i = 0; i < NPOS; ++i)
+          if (lpos[i] >= 0) Xs[(g * 16 + c) * SX + lpos[i]] = xv[c][i];
     }
     __syncthreads();
     if (a.dbias && group == 0) {  // bias gradient: plain per-channel sum of the dY tile
@@ -565,7 +582,8 @@ extern "C" int wtpse_conv_wgrad(const float* dy, const float* x0, int C0, const 
   const int MB = p32 ? 32 : 16;
   const int taps = ksize * ksize;
   a.cg = a.Cin < MB ? a.Cin : MB;
-  a.ngroups = ceil_div(a.Cin, a.cg);   // a ragged last group is zero-filled by the loader
+  a.ngroups = ceil_div(a.Cin, a.cg);   // a ragged last group re-reads valid planes; its slots are never stored
+  WTPSE_REQUIRE(C1 == 0 || C0 % 16 == 0);   // a 16-channel half group must not straddle the two inputs
   a.nblk = ceil_div(a.cg * taps, MB);
   const bool narrow = W <= 16;
   const int TW = narrow ? 16 : 32, TH = 256 / TW;
