@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--bn-sync", type=int, default=0, help="1: BatchNorm statistics over the global batch (parity mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-roofline", action="store_true")
+    ap.add_argument("--kernels-only", action="store_true",
+                    help="run only the per-kernel roofline launches (used under rocprofv3 --pmc to measure HBM traffic)")
     return ap.parse_args()
 
 
@@ -162,6 +164,17 @@ def log(msg):
 T0 = time.time()
 
 
+def measured_traffic():
+    """HBM bytes per launch measured with rocprofv3 --pmc (FETCH_SIZE / WRITE_SIZE in separate passes, gfx950
+    correction applied: FETCH_SIZE x2 for wide coalesced streams) on `bench.py --kernels-only`; committed under
+    profiles/ by tools/pmc_traffic.py.  Returns {} when no measurement has been committed."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.isfile(path):
+        with open(path) as f:
+            return json.load(f)
+    return {}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -179,6 +192,10 @@ def main():
         from wtpse_hip.dp import DataParallel
         dp = DataParallel(world, rank, dev, bn_sync=bool(args.bn_sync))
 
+    if args.kernels_only:
+        kr = kernel_rooflines(args.batch, args.size, dev)
+        print(json.dumps(kr))
+        return
     from wtpse_hip.step import TrainStep
     from wtpse_hip.synth import make_batch, default_hparams
     full = args.workload == "full"
@@ -232,14 +249,15 @@ def main():
         if world == 1 and not args.no_kernel_roofline:
             log("kernel rooflines")
             kr = kernel_rooflines(B, H, dev)
+            tr = measured_traffic() if (B, H) == (32, 256) else {}
             c = kr["conv"]
             line["roofline"] = {"bound": "mfma", "kernel": c["kernel"], "achieved": c["tflops"], "peak": MFMA_F32_PEAK_TF,
-                                "unit": "TFLOP/s", "frac": c["tflops"] / MFMA_F32_PEAK_TF, "traffic": None,
+                                "unit": "TFLOP/s", "frac": c["tflops"] / MFMA_F32_PEAK_TF, "traffic": tr.get("conv"),
                                 "ms_per_launch": c["ms"], "flop_per_launch": c["flop_per_launch"]}
             for k in ("wt_fwd", "wt_bwd"):
                 w = kr[k]
                 line["roofline_" + k] = {"bound": "hbm", "kernel": w["kernel"], "achieved": w["gbs"], "peak": HBM_PEAK_GBS,
-                                         "unit": "GB/s", "frac": w["gbs"] / HBM_PEAK_GBS, "traffic": None,
+                                         "unit": "GB/s", "frac": w["gbs"] / HBM_PEAK_GBS, "traffic": tr.get(k),
                                          "ms_per_launch": w["ms"], "bytes_per_launch": w["bytes_per_launch"]}
         if world == 1 and not args.no_cpu_baseline:
             log("cpu baseline")
