@@ -33,10 +33,12 @@ int wtpse_pack_conv_weights(const float* params, const int* desc, int n_desc, fl
  * Output channels [0, Csplit) go to out0, the rest to out1 (Csplit == Cout, out1 NULL: no split).
  * stats: NULL or [wtpse_conv_stats_blocks(B,H,W)][Cout][2] per-workgroup (sum, sum^2) of the output (train-mode
  * BatchNorm statistics, algorithms.py:883-889); not combinable with relu_out.
+ * mask_ref: NULL or [B][Cout][H][W]: out = mask_ref > 0 ? value : 0 (the ReLU backward of the layer below, fused into
+ * its data gradient; not combinable with a split).
  * The data gradient is this same call on dY with the `wd` layout. */
 int wtpse_conv_fwd(const float* in0, int C0, const float* in1, int C1, const float* wpacked, const float* bias,
                    const float* pro, int pro_relu, float* out0, float* out1, int Csplit, float* stats, int B, int H,
-                   int W, int Cout, int ksize, int relu_out, void* stream);
+                   int W, int Cout, int ksize, int relu_out, const float* mask_ref, void* stream);
 int wtpse_conv_stats_blocks(int B, int H, int W);
 
 /* dW[Cout][C0+C1][k][k] (+)= sum dY * X, dbias (+)= sum dY (dbias/dbias_slab NULL: skip).  slab: [ksplit][Cout*Cin*k*k],

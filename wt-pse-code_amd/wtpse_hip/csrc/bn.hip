@@ -8,24 +8,33 @@
 //             k1 = gamma*invstd,  k2 = -gamma*invstd^2*dgamma/N,  k3 = -k1*dbeta/N - k2*mean
 #include "common.h"
 
-// one 64-lane workgroup per channel; partial sums are folded in fp64 in a fixed order
-__global__ __launch_bounds__(64) void bn_finalize_k(const float* __restrict__ part, int nblk, int C, double count,
+// one workgroup per channel; partial sums are folded in fp64 in a fixed order
+__global__ __launch_bounds__(256) void bn_finalize_k(const float* __restrict__ part, int nblk, int C, double count,
                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
                                                     float* __restrict__ rmean, float* __restrict__ rvar,
                                                     long long* __restrict__ nbt, float momentum, float eps,
                                                     float* __restrict__ scale_shift, float* __restrict__ save_mean,
                                                     float* __restrict__ save_invstd) {
+  __shared__ double shs[2][4];
   const int c = blockIdx.x, t = threadIdx.x;
   double s1 = 0.0, s2 = 0.0;
-  for (int k = t; k < nblk; k += 64) {
-    s1 += part[((size_t)k * C + c) * 2];
-    s2 += part[((size_t)k * C + c) * 2 + 1];
+  for (int k = t; k < nblk; k += 256) {
+    float2 p2 = *reinterpret_cast<const float2*>(part + ((size_t)k * C + c) * 2);
+    s1 += p2.x;
+    s2 += p2.y;
   }
   for (int m = 1; m < 64; m <<= 1) {
     s1 += __shfl_xor(s1, m, 64);
     s2 += __shfl_xor(s2, m, 64);
   }
+  if ((t & 63) == 0) {
+    shs[0][t >> 6] = s1;
+    shs[1][t >> 6] = s2;
+  }
+  __syncthreads();
   if (t == 0) {
+    s1 = shs[0][0] + shs[0][1] + shs[0][2] + shs[0][3];
+    s2 = shs[1][0] + shs[1][1] + shs[1][2] + shs[1][3];
     double mean = s1 / count;
     double var = s2 / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -191,7 +200,7 @@ extern "C" int wtpse_bn_finalize(const float* stats_partial, int nblk, int C, lo
                                  void* stream) {
   WTPSE_REQUIRE(stats_partial && gamma && beta && scale_shift && save_mean && save_invstd && nblk > 0 && C > 0 && count > 0);
   WTPSE_REQUIRE((running_mean == nullptr) == (running_var == nullptr));
-  hipLaunchKernelGGL(bn_finalize_k, dim3(C), dim3(64), 0, (hipStream_t)stream, stats_partial, nblk, C, (double)count,
+  hipLaunchKernelGGL(bn_finalize_k, dim3(C), dim3(256), 0, (hipStream_t)stream, stats_partial, nblk, C, (double)count,
                      gamma, beta, running_mean, running_var, num_batches, momentum, eps, scale_shift, save_mean,
                      save_invstd);
   return wtpse_status();

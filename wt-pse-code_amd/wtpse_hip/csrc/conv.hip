@@ -30,6 +30,7 @@ struct ConvArgs {
   float* out0;
   float* out1;
   float* stats;        // [gridDim.x][Cout][2] or null
+  const float* mask;   // [B][Cout][H][W] or null: out = mask > 0 ? value : 0 (ReLU backward fused into a data gradient)
   int B, H, W;
   int C0, C1, Cin, CinP;
   int Cout, CoutP, Csplit;
@@ -214,6 +215,7 @@ __global__ __launch_bounds__(256) void conv_fwd_k(ConvArgs a) {
         float v = acc[mt][nt][r] + bias;
         if (a.relu_out) v = fmaxf(v, 0.f);
         if (cvalid && gy < a.H && gx < a.W) {
+          if (a.mask && !(a.mask[(size_t)(b * a.Cout + cout) * HW + gy * a.W + gx] > 0.f)) v = 0.f;
           if (cout < a.Csplit)
             a.out0[(size_t)(b * a.Csplit + cout) * HW + gy * a.W + gx] = v;
           else
@@ -269,15 +271,16 @@ extern "C" int wtpse_conv_stats_blocks(int B, int H, int W) {
 extern "C" int wtpse_conv_fwd(const float* in0, int C0, const float* in1, int C1, const float* wpacked,
                               const float* bias, const float* pro, int pro_relu, float* out0, float* out1,
                               int Csplit, float* stats, int B, int H, int W, int Cout, int ksize, int relu_out,
-                              void* stream) {
+                              const float* mask_ref, void* stream) {
   WTPSE_REQUIRE(in0 && wpacked && out0 && B > 0 && H > 0 && W > 0 && C0 > 0 && C1 >= 0 && Cout > 0);
   WTPSE_REQUIRE(ksize == 1 || ksize == 3);
   WTPSE_REQUIRE((C1 == 0) == (in1 == nullptr));
   WTPSE_REQUIRE(Csplit > 0 && Csplit <= Cout && ((Csplit == Cout) == (out1 == nullptr)));
   WTPSE_REQUIRE(!(stats && relu_out));
+  WTPSE_REQUIRE(!(mask_ref && out1));
   WTPSE_REQUIRE(C1 == 0 || C0 % 16 == 0);   // a channel chunk must not straddle the two inputs
   ConvArgs a;
-  a.in0 = in0; a.in1 = in1; a.wp = wpacked; a.bias = bias; a.pro = pro; a.out0 = out0; a.out1 = out1; a.stats = stats;
+  a.in0 = in0; a.in1 = in1; a.wp = wpacked; a.bias = bias; a.pro = pro; a.out0 = out0; a.out1 = out1; a.stats = stats; a.mask = mask_ref;
   a.B = B; a.H = H; a.W = W; a.C0 = C0; a.C1 = C1; a.Cin = C0 + C1; a.CinP = (a.Cin + 3) & ~3;
   a.Cout = Cout; a.CoutP = (Cout + 15) & ~15; a.Csplit = Csplit; a.pro_relu = pro_relu; a.relu_out = relu_out;
   a.tiles_x = a.tiles_y = 0;

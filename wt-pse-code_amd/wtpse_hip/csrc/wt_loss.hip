@@ -28,12 +28,13 @@ __global__ __launch_bounds__(256) void gram_partial_k(const float* __restrict__ 
   const int p_end = min(HW, p_begin + chunk);
   const float* row = z + ((size_t)b * WT_C + c) * HW;
   f32x4 acc0 = {0, 0, 0, 0}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
-  // a wave-iteration covers 4 groups of 16 pixels: lane (c, q) loads pixels [g*16 + q*4, +4) of channel c
-  for (int p0 = p_begin + wave * 64; p0 < p_end; p0 += 256) {
-    float v[4][4];
+  // a wave-iteration covers 8 groups of 16 pixels (two 64-pixel spans 256 apart): lane (c, q) loads pixels
+  // [g*16 + q*4, +4) of channel c; all 8 float4 loads are issued before the first MFMA
+  for (int p0 = p_begin + wave * 64; p0 < p_end; p0 += 512) {
+    float v[8][4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      int p = p0 + g * 16 + q * 4;
+    for (int g = 0; g < 8; ++g) {
+      int p = p0 + (g >> 2) * 256 + (g & 3) * 16 + q * 4;
       if (VEC) {
         float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
         if (p < p_end) t = *reinterpret_cast<const float4*>(row + p);
@@ -44,7 +45,7 @@ __global__ __launch_bounds__(256) void gram_partial_k(const float* __restrict__ 
       }
     }
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
+    for (int g = 0; g < 8; ++g) {
       acc0 = mfma16(v[g][0], v[g][0], acc0);
       acc1 = mfma16(v[g][1], v[g][1], acc1);
       acc2 = mfma16(v[g][2], v[g][2], acc2);
@@ -267,11 +268,12 @@ __global__ __launch_bounds__(256) void gram_bwd_k(const float* __restrict__ z, c
 
 // ------------------------------------------------------------------------------------------------ C ABI
 extern "C" int wtpse_wt_split(int B, int HW, int* chunk_out) {
-  // aim for ~2048 workgroups, chunks a multiple of 256 pixels (one full wave-iteration per wave)
-  int target = 2048 / (B > 0 ? B : 1);
+  // aim for ~768 workgroups (3 per CU) of at least 2048 pixels, chunks a multiple of 512 pixels (one full
+  // wave-iteration per wave): few, fat partials keep the per-image fold short
+  int target = 768 / (B > 0 ? B : 1);
   if (target < 1) target = 1;
-  int chunk = ceil_div(ceil_div(HW, target), 256) * 256;
-  if (chunk < 256) chunk = 256;
+  int chunk = ceil_div(ceil_div(HW, target), 512) * 512;
+  if (chunk < 2048) chunk = 2048;
   int S = ceil_div(HW, chunk);
   if (chunk_out) *chunk_out = chunk;
   return S;

@@ -340,9 +340,11 @@ def _conv(layer, x0, x1=None, pro_relu=0, relu_out=False, want_stats=False):
     return y, stats
 
 
-def _dgrad(layer, dy, split=None):
+def _dgrad(layer, dy, split=None, mask_ref=None):
+    """Data gradient; mask_ref fuses the ReLU backward of the tensor the gradient flows into (d * [ref > 0])."""
     root = layer._root
-    return ops.conv_fwd(dy, None, root.packed_ptr(layer.wd_off), None, layer.cin, layer.k, None, 0, False, False, split)[:2]
+    return ops.conv_fwd(dy, None, root.packed_ptr(layer.wd_off), None, layer.cin, layer.k, None, 0, False, False, split,
+                        mask_ref)[:2]
 
 
 def _wgrad(layer, dy, x0, x1=None, pro_relu=0, with_bias=True):
@@ -484,10 +486,9 @@ def head_bwd(seq, t, d, idxs):
     for n in reversed(range(len(idxs))):
         layer = seq[idxs[n]]
         inp = t.x if n == 0 else t.acts[n - 1]
-        if n != len(idxs) - 1:
-            d = ops.relu_mask(d, t.acts[n])
         _wgrad(layer, d, inp)
-        d, _ = _dgrad(layer, d)
+        # the ReLU backward of the activation below rides in this data gradient's epilogue
+        d, _ = _dgrad(layer, d, mask_ref=(t.acts[n - 1] if n > 0 else None))
     return d
 
 
@@ -507,16 +508,13 @@ def deepwt_bwd(wt, t, dz2, dz1_extra=None):
     """dz2: total gradient wrt z2 (raw).  dz1_extra(dz1): callback adding the WT-loss gradient of z1 in place."""
     a, b = wt.DoubleConv.double_conv, wt.DoubleConv2.double_conv
     _wgrad(b[2], dz2, t.h2)
-    d, _ = _dgrad(b[2], dz2)
-    d = ops.relu_mask(d, t.h2)
+    d, _ = _dgrad(b[2], dz2, mask_ref=t.h2)
     _wgrad(b[0], d, t.z1, None, 1)
-    d, _ = _dgrad(b[0], d)
-    dz1 = ops.relu_mask(d, t.z1)
+    dz1, _ = _dgrad(b[0], d, mask_ref=t.z1)
     if dz1_extra is not None:
         dz1_extra(dz1)
     _wgrad(a[2], dz1, t.h1)
-    d, _ = _dgrad(a[2], dz1)
-    d = ops.relu_mask(d, t.h1)
+    d, _ = _dgrad(a[2], dz1, mask_ref=t.h1)
     _wgrad(a[0], d, t.x)
 
 

@@ -35,7 +35,7 @@ def workspace(tag, nfloats, device):
 
 # ----------------------------------------------------------------------------------------------- convolution
 def conv_fwd(in0, in1, wpacked_ptr, bias, cout, ksize, pro=None, pro_relu=0, relu_out=False, want_stats=False,
-             split=None):
+             split=None, mask_ref=None):
     """-> (out0, out1 or None, stats or None).  `wpacked_ptr` is a raw device pointer into the packed-weight buffer."""
     _chk(in0, "in0"); _chk(in1, "in1"); _chk(pro, "pro")
     B, C0, H, W = in0.shape
@@ -54,7 +54,7 @@ def conv_fwd(in0, in1, wpacked_ptr, bias, cout, ksize, pro=None, pro_relu=0, rel
         nblk = L.query("wtpse_conv_stats_blocks", B, H, W)
         stats = torch.empty((nblk, cout, 2), dtype=torch.float32, device=in0.device)
     L.call("wtpse_conv_fwd", ptr(in0), C0, ptr(in1), C1, wpacked_ptr, ptr(bias), ptr(pro), int(pro_relu), ptr(out0),
-           ptr(out1), csplit, ptr(stats), B, H, W, cout, ksize, int(relu_out), stream_ptr())
+           ptr(out1), csplit, ptr(stats), B, H, W, cout, ksize, int(relu_out), ptr(mask_ref), stream_ptr())
     return out0, out1, stats
 
 
