@@ -86,7 +86,7 @@ def kernel_rooflines(B, H, dev):
     bias = torch.zeros(32, device=dev)
 
     def conv():
-        ops.lib().call("wtpse_conv_fwd", x.data_ptr(), 32, 0, 0, packed.data_ptr(), bias.data_ptr(), 0, 0, y.data_ptr(), 0, 32,
+        ops.lib().call("wtpse_conv_fwd", x.data_ptr(), 32, 0, 0, packed.data_ptr(), bias.data_ptr(), 0, 0, 0, y.data_ptr(), 0, 32,
                        0, B, H, H, 32, 3, 0, 0, ops.stream_ptr())
     ms = time_kernel(conv)
     flops = 2.0 * 32 * 32 * 9 * H * H * B

@@ -29,7 +29,7 @@ extern "C" {
 int wtpse_pack_conv_weights(const float* params, const int* desc, int n_desc, float* packed, void* stream);
 
 /* out = conv(cat(in0, in1)) [+ bias] [ReLU].  in1 may be NULL (C1 = 0): torch.cat (algorithms.py:955,1018) is virtual.
- * pro: [C0+C1][2] or NULL; pro_relu bit0 / bit1: ReLU on in0 / in1 after the affine.
+ * pro0 / pro1: [C0][2] / [C1][2] (scale, shift) for in0 / in1, or NULL; pro_relu bit0 / bit1: ReLU on in0 / in1 after it.
  * Output channels [0, Csplit) go to out0, the rest to out1 (Csplit == Cout, out1 NULL: no split).
  * stats: NULL or [wtpse_conv_stats_blocks(B,H,W)][Cout][2] per-workgroup (sum, sum^2) of the output (train-mode
  * BatchNorm statistics, algorithms.py:883-889); not combinable with relu_out.
@@ -37,14 +37,14 @@ int wtpse_pack_conv_weights(const float* params, const int* desc, int n_desc, fl
  * its data gradient; not combinable with a split).
  * The data gradient is this same call on dY with the `wd` layout. */
 int wtpse_conv_fwd(const float* in0, int C0, const float* in1, int C1, const float* wpacked, const float* bias,
-                   const float* pro, int pro_relu, float* out0, float* out1, int Csplit, float* stats, int B, int H,
-                   int W, int Cout, int ksize, int relu_out, const float* mask_ref, void* stream);
+                   const float* pro0, const float* pro1, int pro_relu, float* out0, float* out1, int Csplit, float* stats,
+                   int B, int H, int W, int Cout, int ksize, int relu_out, const float* mask_ref, void* stream);
 int wtpse_conv_stats_blocks(int B, int H, int W);
 
 /* dW[Cout][C0+C1][k][k] (+)= sum dY * X, dbias (+)= sum dY (dbias/dbias_slab NULL: skip).  slab: [ksplit][Cout*Cin*k*k],
  * dbias_slab: [ksplit][Cout], ksplit = wtpse_wgrad_ksplit(...).  x inputs take the same prologue as the forward. */
-int wtpse_conv_wgrad(const float* dy, const float* x0, int C0, const float* x1, int C1, const float* pro, int pro_relu,
-                     float* slab, float* dbias_slab, int ksplit, float* dw, float* dbias, int accumulate, int B, int H,
+int wtpse_conv_wgrad(const float* dy, const float* x0, int C0, const float* x1, int C1, const float* pro0,
+                     const float* pro1, int pro_relu, float* slab, float* dbias_slab, int ksplit, float* dw, float* dbias, int accumulate, int B, int H,
                      int W, int Cout, int ksize, void* stream);
 int wtpse_wgrad_ksplit(int B, int H, int W, int Cin, int Cout);
 

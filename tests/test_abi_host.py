@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     assert L.query("wtpse_wgrad_ksplit", 32, 256, 256, 32, 32) == 512
     assert L.query("wtpse_wt_split", 32, 65536, 0) >= 1
     # argument validation happens before any launch
-    assert L.raw("wtpse_conv_fwd")(0, 16, 0, 0, 0, 0, 0, 0, 0, 0, 16, 0, 1, 8, 8, 16, 3, 0, 0, 0) == -1
+    assert L.raw("wtpse_conv_fwd")(0, 16, 0, 0, 0, 0, 0, 0, 0, 0, 0, 16, 0, 1, 8, 8, 16, 3, 0, 0, 0) == -1
 
 
 def test_dropin_surface_matches_reference():

@@ -97,7 +97,8 @@ def test_conv_prologue(case):
     act = torch.cat([F.relu(act[:, :C0]), act[:, C0:]], 1)      # ReLU on in0 only (bit 0)
     ref = F.conv2d(act, w, None, padding=k // 2)
     packed, wf, _ = pack(w)
-    y, _, _ = o.conv_fwd(x0.to(DEV), x1.to(DEV) if C1 else None, packed.data_ptr() + 4 * wf, None, Co, k, pro=pro.to(DEV), pro_relu=1)
+    y, _, _ = o.conv_fwd(x0.to(DEV), x1.to(DEV) if C1 else None, packed.data_ptr() + 4 * wf, None, Co, k,
+                         pro0=pro[:C0].contiguous().to(DEV), pro1=(pro[C0:].contiguous().to(DEV) if C1 else None), pro_relu=1)
     close(y, ref, what="prologue")
 
 
@@ -353,6 +354,6 @@ def test_rejects_bad_arguments():
     from wtpse_hip.lib import WtpseError
     o = ops()
     with pytest.raises(WtpseError):
-        o.lib().call("wtpse_conv_fwd", 0, 16, 0, 0, 0, 0, 0, 0, 0, 0, 16, 0, 1, 8, 8, 16, 3, 0, 0, 0)
+        o.lib().call("wtpse_conv_fwd", 0, 16, 0, 0, 0, 0, 0, 0, 0, 0, 0, 16, 0, 1, 8, 8, 16, 3, 0, 0, 0)
     with pytest.raises(ValueError):
         o.conv_fwd(torch.zeros(1, 16, 8, 8), None, 0, None, 16, 3)     # host tensor: no CPU fallback

@@ -141,10 +141,12 @@ def test_blocks_vs_golden(golden_dir, name, bi):
     x = make_noise(300 + bi, spec[1]).to(DEV)
     wgt = None
     if spec[2] is None:
-        y, tape = E.convd_fwd(h.blk, x, False, True)
+        y, tape = E.convd_fwd(h.blk, x, True)
+        y = y.dense()
     else:
         prev = make_noise(400 + bi, spec[2]).to(DEV)
-        y, tape = E.convu_fwd(h.blk, x, prev, False, True)
+        y, tape = E.convu_fwd(h.blk, x, prev, True)
+        y = y.dense()
     close(y, g[name + ".y"], what="y")
     dy = make_noise(500 + bi, tuple(y.shape)).to(DEV)
     h.begin_backward()
@@ -165,10 +167,10 @@ def test_blocks_vs_golden(golden_dir, name, bi):
     h.blk.eval()
     h.eval()
     if spec[2] is None:
-        ye, _ = E.convd_fwd(h.blk, x, False, False, want_tape=False)
+        ye, _ = E.convd_fwd(h.blk, x, False, want_tape=False)
     else:
-        ye, _ = E.convu_fwd(h.blk, x, prev, False, False, want_tape=False)
-    close(ye, g[name + ".y_eval"], what="y_eval")
+        ye, _ = E.convu_fwd(h.blk, x, prev, False, want_tape=False)
+    close(ye.dense(), g[name + ".y_eval"], what="y_eval")
 
 
 def test_deepwt_vs_golden(golden_dir):

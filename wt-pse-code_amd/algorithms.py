@@ -144,7 +144,7 @@ class WT_PSE(E.HipNet, E.UNetBody):
             return out, None
         learn_x_network.ensure_ready(repack=True)
         w = E.deepwt_fwd(learn_x_network.wt_model, wt_in, want_tape=False)
-        z = learn_x_network._student_mu(w.z2, True, learn_x_network.training, None)
+        z = learn_x_network._student_mu(E.Act(w.z2, None, True), learn_x_network.training, None)
         _, pre, _, fuse = ops.attn_fuse_fwd(z, self.attention_layer.layer1.weight.data_ptr(), emb,
                                             float(self.hparams['shape_attention_coeffient']), False, True, False)
         out, _ = E._conv(self.outc[0], fuse)
@@ -174,8 +174,8 @@ class WT_PSE(E.HipNet, E.UNetBody):
 
     def _embedding(self, inputs, training, tape):
         want = tape is not None
-        x1, c_inc = E.convd_fwd(self.inc, inputs, False, training, want)
-        feat, c_unet = E.unet_fwd(self, x1, False, training, want)
+        x1, c_inc = E.convd_fwd(self.inc, inputs, training, want)
+        feat, c_unet = E.unet_fwd(self, x1, training, want)
         emb, c_mu = E.head_fwd(self.mu, feat, (0, 2), want)
         if want:
             tape.inc, tape.unet, tape.mu = c_inc, c_unet, c_mu
@@ -193,7 +193,7 @@ class WT_PSE(E.HipNet, E.UNetBody):
             return (out,), t
         coef = float(hp['shape_attention_coeffient'])
         w = E.deepwt_fwd(self.wt_model, wt_in, want_tape)
-        th = E.teacher_fwd(self.prior_dist, w.z2, True, mask, training, True, want_tape)
+        th = E.teacher_fwd(self.prior_dist, E.Act(w.z2, None, True), mask, training, True, want_tape)
         eps = self.next_noise(th.mu.shape)
         z_post = ops.reparam_fwd(th.mu, th.logvar, eps)
         att, _, att_mask, fuse = ops.attn_fuse_fwd(z_post, self.attention_layer.layer1.weight.data_ptr(), emb, coef,

@@ -76,7 +76,7 @@ class ShapeVariationalDist_x(E.HipNet, E.UNetBody):
         """Reference shape_networks.py:483-500.  `inputs` = W[-1] = relu(z2), materialised by the caller."""
         self.ensure_ready(repack=True)
         x = self._as_input(inputs)
-        mu, fmap = self._student_mu(x, False, self.training, None, want_fmap=True)
+        mu, fmap = self._student_mu(E.Act(x), self.training, None, want_fmap=True)
         if not training:
             return mu
         logvar, _ = E.head_fwd(self.logvar_prior, fmap, (0, 2, 4), False)
@@ -101,10 +101,10 @@ class ShapeVariationalDist_x(E.HipNet, E.UNetBody):
             object.__setattr__(self, "_anchor", a)
         return a
 
-    def _student_mu(self, feat, feat_relu, training, tape, want_fmap=False):
-        """unet_extractor + mu_prior + NaN scrub (shape_networks.py:468-492).  feat: z2 with ReLU-on-load, or activated."""
+    def _student_mu(self, feat, training, tape, want_fmap=False):
+        """unet_extractor + mu_prior + NaN scrub (shape_networks.py:468-492).  feat: Act (z2 with ReLU-on-load, or activated)."""
         want = tape is not None
-        fmap, c_unet = E.unet_fwd(self, feat, feat_relu, training, want)
+        fmap, c_unet = E.unet_fwd(self, feat, training, want)
         mu, c_mu = E.head_fwd(self.mu_prior, fmap, (0, 2, 4), want)
         ops.nan_scrub_(mu, self._flag)
         if want:
@@ -116,12 +116,12 @@ class ShapeVariationalDist_x(E.HipNet, E.UNetBody):
         training = self.training
         # teacher side: forward only (train-mode BatchNorm still advances its running statistics, as in the reference)
         w1 = E.deepwt_fwd(main_network.wt_model, x, want_tape=False)
-        th = E.teacher_fwd(main_network.prior_dist, w1.z2, True, mask, main_network.training, want_logvar=False,
-                           want_tape=False)
+        th = E.teacher_fwd(main_network.prior_dist, E.Act(w1.z2, None, True), mask, main_network.training,
+                           want_logvar=False, want_tape=False)
         mu_t = th.mu
         # student side
         w2 = E.deepwt_fwd(self.wt_model, x, want_tape)
-        mu_s = self._student_mu(w2.z2, True, training, t if want_tape else None)
+        mu_s = self._student_mu(E.Act(w2.z2, None, True), training, t if want_tape else None)
         scal = torch.empty((5,), dtype=torch.float32, device=x.device)   # (kd, ins_total, ins_off, ins_diag, dom)
         ops.mse_fwd(mu_t, mu_s, out=scal[0:1])
         losses = torch.empty((2, 3), dtype=torch.float32, device=x.device)

@@ -86,7 +86,9 @@ __global__ __launch_bounds__(256) void affine_act_k(const float* __restrict__ y,
   }
 }
 
-// partial[(split*C + c)*2 + {0,1}] = sum over this split's elements of (dzh, dzh*xhat); grid = (C, nsplit)
+// partial[(split*C + c)*2 + {0,1}] = sum over this split's elements of (dzh, dzh*xhat); grid = (C, nsplit).
+// A split owns whole images (b = split, split + nsplit, ...): no per-element division, float4 streams.
+template <bool VEC>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_k(const float* __restrict__ dz, const float* __restrict__ y,
                                                        const float* __restrict__ ss, int relu,
                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -95,16 +97,31 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_k(const float* __restrict__
   const int c = blockIdx.x, split = blockIdx.y, nsplit = gridDim.y;
   const float sc = ss[2 * c], sf = ss[2 * c + 1], mu = mean[c], is = invstd[c];
   float s1 = 0.f, s2 = 0.f;
-  const long long total = (long long)B * HW;
-  for (long long e = (long long)split * 256 + threadIdx.x; e < total; e += (long long)nsplit * 256) {
-    int b = (int)(e / HW);
-    int p = (int)(e - (long long)b * HW);
-    size_t idx = ((size_t)b * C + c) * HW + p;
-    float yv = y[idx], g = dz[idx];
-    if (relu && !(fmaf(yv, sc, sf) > 0.f)) g = 0.f;
-    s1 += g;
-    s2 += g * (yv - mu) * is;
+  for (int b = split; b < B; b += nsplit) {
+    const size_t base = ((size_t)b * C + c) * HW;
+    if (VEC) {
+      for (int p = threadIdx.x * 4; p < HW; p += 1024) {
+        float4 yv = *reinterpret_cast<const float4*>(y + base + p);
+        float4 g = *reinterpret_cast<const float4*>(dz + base + p);
+        if (relu) {
+          if (!(fmaf(yv.x, sc, sf) > 0.f)) g.x = 0.f;
+          if (!(fmaf(yv.y, sc, sf) > 0.f)) g.y = 0.f;
+          if (!(fmaf(yv.z, sc, sf) > 0.f)) g.z = 0.f;
+          if (!(fmaf(yv.w, sc, sf) > 0.f)) g.w = 0.f;
+        }
+        s1 += (g.x + g.y) + (g.z + g.w);
+        s2 += (g.x * (yv.x - mu) + g.y * (yv.y - mu)) + (g.z * (yv.z - mu) + g.w * (yv.w - mu));
+      }
+    } else {
+      for (int p = threadIdx.x; p < HW; p += 256) {
+        float yv = y[base + p], g = dz[base + p];
+        if (relu && !(fmaf(yv, sc, sf) > 0.f)) g = 0.f;
+        s1 += g;
+        s2 += g * (yv - mu);
+      }
+    }
   }
+  s2 *= is;
   s1 = wave_xor_sum(s1, 32);
   s2 = wave_xor_sum(s2, 32);
   if ((threadIdx.x & 63) == 0) {
@@ -226,11 +243,8 @@ extern "C" int wtpse_affine_act(const float* y, const float* scale_shift, int re
 }
 
 extern "C" int wtpse_bn_bwd_nsplit(int B, int C, int HW) {
-  long long per_c = (long long)B * HW;
-  int ns = (int)((per_c + 8191) / 8192);
-  int cap = 2048 / (C > 0 ? C : 1);
-  if (cap < 1) cap = 1;
-  if (ns > cap) ns = cap;
+  int ns = 2048 / (C > 0 ? C : 1);   // ~2048 workgroups; a split owns whole images
+  if (ns > B) ns = B;
   if (ns < 1) ns = 1;
   return ns;
 }
@@ -243,8 +257,12 @@ extern "C" int wtpse_bn_bwd(const float* dz, const float* y, const float* scale_
   WTPSE_REQUIRE(B > 0 && C > 0 && HW > 0);
   hipStream_t st = (hipStream_t)stream;
   const int ns = wtpse_bn_bwd_nsplit(B, C, HW);
-  hipLaunchKernelGGL(bn_bwd_reduce_k, dim3(C, ns), dim3(256), 0, st, dz, y, scale_shift, relu, save_mean, save_invstd, B,
-                     C, HW, partial);
+  if (vec_ok(HW, dz, y, nullptr))
+    hipLaunchKernelGGL(bn_bwd_reduce_k<true>, dim3(C, ns), dim3(256), 0, st, dz, y, scale_shift, relu, save_mean,
+                       save_invstd, B, C, HW, partial);
+  else
+    hipLaunchKernelGGL(bn_bwd_reduce_k<false>, dim3(C, ns), dim3(256), 0, st, dz, y, scale_shift, relu, save_mean,
+                       save_invstd, B, C, HW, partial);
   hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(C), dim3(64), 0, st, partial, ns, C, (double)B * HW, gamma, save_mean,
                      save_invstd, dgamma, dbeta, accumulate, coef, (const float*)nullptr, (float*)nullptr);
   if (vec_ok(HW, dz, y, dy))
@@ -265,8 +283,12 @@ extern "C" int wtpse_bn_bwd_reduce(const float* dz, const float* y, const float*
   WTPSE_REQUIRE(dz && y && scale_shift && save_mean && save_invstd && partial && sums_local && B > 0 && C > 0 && HW > 0);
   hipStream_t st = (hipStream_t)stream;
   const int ns = wtpse_bn_bwd_nsplit(B, C, HW);
-  hipLaunchKernelGGL(bn_bwd_reduce_k, dim3(C, ns), dim3(256), 0, st, dz, y, scale_shift, relu, save_mean, save_invstd, B,
-                     C, HW, partial);
+  if (vec_ok(HW, dz, y, nullptr))
+    hipLaunchKernelGGL(bn_bwd_reduce_k<true>, dim3(C, ns), dim3(256), 0, st, dz, y, scale_shift, relu, save_mean,
+                       save_invstd, B, C, HW, partial);
+  else
+    hipLaunchKernelGGL(bn_bwd_reduce_k<false>, dim3(C, ns), dim3(256), 0, st, dz, y, scale_shift, relu, save_mean,
+                       save_invstd, B, C, HW, partial);
   hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(C), dim3(64), 0, st, partial, ns, C, 1.0, (const float*)nullptr, save_mean,
                      save_invstd, (float*)nullptr, (float*)nullptr, 0, (float*)nullptr, (const float*)nullptr, sums_local);
   return wtpse_status();

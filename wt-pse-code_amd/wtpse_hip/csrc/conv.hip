@@ -26,7 +26,8 @@ struct ConvArgs {
   const float* in1;
   const float* wp;     // packed weights [CinP][taps][CoutP]
   const float* bias;   // [Cout] or null
-  const float* pro;    // [Cin][2] (scale, shift) applied to the input on load, or null
+  const float* pro0;   // [C0][2] (scale, shift) applied to in0 on load, or null
+  const float* pro1;   // [C1][2] for in1, or null
   float* out0;
   float* out1;
   float* stats;        // [gridDim.x][Cout][2] or null
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(256) void conv_fwd_k(ConvArgs a) {
   unsigned voff[NPOS];
 #pragma unroll
   for (int i = 0; i < NPOS; ++i) voff[i] = gpos[i] >= 0 ? (unsigned)gpos[i] * 4u : BUF_OOB;
-  const bool any_pro = a.pro != nullptr || a.pro_relu != 0;
+  const bool any_pro = a.pro0 != nullptr || a.pro1 != nullptr || a.pro_relu != 0;
   for (int c0 = 0; c0 < a.CinP; c0 += KC) {
     const int kc = min(KC, a.CinP - c0);
     __syncthreads();
@@ -147,10 +148,11 @@ __global__ __launch_bounds__(256) void conv_fwd_k(ConvArgs a) {
     // zero padding applies AFTER the fused affine/ReLU, as in the reference graph
     if (any_pro) {
       const bool relu = first ? (a.pro_relu & 1) : (a.pro_relu & 2);
+      const float* pro = first ? a.pro0 : a.pro1;
 #pragma unroll
       for (int c = 0; c < KC; ++c) {
-        const int cg = min(c0 + c, a.Cin - 1);
-        const float sc = a.pro ? a.pro[2 * cg] : 1.f, sh = a.pro ? a.pro[2 * cg + 1] : 0.f;
+        const int cg = min(cbase + c, cmax);
+        const float sc = pro ? pro[2 * cg] : 1.f, sh = pro ? pro[2 * cg + 1] : 0.f;
 #pragma unroll
         for (int i = 0; i < NPOS; ++i) {
           float v = fmaf(xv[c][i], sc, sh);
@@ -269,7 +271,7 @@ extern "C" int wtpse_conv_stats_blocks(int B, int H, int W) {
 
 // See include/wtpse_hip.h for the contract.
 extern "C" int wtpse_conv_fwd(const float* in0, int C0, const float* in1, int C1, const float* wpacked,
-                              const float* bias, const float* pro, int pro_relu, float* out0, float* out1,
+                              const float* bias, const float* pro0, const float* pro1, int pro_relu, float* out0, float* out1,
                               int Csplit, float* stats, int B, int H, int W, int Cout, int ksize, int relu_out,
                               const float* mask_ref, void* stream) {
   WTPSE_REQUIRE(in0 && wpacked && out0 && B > 0 && H > 0 && W > 0 && C0 > 0 && C1 >= 0 && Cout > 0);
@@ -280,7 +282,7 @@ extern "C" int wtpse_conv_fwd(const float* in0, int C0, const float* in1, int C1
   WTPSE_REQUIRE(!(mask_ref && out1));
   WTPSE_REQUIRE(C1 == 0 || C0 % 16 == 0);   // a channel chunk must not straddle the two inputs
   ConvArgs a;
-  a.in0 = in0; a.in1 = in1; a.wp = wpacked; a.bias = bias; a.pro = pro; a.out0 = out0; a.out1 = out1; a.stats = stats; a.mask = mask_ref;
+  a.in0 = in0; a.in1 = in1; a.wp = wpacked; a.bias = bias; a.pro0 = pro0; a.pro1 = pro1; a.out0 = out0; a.out1 = out1; a.stats = stats; a.mask = mask_ref;
   a.B = B; a.H = H; a.W = W; a.C0 = C0; a.C1 = C1; a.Cin = C0 + C1; a.CinP = (a.Cin + 3) & ~3;
   a.Cout = Cout; a.CoutP = (Cout + 15) & ~15; a.Csplit = Csplit; a.pro_relu = pro_relu; a.relu_out = relu_out;
   a.tiles_x = a.tiles_y = 0;
@@ -344,7 +346,8 @@ struct WgradArgs {
   const float* dy;
   const float* x0;
   const float* x1;
-  const float* pro;
+  const float* pro0;
+  const float* pro1;
   float* slab;    // [ksplit][Cout][Cin][taps]
   float* dbias;   // [ksplit][Cout] or null
   int B, H, W, C0, C1, Cin, Cout;
@@ -381,7 +384,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_k(WgradArgs a) {
   const int cin0 = group * a.cg;
   const int HW = a.H * a.W;
   const int j = lane & (MB - 1), kl = lane / MB;
-  const bool any_pro = a.pro != nullptr || a.pro_relu != 0;
+  const bool any_pro = a.pro0 != nullptr || a.pro1 != nullptr || a.pro_relu != 0;
 
   int boff[MAXNB];
 #pragma unroll
@@ -448,10 +451,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_k(WgradArgs a) {
       }
       if (any_pro) {
         const bool relu = xfirst ? (a.pro_relu & 1) : (a.pro_relu & 2);
+        const float* pro = xfirst ? a.pro0 : a.pro1;
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
-          const int cgl = min(cin0 + g * 16 + c, a.Cin - 1);
-          const float sc = a.pro ? a.pro[2 * cgl] : 1.f, sh = a.pro ? a.pro[2 * cgl + 1] : 0.f;
+          const int cgl = min(xbase + c, xmax);
+          const float sc = pro ? pro[2 * cgl] : 1.f, sh = pro ? pro[2 * cgl + 1] : 0.f;
 #pragma unroll
           for (int i = 0; i < NPOS; ++i) {
             float v = fmaf(xv[c][i], sc, sh);
@@ -571,8 +575,8 @@ extern "C" int wtpse_wgrad_ksplit(int B, int H, int W, int Cin, int Cout) {
   return ks;
 }
 
-extern "C" int wtpse_conv_wgrad(const float* dy, const float* x0, int C0, const float* x1, int C1, const float* pro,
-                                int pro_relu, float* slab, float* dbias_slab, int ksplit, float* dw, float* dbias,
+extern "C" int wtpse_conv_wgrad(const float* dy, const float* x0, int C0, const float* x1, int C1, const float* pro0,
+                                const float* pro1, int pro_relu, float* slab, float* dbias_slab, int ksplit, float* dw, float* dbias,
                                 int accumulate, int B, int H, int W, int Cout, int ksize, void* stream) {
   WTPSE_REQUIRE(dy && x0 && slab && dw && B > 0 && H > 0 && W > 0 && C0 > 0 && C1 >= 0 && Cout > 0 && ksplit > 0);
   WTPSE_REQUIRE(ksize == 1 || ksize == 3);
@@ -580,7 +584,7 @@ extern "C" int wtpse_conv_wgrad(const float* dy, const float* x0, int C0, const 
   WTPSE_REQUIRE((dbias == nullptr) == (dbias_slab == nullptr));
   const bool p32 = Cout > 16;
   WgradArgs a;
-  a.dy = dy; a.x0 = x0; a.x1 = x1; a.pro = pro; a.slab = slab; a.dbias = dbias_slab;
+  a.dy = dy; a.x0 = x0; a.x1 = x1; a.pro0 = pro0; a.pro1 = pro1; a.slab = slab; a.dbias = dbias_slab;
   a.B = B; a.H = H; a.W = W; a.C0 = C0; a.C1 = C1; a.Cin = C0 + C1; a.Cout = Cout; a.pro_relu = pro_relu;
   const int MB = p32 ? 32 : 16;
   const int taps = ksize * ksize;

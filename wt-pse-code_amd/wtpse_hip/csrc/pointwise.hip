@@ -94,6 +94,42 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_k(const float* __restrict_
   out[i] = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
 }
 
+// 4 consecutive outputs of one row per thread (W even): 2 x 4 input loads, one 16-byte store; bitwise the same
+// expression tree as the scalar kernel / ATen (weights 0.25/0.75, (1,0) at the clamped first column and row)
+__global__ __launch_bounds__(256) void upsample2x_fwd4_k(const float* __restrict__ x, const float* __restrict__ pro, int relu,
+                                                         float* __restrict__ out, int C, int H, int W, long long total4) {
+  const int Ho = 2 * H, Wo = 2 * W, W2 = W / 2;
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;   // over B*C*Ho*(Wo/4)
+  if (i >= total4) return;
+  int k = (int)(i % W2);
+  long long r = i / W2;
+  int yo = (int)(r % Ho);
+  long long bc = r / Ho;
+  int c = (int)(bc % C);
+  int y0, y1;
+  float ly;
+  up_src(yo, H, y0, y1, ly);
+  const int m = 2 * k;
+  const int xm1 = max(m - 1, 0), x1 = min(m + 1, W - 1), x2 = min(m + 2, W - 1);
+  const float* r0 = x + (size_t)bc * H * W + (size_t)y0 * W;
+  const float* r1 = x + (size_t)bc * H * W + (size_t)y1 * W;
+  float a[4] = {act_in(r0[xm1], pro, c, relu), act_in(r0[m], pro, c, relu), act_in(r0[x1], pro, c, relu), act_in(r0[x2], pro, c, relu)};
+  float b[4] = {act_in(r1[xm1], pro, c, relu), act_in(r1[m], pro, c, relu), act_in(r1[x1], pro, c, relu), act_in(r1[x2], pro, c, relu)};
+  float ha[4], hb[4];
+  // horizontal: out0 = xo 2m (first column of the image: weights (1, 0) on (c[0], c[1])), out1 = 2m+1, out2 = 2m+2, out3 = 2m+3
+  if (m == 0) { ha[0] = 1.f * a[1] + 0.f * a[2]; hb[0] = 1.f * b[1] + 0.f * b[2]; }
+  else        { ha[0] = 0.25f * a[0] + 0.75f * a[1]; hb[0] = 0.25f * b[0] + 0.75f * b[1]; }
+  ha[1] = 0.75f * a[1] + 0.25f * a[2]; hb[1] = 0.75f * b[1] + 0.25f * b[2];
+  ha[2] = 0.25f * a[1] + 0.75f * a[2]; hb[2] = 0.25f * b[1] + 0.75f * b[2];
+  ha[3] = 0.75f * a[2] + 0.25f * a[3]; hb[3] = 0.75f * b[2] + 0.25f * b[3];
+  float4 o;
+  o.x = (1.f - ly) * ha[0] + ly * hb[0];
+  o.y = (1.f - ly) * ha[1] + ly * hb[1];
+  o.z = (1.f - ly) * ha[2] + ly * hb[2];
+  o.w = (1.f - ly) * ha[3] + ly * hb[3];
+  *reinterpret_cast<float4*>(out + (size_t)bc * Ho * Wo + (size_t)yo * Wo + 4 * k) = o;
+}
+
 __device__ __forceinline__ float up_w(int d, int n, int k) {  // weight of source k in destination d (1-D)
   int i0, i1;
   float l1;
@@ -434,7 +470,10 @@ extern "C" int wtpse_maxpool2_bwd(const float* x, const float* pro, int relu, co
 extern "C" int wtpse_upsample2x_fwd(const float* x, const float* pro, int relu, float* out, int B, int C, int H, int W, void* stream) {
   WTPSE_REQUIRE(x && out && B > 0 && C > 0 && H > 0 && W > 0);
   long long total = (long long)B * C * H * W * 4;
-  hipLaunchKernelGGL(upsample2x_fwd_k, GRID1(total), dim3(256), 0, ST, x, pro, relu, out, C, H, W, total);
+  if (W % 2 == 0 && W >= 2 && (((uintptr_t)out) & 15) == 0)
+    hipLaunchKernelGGL(upsample2x_fwd4_k, GRID1(total / 4), dim3(256), 0, ST, x, pro, relu, out, C, H, W, total / 4);
+  else
+    hipLaunchKernelGGL(upsample2x_fwd_k, GRID1(total), dim3(256), 0, ST, x, pro, relu, out, C, H, W, total);
   return wtpse_status();
 }
 extern "C" int wtpse_upsample2x_bwd(const float* dout, float* dx, int accumulate, int B, int C, int H, int W, void* stream) {

@@ -152,7 +152,7 @@ class TeacherP(UNetBody):
         """(z, mu) in training, mu otherwise; `inputs` = W[-1] = relu(z2) materialised by the caller."""
         root = self.fusion[0]._root
         root.ensure_ready(repack=True)
-        t = teacher_fwd(self, inputs.contiguous(), False, mask.contiguous(), self.training, want_logvar=training,
+        t = teacher_fwd(self, inputs.contiguous(), mask.contiguous(), self.training, want_logvar=training,
                         want_tape=False)
         if not training:
             return t.mu
@@ -333,10 +333,37 @@ class Tape:
     pass
 
 
-def _conv(layer, x0, x1=None, pro_relu=0, relu_out=False, want_stats=False):
+class Act:
+    """An activation as its producer left it in HBM: the stored tensor `t`, still to be passed through
+    act(t * scale + shift) — BatchNorm-apply (`pro` = [C,2] scale/shift or None) and ReLU (`relu`) — which every consumer
+    (conv / weight-gradient loaders, max-pool, bilinear upsample) applies as it loads.  BatchNorm outputs, relu(z2) and the
+    two halves of a torch.cat therefore never make a round trip through memory."""
+    __slots__ = ("t", "pro", "relu")
+
+    def __init__(self, t, pro=None, relu=False):
+        self.t, self.pro, self.relu = t, pro, bool(relu)
+
+    def dense(self):
+        if self.pro is None and not self.relu:
+            return self.t
+        return ops.affine_act(self.t, self.pro, self.relu)
+
+
+def as_act(x):
+    return x if isinstance(x, Act) else Act(x)
+
+
+def _relu_bits(a0, a1):
+    return (1 if a0.relu else 0) | (2 if (a1 is not None and a1.relu) else 0)
+
+
+def _conv(layer, a0, a1=None, relu_out=False, want_stats=False):
     root = layer._root
-    y, _, stats = ops.conv_fwd(x0, x1, root.packed_ptr(layer.wf_off), layer.bias, layer.cout, layer.k, None, pro_relu,
-                               relu_out, want_stats)
+    a0 = as_act(a0)
+    a1 = as_act(a1) if a1 is not None else None
+    y, _, stats = ops.conv_fwd(a0.t, a1.t if a1 is not None else None, root.packed_ptr(layer.wf_off), layer.bias, layer.cout,
+                               layer.k, a0.pro, _relu_bits(a0, a1), relu_out, want_stats, None, None,
+                               a1.pro if a1 is not None else None)
     return y, stats
 
 
@@ -347,18 +374,23 @@ def _dgrad(layer, dy, split=None, mask_ref=None):
                         mask_ref)[:2]
 
 
-def _wgrad(layer, dy, x0, x1=None, pro_relu=0, with_bias=True):
+def _wgrad(layer, dy, a0, a1=None, with_bias=True):
     root = layer._root
+    a0 = as_act(a0)
+    a1 = as_act(a1) if a1 is not None else None
     dw = root.gview(layer.weight)
     db = root.gview(layer.bias) if with_bias else None
-    ops.conv_wgrad(dy, x0, x1, layer.k, dw, db, None, pro_relu, False)
+    ops.conv_wgrad(dy, a0.t, a1.t if a1 is not None else None, layer.k, dw, db, a0.pro, _relu_bits(a0, a1), False,
+                   a1.pro if a1 is not None else None)
 
 
-# ---- conv + BatchNorm (+ReLU), activations materialised ------------------------------------------------------
-def convbn_fwd(conv, bn, x0, x1, relu, training, pro_relu=0, want_tape=True):
+# ---- conv + BatchNorm (+ReLU): the result stays virtual (raw conv output + per-channel scale/shift) --------------
+def convbn_fwd(conv, bn, a0, a1, relu, training, want_tape=True):
     root = conv._root
+    a0 = as_act(a0)
+    a1 = as_act(a1) if a1 is not None else None
     if training:
-        y, stats = _conv(conv, x0, x1, pro_relu, False, True)
+        y, stats = _conv(conv, a0, a1, False, True)
         B, _, H, W = y.shape
         if root._dp is not None and root._dp.bn_sync:
             stats, count = root._dp.sync_bn_stats(stats, B * H * W)
@@ -367,19 +399,19 @@ def convbn_fwd(conv, bn, x0, x1, relu, training, pro_relu=0, want_tape=True):
         ss, mean, invstd = ops.bn_finalize(stats, count, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                            bn.num_batches_tracked)
     else:
-        y, _ = _conv(conv, x0, x1, pro_relu, False, False)
+        y, _ = _conv(conv, a0, a1, False, False)
         ss = ops.bn_eval_coeffs(bn.weight, bn.bias, bn.running_mean, bn.running_var)
         mean = invstd = None
-    z = ops.affine_act(y, ss, relu)
+    z = Act(y, ss, relu)
     if not want_tape:
         return z, None
     t = Tape()
-    t.x0, t.x1, t.pro_relu, t.y, t.ss, t.mean, t.invstd, t.relu = x0, x1, pro_relu, y, ss, mean, invstd, relu
+    t.a0, t.a1, t.y, t.ss, t.mean, t.invstd, t.relu = a0, a1, y, ss, mean, invstd, relu
     return z, t
 
 
 def convbn_bwd(conv, bn, t, dz, need_dx=True):
-    """-> (dx0, dx1): gradients wrt the inputs AS LOADED (i.e. after a ReLU-on-load, if any)."""
+    """dz: gradient wrt the activated output.  -> (dx0, dx1): gradients wrt the inputs AS LOADED (activated)."""
     root = conv._root
     if root._dp is not None and root._dp.bn_sync:
         dy = root._dp.bn_bwd_synced(dz, t, bn, root)
@@ -387,22 +419,22 @@ def convbn_bwd(conv, bn, t, dz, need_dx=True):
         dy = ops.bn_bwd(dz, t.y, t.ss, t.relu, bn.weight, t.mean, t.invstd, root.gview(bn.weight), root.gview(bn.bias))
     # the conv bias in front of a train-mode BatchNorm has an exactly-zero gradient (sum of dy over the batch
     # vanishes); the reference carries rounding noise there. It is left at 0.
-    _wgrad(conv, dy, t.x0, t.x1, t.pro_relu, with_bias=False)
+    _wgrad(conv, dy, t.a0, t.a1, with_bias=False)
     if not need_dx:
         return None, None
-    split = t.x0.shape[1] if t.x1 is not None else None
+    split = t.a0.t.shape[1] if t.a1 is not None else None
     return _dgrad(conv, dy, split)
 
 
 # ---- ConvD (algorithms.py:897-917) ---------------------------------------------------------------------------
-def convd_fwd(blk, x, x_relu, training, want_tape=True):
+def convd_fwd(blk, x, training, want_tape=True):
     t = Tape()
-    t.x, t.x_relu = x, x_relu
-    h = x if blk.first else ops.maxpool2_fwd(x, None, x_relu)
-    a, t.c1 = convbn_fwd(blk.conv1, blk.bn1, h, None, False, training, pro_relu=(1 if (blk.first and x_relu) else 0),
-                         want_tape=want_tape)
-    b, t.c2 = convbn_fwd(blk.conv2, blk.bn2, a, None, True, training, want_tape=want_tape)
-    c, t.c3 = convbn_fwd(blk.conv3, blk.bn3, b, None, True, training, want_tape=want_tape)
+    x = as_act(x)
+    t.x = x
+    h = x if blk.first else Act(ops.maxpool2_fwd(x.t, x.pro, x.relu))
+    a, t.c1 = convbn_fwd(blk.conv1, blk.bn1, h, None, False, training, want_tape)
+    b, t.c2 = convbn_fwd(blk.conv2, blk.bn2, a, None, True, training, want_tape)
+    c, t.c3 = convbn_fwd(blk.conv3, blk.bn3, b, None, True, training, want_tape)
     return c, t
 
 
@@ -418,23 +450,23 @@ def convd_bwd(blk, t, dz, dx_accum=None, need_dx=True):
             ops.axpy(dx_accum, d)
             return dx_accum
         return d
-    return ops.maxpool2_bwd(t.x, d, dx_accum, dx_accum is not None, None, t.x_relu)
+    return ops.maxpool2_bwd(t.x.t, d, dx_accum, dx_accum is not None, t.x.pro, t.x.relu)
 
 
 # ---- ConvU (algorithms.py:941-962) ---------------------------------------------------------------------------
-def convu_fwd(blk, x, prev, prev_relu, training, want_tape=True):
+def convu_fwd(blk, x, prev, training, want_tape=True):
     t = Tape()
+    x = as_act(x)
     if not blk.first:
-        x, t.c1 = convbn_fwd(blk.conv1, blk.bn1, x, None, True, training, want_tape=want_tape)
-    u = ops.upsample2x_fwd(x)
-    y, t.c2 = convbn_fwd(blk.conv2, blk.bn2, u, None, True, training, want_tape=want_tape)
-    out, t.c3 = convbn_fwd(blk.conv3, blk.bn3, prev, y, True, training, pro_relu=(1 if prev_relu else 0),
-                           want_tape=want_tape)
+        x, t.c1 = convbn_fwd(blk.conv1, blk.bn1, x, None, True, training, want_tape)
+    u = ops.upsample2x_fwd(x.t, x.pro, x.relu)
+    y, t.c2 = convbn_fwd(blk.conv2, blk.bn2, u, None, True, training, want_tape)
+    out, t.c3 = convbn_fwd(blk.conv3, blk.bn3, prev, y, True, training, want_tape)
     return out, t
 
 
 def convu_bwd(blk, t, dout):
-    """-> (dx, dprev); dprev is wrt prev as loaded."""
+    """-> (dx, dprev); both wrt the activated tensors."""
     dprev, dy = convbn_bwd(blk.conv3, blk.bn3, t.c3, dout)
     du, _ = convbn_bwd(blk.conv2, blk.bn2, t.c2, dy)
     dx = ops.upsample2x_bwd(du)
@@ -444,21 +476,22 @@ def convu_bwd(blk, t, dout):
 
 
 # ---- U-Net body ------------------------------------------------------------------------------------------------
-def unet_fwd(net, x1, x1_relu, training, want_tape=True):
+def unet_fwd(net, x1, training, want_tape=True):
     t = Tape()
-    x2, t.d1 = convd_fwd(net.down1, x1, x1_relu, training, want_tape)
-    x3, t.d2 = convd_fwd(net.down2, x2, False, training, want_tape)
-    x4, t.d3 = convd_fwd(net.down3, x3, False, training, want_tape)
-    x5, t.d4 = convd_fwd(net.down4, x4, False, training, want_tape)
-    x, t.u1 = convu_fwd(net.up1, x5, x4, False, training, want_tape)
-    x, t.u2 = convu_fwd(net.up2, x, x3, False, training, want_tape)
-    x, t.u3 = convu_fwd(net.up3, x, x2, False, training, want_tape)
-    x, t.u4 = convu_fwd(net.up4, x, x1, x1_relu, training, want_tape)
+    x1 = as_act(x1)
+    x2, t.d1 = convd_fwd(net.down1, x1, training, want_tape)
+    x3, t.d2 = convd_fwd(net.down2, x2, training, want_tape)
+    x4, t.d3 = convd_fwd(net.down3, x3, training, want_tape)
+    x5, t.d4 = convd_fwd(net.down4, x4, training, want_tape)
+    x, t.u1 = convu_fwd(net.up1, x5, x4, training, want_tape)
+    x, t.u2 = convu_fwd(net.up2, x, x3, training, want_tape)
+    x, t.u3 = convu_fwd(net.up3, x, x2, training, want_tape)
+    x, t.u4 = convu_fwd(net.up4, x, x1, training, want_tape)
     return x, t
 
 
 def unet_bwd(net, t, dfeat, need_dx1=True):
-    """-> gradient wrt x1 as loaded (None if not needed)."""
+    """-> gradient wrt the activated x1 (None if not needed)."""
     d, g1 = convu_bwd(net.up4, t.u4, dfeat)
     d, g2 = convu_bwd(net.up3, t.u3, d)
     d, g3 = convu_bwd(net.up2, t.u2, d)
@@ -473,16 +506,17 @@ def unet_bwd(net, t, dfeat, need_dx1=True):
 # ---- 1x1 heads: conv, ReLU, conv, ReLU, conv (algorithms.py:1006-1012) / conv, ReLU, conv (:1199-1200) -------------
 def head_fwd(seq, x, idxs, want_tape=True):
     t = Tape()
-    t.x, t.acts = x, []
-    h = x
+    t.x, t.acts = as_act(x), []
+    h = t.x
     for n, i in enumerate(idxs):
         last = n == len(idxs) - 1
-        h, _ = _conv(seq[i], h, None, 0, not last, False)
+        h, _ = _conv(seq[i], h, None, not last, False)
         t.acts.append(h)
     return h, t
 
 
 def head_bwd(seq, t, d, idxs):
+    """-> gradient wrt the activated head input."""
     for n in reversed(range(len(idxs))):
         layer = seq[idxs[n]]
         inp = t.x if n == 0 else t.acts[n - 1]
@@ -497,9 +531,9 @@ def deepwt_fwd(wt, x, want_tape=True):
     t = Tape()
     a, b = wt.DoubleConv.double_conv, wt.DoubleConv2.double_conv
     t.x = x
-    t.h1, _ = _conv(a[0], x, None, 0, True)
+    t.h1, _ = _conv(a[0], x, None, True)
     t.z1, _ = _conv(a[2], t.h1)
-    t.h2, _ = _conv(b[0], t.z1, None, 1, True)     # ReLU(z1) on load
+    t.h2, _ = _conv(b[0], Act(t.z1, None, True), None, True)     # ReLU(z1) on load
     t.z2, _ = _conv(b[2], t.h2)
     return t
 
@@ -509,7 +543,7 @@ def deepwt_bwd(wt, t, dz2, dz1_extra=None):
     a, b = wt.DoubleConv.double_conv, wt.DoubleConv2.double_conv
     _wgrad(b[2], dz2, t.h2)
     d, _ = _dgrad(b[2], dz2, mask_ref=t.h2)
-    _wgrad(b[0], d, t.z1, None, 1)
+    _wgrad(b[0], d, Act(t.z1, None, True))
     dz1, _ = _dgrad(b[0], d, mask_ref=t.z1)
     if dz1_extra is not None:
         dz1_extra(dz1)
@@ -519,15 +553,16 @@ def deepwt_bwd(wt, t, dz2, dz1_extra=None):
 
 
 # ---- teacher: ShapeVariationalDist_y_x (algorithms.py:1014-1033,1055-1075) ---------------------------------------------
-def teacher_fwd(tn, feat, feat_relu, mask, training, want_logvar=True, want_tape=True):
-    """feat: z2 (feat_relu=True: ReLU on load) or an already-activated tensor."""
+def teacher_fwd(tn, feat, mask, training, want_logvar=True, want_tape=True):
+    """feat: Act — z2 with ReLU-on-load, or an already-activated tensor."""
     t = Tape()
     inc = tn.inc.double_conv
-    m1, t.i0 = convbn_fwd(inc[0], inc[1], mask, None, True, training, want_tape=want_tape)
-    m2, t.i3 = convbn_fwd(inc[3], inc[4], m1, None, True, training, want_tape=want_tape)
-    t.m2, t.feat, t.feat_relu = m2, feat, feat_relu
-    t.xf, _ = _conv(tn.fusion[0], m2, feat, 2 if feat_relu else 0, True)
-    fmap, t.unet = unet_fwd(tn, t.xf, False, training, want_tape)
+    feat = as_act(feat)
+    m1, t.i0 = convbn_fwd(inc[0], inc[1], mask, None, True, training, want_tape)
+    m2, t.i3 = convbn_fwd(inc[3], inc[4], m1, None, True, training, want_tape)
+    t.m2, t.feat = m2, feat
+    t.xf, _ = _conv(tn.fusion[0], m2, feat, True)
+    fmap, t.unet = unet_fwd(tn, t.xf, training, want_tape)
     t.mu, t.hmu = head_fwd(tn.mu_prior, fmap, (0, 2, 4), want_tape)
     if want_logvar:
         t.logvar, t.hlv = head_fwd(tn.logvar_prior, fmap, (0, 2, 4), want_tape)
@@ -535,15 +570,15 @@ def teacher_fwd(tn, feat, feat_relu, mask, training, want_logvar=True, want_tape
 
 
 def teacher_bwd(tn, t, dmu, dlogvar):
-    """-> gradient wrt feat as loaded (i.e. wrt relu(z2) when feat_relu)."""
+    """-> gradient wrt the activated feat (i.e. wrt relu(z2) when feat carries ReLU-on-load)."""
     d = head_bwd(tn.mu_prior, t.hmu, dmu, (0, 2, 4))
     if dlogvar is not None:
         d2 = head_bwd(tn.logvar_prior, t.hlv, dlogvar, (0, 2, 4))
         ops.axpy(d, d2)
     dxf = unet_bwd(tn, t.unet, d)
     dxf = ops.relu_mask(dxf, t.xf)
-    _wgrad(tn.fusion[0], dxf, t.m2, t.feat, 2 if t.feat_relu else 0)
-    dm2, dfeat = _dgrad(tn.fusion[0], dxf, split=t.m2.shape[1])
+    _wgrad(tn.fusion[0], dxf, t.m2, t.feat)
+    dm2, dfeat = _dgrad(tn.fusion[0], dxf, split=t.m2.t.shape[1])
     inc = tn.inc.double_conv
     dm1, _ = convbn_bwd(inc[3], inc[4], t.i3, dm2)
     convbn_bwd(inc[0], inc[1], t.i0, dm1, need_dx=False)

@@ -34,10 +34,10 @@ def workspace(tag, nfloats, device):
 
 
 # ----------------------------------------------------------------------------------------------- convolution
-def conv_fwd(in0, in1, wpacked_ptr, bias, cout, ksize, pro=None, pro_relu=0, relu_out=False, want_stats=False,
-             split=None, mask_ref=None):
+def conv_fwd(in0, in1, wpacked_ptr, bias, cout, ksize, pro0=None, pro_relu=0, relu_out=False, want_stats=False,
+             split=None, mask_ref=None, pro1=None):
     """-> (out0, out1 or None, stats or None).  `wpacked_ptr` is a raw device pointer into the packed-weight buffer."""
-    _chk(in0, "in0"); _chk(in1, "in1"); _chk(pro, "pro")
+    _chk(in0, "in0"); _chk(in1, "in1"); _chk(pro0, "pro0"); _chk(pro1, "pro1")
     B, C0, H, W = in0.shape
     C1 = 0 if in1 is None else in1.shape[1]
     L = lib()
@@ -53,12 +53,12 @@ def conv_fwd(in0, in1, wpacked_ptr, bias, cout, ksize, pro=None, pro_relu=0, rel
     if want_stats:
         nblk = L.query("wtpse_conv_stats_blocks", B, H, W)
         stats = torch.empty((nblk, cout, 2), dtype=torch.float32, device=in0.device)
-    L.call("wtpse_conv_fwd", ptr(in0), C0, ptr(in1), C1, wpacked_ptr, ptr(bias), ptr(pro), int(pro_relu), ptr(out0),
+    L.call("wtpse_conv_fwd", ptr(in0), C0, ptr(in1), C1, wpacked_ptr, ptr(bias), ptr(pro0), ptr(pro1), int(pro_relu), ptr(out0),
            ptr(out1), csplit, ptr(stats), B, H, W, cout, ksize, int(relu_out), ptr(mask_ref), stream_ptr())
     return out0, out1, stats
 
 
-def conv_wgrad(dy, x0, x1, ksize, dw, dbias, pro=None, pro_relu=0, accumulate=False):
+def conv_wgrad(dy, x0, x1, ksize, dw, dbias, pro0=None, pro_relu=0, accumulate=False, pro1=None):
     """dw / dbias are views into the flat gradient buffer ([Cout,Cin,k,k] / [Cout] or None)."""
     _chk(dy, "dy"); _chk(x0, "x0"); _chk(x1, "x1")
     B, cout, H, W = dy.shape
@@ -69,7 +69,7 @@ def conv_wgrad(dy, x0, x1, ksize, dw, dbias, pro=None, pro_relu=0, accumulate=Fa
     ks = L.query("wtpse_wgrad_ksplit", B, H, W, cin, cout)
     slab = workspace("wgrad_slab", ks * cout * cin * ksize * ksize, dy.device)
     dbs = workspace("wgrad_dbias", ks * cout, dy.device) if dbias is not None else None
-    L.call("wtpse_conv_wgrad", ptr(dy), ptr(x0), C0, ptr(x1), C1, ptr(pro), int(pro_relu), ptr(slab), ptr(dbs), ks,
+    L.call("wtpse_conv_wgrad", ptr(dy), ptr(x0), C0, ptr(x1), C1, ptr(pro0), ptr(pro1), int(pro_relu), ptr(slab), ptr(dbs), ks,
            ptr(dw), ptr(dbias), int(accumulate), B, H, W, cout, ksize, stream_ptr())
 
 
