@@ -182,13 +182,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("WTPSE_DIST_BACKEND", "nccl")     # "gloo": rehearsal of the N>1 path on a 1-GPU box
+    if backend == "nccl":
+        assert local_rank < ndev, "rank %d has no GPU (%d visible)" % (local_rank, ndev)
+    dev = torch.device("cuda", local_rank % ndev)
+    torch.cuda.set_device(dev)
     dp = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
         from wtpse_hip.dp import DataParallel
         dp = DataParallel(world, rank, dev, bn_sync=bool(args.bn_sync))
 

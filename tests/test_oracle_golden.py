@@ -168,6 +168,21 @@ def test_wtloss_and_mmd(golden_dir):
         close(v.grad.numpy(), g[p + "dmmd_dv"], rtol=1e-3, atol=1e-7, what=p + "dmmd")
 
 
+def test_c_restatement(golden_dir):
+    """oracle/wt_loss_ref.c (plain C, fp64, no PyTorch) against the reference fixtures and the torch oracle."""
+    from oracle import cref
+    g = load(golden_dir, "wtloss.npz")
+    for ci, (B, pb, H, white, margin, seed) in enumerate(g["cases"]):
+        B, pb, H, seed = int(B), int(pb), int(H), int(seed)
+        z = make_feature(seed, (B, 16, H, H), bool(white))
+        off, dg, dom, gram = cref.wt_loss(z.numpy(), 3, pb, float(margin))
+        p = f"c{ci}_"
+        close(off, g[p + "off"], rtol=1e-5, atol=1e-7, what=p + "off")
+        close(dg, g[p + "diag"], rtol=1e-5, atol=1e-7, what=p + "diag")
+        close(dom, g[p + "dom"], rtol=1e-3, atol=2e-7, what=p + "dom")
+        close(gram, g[p + "gram"], rtol=1e-5, atol=1e-6, what=p + "gram")
+
+
 # ---------------------------------------------------------------- a-1 / a-2 / a-3 / a-10
 @pytest.mark.parametrize("name,bi,kind", [("convd_first", 0, "d"), ("convd", 1, "d"), ("convu_first", 2, "u"), ("convu", 3, "u")])
 def test_blocks(golden_dir, name, bi, kind):
