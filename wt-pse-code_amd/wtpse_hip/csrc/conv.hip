@@ -50,8 +50,9 @@ struct PlaneStride {  // smallest S >= PE with S % 32 == 16: the four k-planes a
   static constexpr int value = ((PE - 16 + 31) / 32) * 32 + 16;
 };
 
+// __launch_bounds__(256, 3): at least 3 workgroups per CU (<= 168 registers per lane, accumulators included)
 template <int KS, int MODE, int TWL>
-__global__ __launch_bounds__(256) void conv_fwd_k(ConvArgs a) {
+__global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
   constexpr int TAPS = KS * KS, PAD = KS / 2;
   constexpr int TW = 1 << TWL, TH = 256 / TW;
   constexpr int PITCH = TW + 2 * PAD, ROWS = TH + 2 * PAD;
@@ -201,39 +202,71 @@ __global__ __launch_bounds__(256) void conv_fwd_k(ConvArgs a) {
   if (want_stats) __syncthreads();  // everyone is done with Xs/Ws before they are reused for the reduction
   float* red = smem;                // [4 waves][CB][2]
   const int C1out = a.Cout - a.Csplit;
+  // pixel offsets / validity of this lane's NT pixels (same for every channel)
+  int poff[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    int p = wave * 64 + nt * NB + (lane & (NB - 1));
+    int gy = ty * TH + (p >> TWL), gx = tx * TW + (p & (TW - 1));
+    poff[nt] = (gy < a.H && gx < a.W) ? gy * a.W + gx : -1;
+  }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
+    // per-lane statistics of this M block: index (r*2 + k), k = 0: sum, 1: sum of squares over this lane's NT pixels
+    constexpr int NSV = NACC * 2;
+    float sv[NSV];
 #pragma unroll
     for (int r = 0; r < NACC; ++r) {
       int crel = P16 ? ((lane >> 4) * 4 + r) : (mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5));
       int cout = cout0 + crel;
       bool cvalid = cout < a.Cout;
       float bias = (cvalid && a.bias) ? a.bias[cout] : 0.f;
+      float* dst = cout < a.Csplit ? a.out0 + (size_t)(b * a.Csplit + cout) * HW
+                                   : a.out1 + (size_t)(b * C1out + (cout - a.Csplit)) * HW;
+      const float* msk = a.mask ? a.mask + (size_t)(b * a.Cout + cout) * HW : nullptr;
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        int p = wave * 64 + nt * NB + (lane & (NB - 1));
-        int gy = ty * TH + (p >> TWL), gx = tx * TW + (p & (TW - 1));
         float v = acc[mt][nt][r] + bias;
         if (a.relu_out) v = fmaxf(v, 0.f);
-        if (cvalid && gy < a.H && gx < a.W) {
-          if (a.mask && !(a.mask[(size_t)(b * a.Cout + cout) * HW + gy * a.W + gx] > 0.f)) v = 0.f;
-          if (cout < a.Csplit)
-            a.out0[(size_t)(b * a.Csplit + cout) * HW + gy * a.W + gx] = v;
-          else
-            a.out1[(size_t)(b * C1out + (cout - a.Csplit)) * HW + gy * a.W + gx] = v;
+        if (cvalid && poff[nt] >= 0) {
+          if (msk && !(msk[poff[nt]] > 0.f)) v = 0.f;
+          dst[poff[nt]] = v;
           s1 += v;
           s2 += v * v;
         }
       }
-      if (want_stats) {
-        s1 = wave_xor_sum(s1, NB / 2);
-        s2 = wave_xor_sum(s2, NB / 2);
-        if ((lane & (NB - 1)) == 0) {
-          red[(wave * CB + crel) * 2 + 0] = s1;
-          red[(wave * CB + crel) * 2 + 1] = s2;
+      sv[r * 2 + 0] = s1;
+      sv[r * 2 + 1] = s2;
+    }
+    if (want_stats) {
+      // Butterfly "transpose" reduction over the NB lanes that hold one channel's pixels: at step s a lane hands its
+      // partner (lane ^ 2^s) the half of the values the partner will own and adds the half it receives, so the value
+      // count halves each step: NSV - 1 shuffles instead of NSV * log2(NB).  Afterwards the lane's one remaining value
+      // is the total of index  sum_s bit_s(lane) * (NSV >> (s+1)).
+      constexpr int LB = P16 ? 4 : 5;               // lane bits spanned by one channel's pixels
+      constexpr int HB = P16 ? 3 : 5;               // halving steps = log2(NSV): NSV = 8 | 32
+#pragma unroll
+      for (int st = 0; st < HB; ++st) {
+        const int half = NSV >> (st + 1);
+        const bool up = (lane >> st) & 1;
+#pragma unroll
+        for (int i = 0; i < NSV / 2; ++i) {
+          if (i < half) {
+            float keep = up ? sv[i + half] : sv[i];
+            float send = up ? sv[i] : sv[i + half];
+            sv[i] = keep + __shfl_xor(send, 1 << st, 64);
+          }
         }
       }
+#pragma unroll
+      for (int st = HB; st < LB; ++st) sv[0] += __shfl_xor(sv[0], 1 << st, 64);   // leftover lane bit: plain sum
+      int idx = 0;
+#pragma unroll
+      for (int st = 0; st < HB; ++st) idx += ((lane >> st) & 1) * (NSV >> (st + 1));
+      const int k = idx & 1, r = idx >> 1;
+      const int crel = P16 ? ((lane >> 4) * 4 + r) : (mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5));
+      if (((lane & (NB - 1)) >> HB) == 0) red[(wave * CB + crel) * 2 + k] = sv[0];
     }
   }
   if (want_stats) {
