@@ -107,6 +107,9 @@ int wtpse_maxpool2_bwd(const float* x, const float* pro, int relu, const float* 
 int wtpse_upsample2x_fwd(const float* x, const float* pro, int relu, float* out, int B, int C, int H, int W, void* stream);
 int wtpse_upsample2x_bwd(const float* dout, float* dx, int accumulate, int B, int C, int H, int W, void* stream);
 
+/* F.interpolate(size=(Ho,Wo), mode="bilinear"), align_corners=False: validation resize of the logits (Trainer.py:206-209). */
+int wtpse_resize_bilinear(const float* x, float* out, int B, int C, int H, int W, int Ho, int Wo, void* stream);
+
 /* ---- shape attention + fusion (algorithms.py:1126-1129,1243-1248,1342-1344) ------------------------------------- */
 /* att = sigmoid(w*z + b), fuse = coef*emb + att*emb, mask = att > 0.75.  wb: device {w, b}.  att/att_pre/mask optional. */
 int wtpse_attn_fuse_fwd(const float* z, const float* wb, const float* emb, float coef, float* att, float* att_pre,

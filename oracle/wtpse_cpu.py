@@ -400,3 +400,16 @@ def checksum(t):
     n = f.numel()
     idx = torch.linspace(0, n - 1, steps=min(32, n)).long()
     return np.concatenate([[f.sum().item(), f.abs().sum().item()], f[idx].numpy()]).astype(np.float64)
+
+
+# ----------------------------------------------------------------------------- validation front half (Trainer.py:170-209)
+def validate_predict(sd_od, sd_shape_od, sd_oc, sd_shape_oc, hp, data, label_size):
+    """predictions (OD) and predictions_oc * od_pred (OC), both resized to the label size — Trainer.py:170-209."""
+    pred, _ = wt_pse_predict(sd_od, sd_shape_od, hp, data, False)
+    od_pred = (torch.sigmoid(pred) > THRESH).float()
+    roi = (data + 1) * od_pred - 1
+    pred_oc, _ = wt_pse_predict(sd_oc, sd_shape_oc, hp, torch.stack((roi, roi), 0), True)
+    pred_oc = pred_oc * od_pred
+    pred = F.interpolate(pred, size=tuple(label_size), mode="bilinear")
+    pred_oc = F.interpolate(pred_oc, size=tuple(label_size), mode="bilinear")
+    return pred, pred_oc

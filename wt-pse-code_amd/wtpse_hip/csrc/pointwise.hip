@@ -168,6 +168,27 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_k(const float* __restrict_
   dx[i] = accumulate ? dx[i] + g : g;
 }
 
+// F.interpolate(x, size=(Ho,Wo), mode="bilinear") with align_corners=False (Trainer.py:206-209): validation resizes the
+// logits to the label size.  src = (dst + 0.5) * in/out - 0.5, clamped at 0; same expression tree as ATen.
+__global__ __launch_bounds__(256) void resize_bilinear_k(const float* __restrict__ x, float* __restrict__ out, int H, int W,
+                                                         int Ho, int Wo, float sy, float sx, long long total) {
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  int xo = (int)(i % Wo);
+  long long r = i / Wo;
+  int yo = (int)(r % Ho);
+  long long bc = r / Ho;
+  float fy = sy * (yo + 0.5f) - 0.5f, fx = sx * (xo + 0.5f) - 0.5f;
+  if (fy < 0.f) fy = 0.f;
+  if (fx < 0.f) fx = 0.f;
+  int y0 = (int)fy, x0 = (int)fx;
+  int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+  float ly = fy - (float)y0, lx = fx - (float)x0;
+  const float* src = x + (size_t)bc * H * W;
+  float v00 = src[y0 * W + x0], v01 = src[y0 * W + x1], v10 = src[y1 * W + x0], v11 = src[y1 * W + x1];
+  out[i] = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+}
+
 // ------------------------------------------------------------------------------------------------ small elementwise
 __global__ __launch_bounds__(256) void relu_mask_k(const float* __restrict__ dz, const float* __restrict__ ref,
                                                    float* __restrict__ dy, int accumulate, long long n) {
@@ -480,6 +501,13 @@ extern "C" int wtpse_upsample2x_bwd(const float* dout, float* dx, int accumulate
   WTPSE_REQUIRE(dout && dx && B > 0 && C > 0 && H > 0 && W > 0);
   long long total = (long long)B * C * H * W;
   hipLaunchKernelGGL(upsample2x_bwd_k, GRID1(total), dim3(256), 0, ST, dout, dx, accumulate, H, W, total);
+  return wtpse_status();
+}
+extern "C" int wtpse_resize_bilinear(const float* x, float* out, int B, int C, int H, int W, int Ho, int Wo, void* stream) {
+  WTPSE_REQUIRE(x && out && B > 0 && C > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0);
+  long long total = (long long)B * C * Ho * Wo;
+  hipLaunchKernelGGL(resize_bilinear_k, GRID1(total), dim3(256), 0, ST, x, out, H, W, Ho, Wo, (float)H / (float)Ho,
+                     (float)W / (float)Wo, total);
   return wtpse_status();
 }
 extern "C" int wtpse_relu_mask(const float* dz, const float* ref, float* dy, int accumulate, long long n, void* stream) {

@@ -194,6 +194,15 @@ def upsample2x_bwd(dout):
     return dx
 
 
+def resize_bilinear(x, size):
+    _chk(x, "x")
+    B, C, H, W = x.shape
+    Ho, Wo = int(size[0]), int(size[1])
+    out = torch.empty((B, C, Ho, Wo), dtype=torch.float32, device=x.device)
+    lib().call("wtpse_resize_bilinear", ptr(x), ptr(out), B, C, H, W, Ho, Wo, stream_ptr())
+    return out
+
+
 def relu_mask(dz, ref, out=None, accumulate=False):
     _chk(dz, "dz"); _chk(ref, "ref")
     if out is None:
