@@ -242,7 +242,7 @@ def main():
     if rank == 0:
         ips = world * B * args.steps / dt
         line = {
-            "metric": "training images/sec (256x256 fundus) — full WT-PSE iteration" if full else "training images/sec (256x256 fundus) — seg-net only",
+            "metric": ("training images/sec (%dx%d fundus) — " % (H, H)) + ("full WT-PSE iteration" if full else "seg-net only"),
             "value": ips, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
