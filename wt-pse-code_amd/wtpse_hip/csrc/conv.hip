@@ -51,7 +51,7 @@ struct PlaneStride {  // smallest S >= PE with S % 32 == 16: the four k-planes a
 };
 
 // __launch_bounds__(256, 3): at least 3 workgroups per CU (<= 168 registers per lane, accumulators included)
-template <int KS, int MODE, int TWL>
+template <int KS, int MODE, int TWL, bool DB>
 __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
   constexpr int TAPS = KS * KS, PAD = KS / 2;
   constexpr int TW = 1 << TWL, TH = 256 / TW;
@@ -118,25 +118,26 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
 #pragma unroll
   for (int i = 0; i < NPOS; ++i) voff[i] = gpos[i] >= 0 ? (unsigned)gpos[i] * 4u : BUF_OOB;
   const bool any_pro = a.pro0 != nullptr || a.pro1 != nullptr || a.pro_relu != 0;
-  for (int c0 = 0; c0 < a.CinP; c0 += KC) {
-    const int kc = min(KC, a.CinP - c0);
-    __syncthreads();
-    // ---- issue every global load of this chunk before the first LDS store (memory-level parallelism:
-    //      up to KC*NPOS + NW independent loads in flight per lane), then transform + store
-    // a chunk never straddles the two inputs (C0 % KC == 0 is checked on the host); channels past Cin re-read a
+  // Every global load of a chunk is issued before its first use (KC*NPOS + NW independent loads in flight per lane).
+  // DB (register double-buffering, chosen by the host for grids too small to fill the chip with several workgroups
+  // per CU): the loads of chunk k+1 are issued right after chunk k has been stashed in LDS and are in flight during
+  // chunk k's MFMAs.  With >= 3 resident workgroups per CU other workgroups already cover that latency (measured: +0 %).
+  float xv[KC][NPOS];
+  float4 wv[NW];
+  auto issue_loads = [&](int c0) {
+    // a chunk never straddles the two inputs (C0 % 16 == 0 is checked on the host); channels past Cin re-read a
     // valid plane (their packed weight rows are zero), so the unrolled load block has no per-channel conditionals
+    const int kc = min(KC, a.CinP - c0);
     const bool first = c0 < a.C0;
     const __amdgpu_buffer_rsrc_t rs = first ? rs0 : rs1;
     const int cbase = first ? c0 : c0 - a.C0;
     const int cmax = (first ? a.C0 : a.C1) - 1;
-    float xv[KC][NPOS];
 #pragma unroll
     for (int c = 0; c < KC; ++c) {
       const unsigned soff = (unsigned)min(cbase + c, cmax) * (unsigned)HW * 4u;
 #pragma unroll
       for (int i = 0; i < NPOS; ++i) xv[c][i] = buf_load(rs, voff[i], soff);
     }
-    float4 wv[NW];
     const int n4 = kc * TAPS * CB4;
 #pragma unroll
     for (int it = 0; it < NW; ++it) {
@@ -146,10 +147,16 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
       if (e4 < n4 && cout0 + j4 * 4 < a.CoutP)
         wv[it] = *reinterpret_cast<const float4*>(a.wp + (size_t)(c0 * TAPS + row) * a.CoutP + cout0 + j4 * 4);
     }
+  };
+  auto stash = [&](int c0) {
+    const int kc = min(KC, a.CinP - c0);
+    const bool first = c0 < a.C0;
     // zero padding applies AFTER the fused affine/ReLU, as in the reference graph
     if (any_pro) {
       const bool relu = first ? (a.pro_relu & 1) : (a.pro_relu & 2);
       const float* pro = first ? a.pro0 : a.pro1;
+      const int cbase = first ? c0 : c0 - a.C0;
+      const int cmax = (first ? a.C0 : a.C1) - 1;
 #pragma unroll
       for (int c = 0; c < KC; ++c) {
         const int cg = min(cbase + c, cmax);
@@ -167,12 +174,22 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
 #pragma unroll
       for (int i = 0; i < NPOS; ++i)
         if (lpos[i] >= 0) Xs[c * S + lpos[i]] = xv[c][i];
+    const int n4 = kc * TAPS * CB4;
 #pragma unroll
     for (int it = 0; it < NW; ++it) {
       const int e4 = tid + 256 * it;
       if (e4 < n4) *reinterpret_cast<float4*>(Ws + e4 * 4) = wv[it];
     }
+  };
+
+  if (DB) issue_loads(0);
+  for (int c0 = 0; c0 < a.CinP; c0 += KC) {
+    const int kc = min(KC, a.CinP - c0);
+    __syncthreads();   // the previous chunk's MFMAs are done with LDS
+    if (!DB) issue_loads(c0);
+    stash(c0);
     __syncthreads();
+    if (DB && c0 + KC < a.CinP) issue_loads(c0 + KC);
     // ---- MFMA
     const int nq = kc / KQ;
     for (int q = 0; q < nq; ++q) {
@@ -281,7 +298,7 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
   }
 }
 
-template <int KS, int MODE>
+template <int KS, int MODE, bool DB>
 static int launch_fwd(const ConvArgs& a, hipStream_t st) {
   constexpr int CB = MODE == 0 ? 16 : 32 * MODE;
   ConvArgs args = a;
@@ -291,10 +308,15 @@ static int launch_fwd(const ConvArgs& a, hipStream_t st) {
   args.tiles_y = ceil_div(a.H, TH);
   dim3 grid((unsigned)(a.B * args.tiles_x * args.tiles_y), (unsigned)ceil_div(a.CoutP, CB));
   if (narrow)
-    hipLaunchKernelGGL((conv_fwd_k<KS, MODE, 4>), grid, dim3(256), 0, st, args);
+    hipLaunchKernelGGL((conv_fwd_k<KS, MODE, 4, DB>), grid, dim3(256), 0, st, args);
   else
-    hipLaunchKernelGGL((conv_fwd_k<KS, MODE, 5>), grid, dim3(256), 0, st, args);
+    hipLaunchKernelGGL((conv_fwd_k<KS, MODE, 5, DB>), grid, dim3(256), 0, st, args);
   return wtpse_status();
+}
+
+static int fwd_tiles(int B, int H, int W) {
+  const int TW = W <= 16 ? 16 : 32, TH = 256 / TW;
+  return B * ceil_div(W, TW) * ceil_div(H, TH);
 }
 
 extern "C" int wtpse_conv_stats_blocks(int B, int H, int W) {
@@ -320,15 +342,23 @@ extern "C" int wtpse_conv_fwd(const float* in0, int C0, const float* in1, int C1
   a.Cout = Cout; a.CoutP = (Cout + 15) & ~15; a.Csplit = Csplit; a.pro_relu = pro_relu; a.relu_out = relu_out;
   a.tiles_x = a.tiles_y = 0;
   hipStream_t st = (hipStream_t)stream;
-  const int mode = Cout <= 16 ? 0 : (Cout % 64 == 0 ? 2 : 1);  // ragged channel counts run on the 32-wide path
+  int mode = Cout <= 16 ? 0 : (Cout % 64 == 0 ? 2 : 1);  // ragged channel counts run on the 32-wide path
+  // Grids that cannot give every CU ~3 workgroups (the 16x16 / 32x32 levels): halve the cout block to double the
+  // workgroup count, and overlap each workgroup's own loads with its MFMAs (register double-buffering)
+  const int tiles = fwd_tiles(B, H, W);
+  if (mode == 2 && tiles * (a.CoutP / 64) < 512) mode = 1;
+  const int cb = mode == 0 ? 16 : 32 * mode;
+  const bool db = tiles * ceil_div(a.CoutP, cb) < 768 && a.CinP > (mode == 0 ? 16 : 8);
+#define FWD(KS, M) (db ? launch_fwd<KS, M, true>(a, st) : launch_fwd<KS, M, false>(a, st))
   if (ksize == 3) {
-    if (mode == 0) return launch_fwd<3, 0>(a, st);
-    if (mode == 1) return launch_fwd<3, 1>(a, st);
-    return launch_fwd<3, 2>(a, st);
+    if (mode == 0) return FWD(3, 0);
+    if (mode == 1) return FWD(3, 1);
+    return FWD(3, 2);
   }
-  if (mode == 0) return launch_fwd<1, 0>(a, st);
-  if (mode == 1) return launch_fwd<1, 1>(a, st);
-  return launch_fwd<1, 2>(a, st);
+  if (mode == 0) return FWD(1, 0);
+  if (mode == 1) return FWD(1, 1);
+  return FWD(1, 2);
+#undef FWD
 }
 
 // ------------------------------------------------------------------------------------------------
