@@ -51,6 +51,14 @@ class _Lib:
             raise WtpseError(
                 "libwtpse_hip.so is missing (%s). Build it with `python -c 'import __graft_entry__ as g; g.build()'`; "
                 "the WT-PSE MI355X path has no CPU fallback." % LIB_PATH)
+        # When a GPU is present, let torch create its HIP context first: loading a HIP code object into a process
+        # whose runtime has not been initialised yet left the first launch with hipErrorNoDevice (100) on the GPU box.
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except ImportError:
+            pass
         self._dll = ctypes.CDLL(LIB_PATH)
         self.protos = parse_header()
         for name, argtypes in self.protos.items():
