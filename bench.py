@@ -72,25 +72,29 @@ def time_kernel(fn, reps=20):
 
 
 def kernel_rooflines(B, H, dev):
-    """Live HIP-event timings of the two kernels BASELINE.json names a roofline for, at the benchmark's own shapes:
-    the FLOP-heaviest conv launch (up4.conv3: 3x3, 32->32 @ HxH; 1208 MFLOP/img at 256^2 — Appendix B) against the
-    fp32 MFMA peak, and the WT-loss Gram kernel (compute_whitening_loss forward, 16*H*W*4 bytes/img) against HBM."""
+    """Live HIP-event timings of the kernels BASELINE.json names a roofline for, at the benchmark's own shapes:
+    the dominant kernel of a step — conv_fwd_k<3,2,5> (forward + data-gradient of the >= 64-channel 3x3 layers, 23 % of
+    a step in profiles/r01_bench_b32_kernel_stats.csv) on one of its FLOP-heaviest launches, up3.conv3's 3x3 64->64 at
+    half resolution (1208 MFLOP/img — SURVEY.md Appendix B) — against the fp32 MFMA peak; and the WT-loss Gram kernels
+    (compute_whitening_loss forward / backward, 16*H*W*4 bytes/img/pass) against HBM."""
     from wtpse_hip import ops
     out = {}
-    x = torch.randn(B, 32, H, H, device=dev)
-    w = torch.randn(32, 32, 3, 3, device=dev) * 0.05
-    packed = torch.empty(32 * 9 * 32 * 2, device=dev)
-    desc = torch.tensor([0, 32, 32, 9, 0, 32 * 9 * 32, 0, 0], dtype=torch.int32, device=dev)
+    C, Hc = 64, H // 2
+    x = torch.randn(B, C, Hc, Hc, device=dev)
+    w = torch.randn(C, C, 3, 3, device=dev) * 0.05
+    packed = torch.empty(C * 9 * C * 2, device=dev)
+    desc = torch.tensor([0, C, C, 9, 0, C * 9 * C, 0, 0], dtype=torch.int32, device=dev)
     ops.lib().call("wtpse_pack_conv_weights", w.data_ptr(), desc.data_ptr(), 1, packed.data_ptr(), ops.stream_ptr())
-    y = torch.empty(B, 32, H, H, device=dev)
-    bias = torch.zeros(32, device=dev)
+    y = torch.empty(B, C, Hc, Hc, device=dev)
+    bias = torch.zeros(C, device=dev)
+    stats = torch.empty(ops.lib().query("wtpse_conv_stats_blocks", B, Hc, Hc) * C * 2, device=dev)
 
-    def conv():
-        ops.lib().call("wtpse_conv_fwd", x.data_ptr(), 32, 0, 0, packed.data_ptr(), bias.data_ptr(), 0, 0, 0, y.data_ptr(), 0, 32,
-                       0, B, H, H, 32, 3, 0, 0, ops.stream_ptr())
+    def conv():   # as the training step launches it: bias + BatchNorm (sum, sum^2) partials in the epilogue
+        ops.lib().call("wtpse_conv_fwd", x.data_ptr(), C, 0, 0, packed.data_ptr(), bias.data_ptr(), 0, 0, 0, y.data_ptr(), 0, C,
+                       stats.data_ptr(), B, Hc, Hc, C, 3, 0, 0, ops.stream_ptr())
     ms = time_kernel(conv)
-    flops = 2.0 * 32 * 32 * 9 * H * H * B
-    out["conv"] = {"kernel": "conv_fwd_k<3,1,5> 32->32 3x3 @%dx%d B=%d" % (H, H, B), "ms": ms,
+    flops = 2.0 * C * C * 9 * Hc * Hc * B
+    out["conv"] = {"kernel": "conv_fwd_k<3,2,5> 64->64 3x3 @%dx%d B=%d (+bias, BN partials)" % (Hc, Hc, B), "ms": ms,
                    "tflops": flops / ms / 1e9, "flop_per_launch": flops}
     z = torch.randn(B, 16, H, H, device=dev)
     L = ops.lib()
