@@ -30,7 +30,7 @@ int wtpse_pack_conv_weights(const float* params, const int* desc, int n_desc, fl
 
 /* out = conv(cat(in0, in1)) [+ bias] [ReLU].  in1 may be NULL (C1 = 0): torch.cat (algorithms.py:955,1018) is virtual.
  * pro0 / pro1: [C0][2] / [C1][2] (scale, shift) for in0 / in1, or NULL; pro_relu bit0 / bit1: ReLU on in0 / in1 after it.
- * Output channels [0, Csplit) go to out0, the rest to out1 (Csplit == Cout, out1 NULL: no split).
+ * Output channels [0, Csplit) go to out0, the rest to out1 (Csplit == Cout, out1 NULL: no split; otherwise Csplit % 16 == 0).
  * stats: NULL or [wtpse_conv_stats_blocks(B,H,W)][Cout][2] per-workgroup (sum, sum^2) of the output (train-mode
  * BatchNorm statistics, algorithms.py:883-889); not combinable with relu_out.
  * mask_ref: NULL or [B][Cout][H][W]: out = mask_ref > 0 ? value : 0 (the ReLU backward of the layer below, fused into

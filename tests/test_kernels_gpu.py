@@ -129,6 +129,22 @@ def test_conv_dgrad_wgrad(case):
     close(dw, 2 * w.grad, rtol=2e-4, atol=4e-5 * max(scale, 1.0), what="wgrad accumulate")
 
 
+@pytest.mark.parametrize("case", [(2, 32, 8, 16, 32, 1), (2, 8, 32, 17, 35, 1), (2, 16, 16, 20, 40, 3), (1, 64, 40, 8, 8, 3),
+                                  (2, 32, 128, 4, 4, 1)])
+def test_conv_dgrad_relu_mask(case):
+    """mask_ref: the ReLU backward of the tensor the data gradient flows into rides in the epilogue (heads, DeepWT)."""
+    o = ops()
+    B, Co, Ci, H, W, k = case            # forward conv Ci -> Co; the data gradient has Ci output channels
+    w = rnd(Co, Ci, k, k, seed=21, scale=0.2)
+    dy = rnd(B, Co, H, W, seed=22)
+    ref_act = rnd(B, Ci, H, W, seed=23)  # the (pre- or post-ReLU) activation whose sign gates the gradient
+    ref_act[0, 0, 0, :4] = 0.0           # exactly zero counts as "not positive"
+    want = F.conv_transpose2d(dy, w, padding=k // 2) * (ref_act > 0).float()
+    packed, _, wd = pack(w)
+    d0, _, _ = o.conv_fwd(dy.to(DEV), None, packed.data_ptr() + 4 * wd, None, Ci, k, mask_ref=ref_act.to(DEV))
+    close(d0, want, what="masked dgrad")
+
+
 @pytest.mark.parametrize("shape,relu", [((4, 16, 16, 32), True), ((3, 32, 9, 7), False), ((2, 64, 4, 4), True)])
 def test_batchnorm_train(shape, relu):
     o = ops()

@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Phase timeline of the forward conv kernel (dominant shape 64->64 3x3 @128x128, B=32) from in-kernel s_memtime stamps.
+
+Builds csrc/conv.hip with -DWTPSE_STAMPS into tools/probe/_build/ (git-ignored; the product library never carries the
+stamps), runs the shape once and prints, for the workgroups that shared a few CUs, when each phase of each input-channel
+chunk started.  Used to find where the matrix pipe idles ("where the conv kernel's time goes").
+    gpurun -- python tools/probe/conv_stamps.py [Cin Cout H B]
+"""
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "wt-pse-code_amd", "wtpse_hip", "csrc")
+OUT = os.path.join(HERE, "_build", "libconv_stamps.so")
+
+
+def build():
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DWTPSE_STAMPS",
+                           os.path.join(CSRC, "conv.hip"), "-o", OUT])
+
+
+def main():
+    cin, cout, hw, B = [int(v) for v in (sys.argv[1:5] + ["64", "64", "128", "32"][len(sys.argv) - 1:])]
+    if not os.path.isfile(OUT):
+        build()
+    torch.cuda.init()
+    dll = ctypes.CDLL(OUT)
+    dev = torch.device("cuda:0")
+    x = torch.randn(B, cin, hw, hw, device=dev)
+    w = torch.randn(cout, cin, 3, 3, device=dev) * 0.05
+    bias = torch.randn(cout, device=dev)
+    cinp, coutp = (cin + 3) & ~3, (cout + 15) & ~15
+    packed = torch.zeros(cinp * 9 * coutp + 64, device=dev)
+    desc = torch.tensor([0, cout, cin, 9, 0, -1, 0, 0], dtype=torch.int32, device=dev)
+    vp = ctypes.c_void_p
+    assert dll.wtpse_pack_conv_weights(vp(w.data_ptr()), vp(desc.data_ptr()), 1, vp(packed.data_ptr()), None) == 0
+    y = torch.empty(B, cout, hw, hw, device=dev)
+    nblk = dll.wtpse_conv_stats_blocks(B, hw, hw)
+    stats = torch.zeros(nblk * cout * 2, device=dev)
+    ngrid = nblk * ((coutp + 31) // 32)           # upper bound on workgroups (32-cout blocks)
+    stamps = torch.zeros(ngrid * 64, dtype=torch.int64, device=dev)
+
+    def run():
+        return dll.wtpse_conv_fwd(vp(x.data_ptr()), cin, None, 0, vp(packed.data_ptr()), vp(bias.data_ptr()), None, None, 0,
+                                  vp(y.data_ptr()), None, cout, vp(stats.data_ptr()), B, hw, hw, cout, 3, 0, None, None)
+    for _ in range(3):
+        assert run() == 0
+    torch.cuda.synchronize()
+    assert dll.wtpse_probe_set_stamps(vp(stamps.data_ptr())) == 0
+    assert run() == 0
+    torch.cuda.synchronize()
+    st = stamps.cpu().numpy().reshape(-1, 64)
+    st = st[st[:, 0] != 0]
+    hw_id = st[:, 1] & 0xFFFFFFFF
+    xcc = (st[:, 1] >> 32) & 0xF
+    cu = (hw_id >> 8) & 0xF
+    sh = (hw_id >> 12) & 0x1
+    se = (hw_id >> 13) & 0x7
+    key = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+    t0 = st[:, 0].min()
+    print("workgroups %d, distinct CUs %d, kernel span %d cycles" % (len(st), len(np.unique(key)), st[:, 61].max() - t0))
+    nch = (cinp + 7) // 8
+    dur = {"load+stash": [], "barrier": [], "mfma": [], "epilogue": [], "wg": []}
+    for r in st:
+        for c in range(nch):
+            dur["load+stash"].append(r[3 + 4 * c] - r[2 + 4 * c])
+            dur["barrier"].append(r[4 + 4 * c] - r[3 + 4 * c])
+            dur["mfma"].append(r[5 + 4 * c] - r[4 + 4 * c])
+        dur["epilogue"].append(r[61] - r[60])
+        dur["wg"].append(r[61] - r[0])
+    for k, v in dur.items():
+        v = np.array(v)
+        print("%-11s mean %7.0f  p10 %7.0f  p50 %7.0f  p90 %7.0f cycles" % (k, v.mean(), *np.percentile(v, [10, 50, 90])))
+    # timeline of one CU per XCD 0/1
+    for kk in np.unique(key)[:2]:
+        rows = st[key == kk]
+        rows = rows[np.argsort(rows[:, 0])]
+        print("CU key %d: %d workgroups" % (kk, len(rows)))
+        for r in rows:
+            segs = " ".join("%d:%d/%d/%d" % (c, r[3 + 4 * c] - r[2 + 4 * c], r[4 + 4 * c] - r[3 + 4 * c], r[5 + 4 * c] - r[4 + 4 * c])
+                            for c in range(nch))
+            print("  start %7d end %7d simd %d | chunk:load+stash/barrier/mfma %s | epi %d" %
+                  (r[0] - t0, r[61] - t0, (r[1] >> 4) & 3, segs, r[61] - r[60]))
+
+
+if __name__ == "__main__":
+    main()

@@ -41,12 +41,16 @@ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // Raw buffer resource (stride 0) over `bytes` bytes at `p`: loads whose per-lane byte offset is >= bytes return 0
 // in hardware, so zero padding / ragged tiles need no per-element branch; the per-channel plane offset rides in
-// the scalar `soffset` operand (measured on gfx950 with tools/probe/bufload.hip: voffset + soffset is what is range
-// checked, flags word 0x00020000).  BUF_OOB marks a lane as out of range.
+// the scalar `soffset` operand (measured on gfx950 with tools/probe/bufload.hip: a lane is out of range when
+// voffset >= num_records - soffset; keep soffset <= num_records; flags word 0x00020000).  BUF_OOB marks a lane as out of range.
 #define BUF_OOB 0x80000000u
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
 }
 __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned voffset, unsigned soffset) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voffset, (int)soffset, 0));  // b32 = raw bits
+}
+// Out-of-range lanes (voffset = BUF_OOB) are dropped by the hardware: predicated stores without an exec-mask branch.
+__device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t r, unsigned voffset, unsigned soffset, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, (int)voffset, (int)soffset, 0);
 }

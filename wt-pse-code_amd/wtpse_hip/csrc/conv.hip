@@ -40,6 +40,18 @@ struct ConvArgs {
   int tiles_x, tiles_y;
 };
 
+// Phase stamps for tools/probe/conv_stamps.py (never compiled into libwtpse_hip.so): thread 0 of every workgroup
+// records s_memtime at the phase boundaries of the forward kernel.
+#ifdef WTPSE_STAMPS
+__device__ unsigned long long* g_stamps = nullptr;
+extern "C" int wtpse_probe_set_stamps(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &p, sizeof(p)); }
+#define STAMP(i) do { if (g_stamps && threadIdx.x == 0) g_stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 64 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define STAMPV(i, v) do { if (g_stamps && threadIdx.x == 0) g_stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 64 + (i)] = (v); } while (0)
+#else
+#define STAMP(i)
+#define STAMPV(i, v)
+#endif
+
 template <bool P16> struct AccT { typedef f32x16 type; };
 template <> struct AccT<true> { typedef f32x4 type; };
 __device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) { return mfma16(a, b, c); }
@@ -51,7 +63,9 @@ struct PlaneStride {  // smallest S >= PE with S % 32 == 16: the four k-planes a
 };
 
 // __launch_bounds__(256, 3): at least 3 workgroups per CU (<= 168 registers per lane, accumulators included)
-template <int KS, int MODE, int TWL, bool DB>
+// MASK is a template parameter, not a run-time test of a.mask: s_waitcnt operands are static, so the waits the mask
+// loads need would also be executed (and drain earlier stores) by launches without a mask.
+template <int KS, int MODE, int TWL, bool DB, bool MASK>
 __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
   constexpr int TAPS = KS * KS, PAD = KS / 2;
   constexpr int TW = 1 << TWL, TH = 256 / TW;
@@ -69,7 +83,9 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
   constexpr int NACC = P16 ? 4 : 16;
   constexpr int XS_SZ = KC * S, WS_SZ = KC * TAPS * CB;
   constexpr int RED_SZ = 4 * CB * 2;
-  __shared__ __attribute__((aligned(16))) float smem[(XS_SZ + WS_SZ) > RED_SZ ? (XS_SZ + WS_SZ) : RED_SZ];
+  constexpr int MAIN_SZ = (XS_SZ + WS_SZ) > RED_SZ ? (XS_SZ + WS_SZ) : RED_SZ;
+  __shared__ __attribute__((aligned(16))) float smem[MAIN_SZ + CB];
+  float* bias_s = smem + MAIN_SZ;   // this block's biases (written here, visible after the first barrier of the chunk loop)
   float* Xs = smem;
   float* Ws = smem + XS_SZ;
 
@@ -81,6 +97,7 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
   const int b = bx / a.tiles_y;
   const int cout0 = blockIdx.y * CB;
   const int HW = a.H * a.W;
+  if (tid < CB) bias_s[tid] = (a.bias && cout0 + tid < a.Cout) ? a.bias[cout0 + tid] : 0.f;
 
   int off[NT];
 #pragma unroll
@@ -182,13 +199,18 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
     }
   };
 
+  STAMP(0);
+  STAMPV(1, (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32));
   if (DB) issue_loads(0);
   for (int c0 = 0; c0 < a.CinP; c0 += KC) {
     const int kc = min(KC, a.CinP - c0);
     __syncthreads();   // the previous chunk's MFMAs are done with LDS
+    STAMP(2 + 4 * (c0 / KC));
     if (!DB) issue_loads(c0);
     stash(c0);
+    STAMP(3 + 4 * (c0 / KC));
     __syncthreads();
+    STAMP(4 + 4 * (c0 / KC));
     if (DB && c0 + KC < a.CinP) issue_loads(c0 + KC);
     // ---- MFMA
     const int nq = kc / KQ;
@@ -212,6 +234,22 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mfma(av[t][mt], bv[t][nt], acc[mt][nt]);
     }
+    STAMP(5 + 4 * (c0 / KC));
+  }
+  STAMP(60);
+  if (a.bias) {
+    float bz[MT][NACC];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < NACC; ++r)
+        bz[mt][r] = bias_s[P16 ? ((lane >> 4) * 4 + r) : (mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5))];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < NACC; ++r)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt][r] += bz[mt][r];
   }
 
   // ---- epilogue: bias, ReLU, store (pixels on lanes -> contiguous runs per channel plane), BN partial statistics
@@ -227,28 +265,57 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
     int gy = ty * TH + (p >> TWL), gx = tx * TW + (p & (TW - 1));
     poff[nt] = (gy < a.H && gx < a.W) ? gy * a.W + gx : -1;
   }
+  // vmcnt counts loads and stores in one in-order queue on gfx9 and s_waitcnt operands are static.  A load issued
+  // after a store cannot be waited on without waiting for that store's write acknowledgement (1-2 us), and around a
+  // store inside an exec-mask branch the compiler must assume the store was skipped, so every wait behind it drains
+  // the queue (measured with tools/probe/conv_stamps.py: the epilogue took 60k cycles, 21 % of a workgroup's life).
+  // Hence: the biases come from LDS (added after the sum, as the reference does), the ReLU-mask loads of an M block are issued before that
+  // block's first store, and loads/stores are branch-free buffer operations: the lane's pixel (and the +4 channels of
+  // the upper half-wave) sit in a per-lane voffset computed once, the register's first channel in the scalar soffset,
+  // and lanes outside the image (BUF_OOB) or channels past the end of the tensor are dropped by the range check
+  // (voffset >= num_records - soffset).
+  const __amdgpu_buffer_rsrc_t rs_o0 = make_rsrc(a.out0 + (size_t)b * a.Csplit * HW, (unsigned)a.Csplit * HW * 4u);
+  const __amdgpu_buffer_rsrc_t rs_o1 = a.out1 ? make_rsrc(a.out1 + (size_t)b * C1out * HW, (unsigned)C1out * HW * 4u) : rs_o0;
+  const __amdgpu_buffer_rsrc_t rs_m = MASK ? make_rsrc(a.mask + (size_t)b * a.Cout * HW, (unsigned)a.Cout * HW * 4u) : rs_o0;
+  const int clane = P16 ? (lane >> 4) * 4 : (lane >> 5) * 4;   // channel offset of this lane within a register's group
+  unsigned pvo[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) pvo[nt] = poff[nt] >= 0 ? (unsigned)(clane * HW + poff[nt]) * 4u : BUF_OOB;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
+    float mk[NACC][NT];
+    if (MASK) {
+#pragma unroll
+      for (int r = 0; r < NACC; ++r) {
+        const int cbase = cout0 + (P16 ? r : (mt * 32 + (r & 3) + 8 * (r >> 2)));
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          mk[r][nt] = buf_load(rs_m, pvo[nt], (unsigned)min(cbase, a.Cout) * (unsigned)HW * 4u);
+      }
+    }
     // per-lane statistics of this M block: index (r*2 + k), k = 0: sum, 1: sum of squares over this lane's NT pixels
     constexpr int NSV = NACC * 2;
     float sv[NSV];
 #pragma unroll
     for (int r = 0; r < NACC; ++r) {
-      int crel = P16 ? ((lane >> 4) * 4 + r) : (mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5));
-      int cout = cout0 + crel;
-      bool cvalid = cout < a.Cout;
-      float bias = (cvalid && a.bias) ? a.bias[cout] : 0.f;
-      float* dst = cout < a.Csplit ? a.out0 + (size_t)(b * a.Csplit + cout) * HW
-                                   : a.out1 + (size_t)(b * C1out + (cout - a.Csplit)) * HW;
-      const float* msk = a.mask ? a.mask + (size_t)(b * a.Cout + cout) * HW : nullptr;
+      // the channels one register holds across the wave lie in one aligned group of 8 (16 on the 16-wide path) and
+      // Csplit is a multiple of 16, so the choice of output tensor is wave-uniform
+      const int cbase = cout0 + (P16 ? r : (mt * 32 + (r & 3) + 8 * (r >> 2)));
+      const bool cvalid = cbase + clane < a.Cout;
+      const bool second = a.out1 != nullptr && cbase >= a.Csplit;
+      const __amdgpu_buffer_rsrc_t rs_o = second ? rs_o1 : rs_o0;
+      // min(): soffset stays <= num_records for the zero-padded channels past Cout, so num_records - soffset cannot wrap
+      const unsigned soff = (unsigned)(second ? min(cbase, a.Cout) - a.Csplit : min(cbase, a.Csplit)) * (unsigned)HW * 4u;
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        float v = acc[mt][nt][r] + bias;
+        float v = acc[mt][nt][r];
         if (a.relu_out) v = fmaxf(v, 0.f);
-        if (cvalid && poff[nt] >= 0) {
-          if (msk && !(msk[poff[nt]] > 0.f)) v = 0.f;
-          dst[poff[nt]] = v;
+        if (MASK && !(mk[r][nt] > 0.f)) v = 0.f;
+        buf_store(rs_o, pvo[nt], soff, v);
+        if (want_stats) {
+#pragma clang fp contract(off)   // square, then add: the partials must not depend on which pairs the compiler fuses
+          v = (cvalid && poff[nt] >= 0) ? v : 0.f;
           s1 += v;
           s2 += v * v;
         }
@@ -296,9 +363,10 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
       }
     }
   }
+  STAMP(61);
 }
 
-template <int KS, int MODE, bool DB>
+template <int KS, int MODE, bool DB, bool MASK>
 static int launch_fwd(const ConvArgs& a, hipStream_t st) {
   constexpr int CB = MODE == 0 ? 16 : 32 * MODE;
   ConvArgs args = a;
@@ -308,9 +376,9 @@ static int launch_fwd(const ConvArgs& a, hipStream_t st) {
   args.tiles_y = ceil_div(a.H, TH);
   dim3 grid((unsigned)(a.B * args.tiles_x * args.tiles_y), (unsigned)ceil_div(a.CoutP, CB));
   if (narrow)
-    hipLaunchKernelGGL((conv_fwd_k<KS, MODE, 4, DB>), grid, dim3(256), 0, st, args);
+    hipLaunchKernelGGL((conv_fwd_k<KS, MODE, 4, DB, MASK>), grid, dim3(256), 0, st, args);
   else
-    hipLaunchKernelGGL((conv_fwd_k<KS, MODE, 5, DB>), grid, dim3(256), 0, st, args);
+    hipLaunchKernelGGL((conv_fwd_k<KS, MODE, 5, DB, MASK>), grid, dim3(256), 0, st, args);
   return wtpse_status();
 }
 
@@ -333,6 +401,7 @@ extern "C" int wtpse_conv_fwd(const float* in0, int C0, const float* in1, int C1
   WTPSE_REQUIRE(ksize == 1 || ksize == 3);
   WTPSE_REQUIRE((C1 == 0) == (in1 == nullptr));
   WTPSE_REQUIRE(Csplit > 0 && Csplit <= Cout && ((Csplit == Cout) == (out1 == nullptr)));
+  WTPSE_REQUIRE(Csplit == Cout || Csplit % 16 == 0);   // the epilogue picks the output tensor per register, not per lane
   WTPSE_REQUIRE(!(stats && relu_out));
   WTPSE_REQUIRE(!(mask_ref && out1));
   WTPSE_REQUIRE(C1 == 0 || C0 % 16 == 0);   // a channel chunk must not straddle the two inputs
@@ -349,7 +418,8 @@ extern "C" int wtpse_conv_fwd(const float* in0, int C0, const float* in1, int C1
   if (mode == 2 && tiles * (a.CoutP / 64) < 512) mode = 1;
   const int cb = mode == 0 ? 16 : 32 * mode;
   const bool db = tiles * ceil_div(a.CoutP, cb) < 768 && a.CinP > (mode == 0 ? 16 : 8);
-#define FWD(KS, M) (db ? launch_fwd<KS, M, true>(a, st) : launch_fwd<KS, M, false>(a, st))
+#define FWD(KS, M) (mask_ref ? (db ? launch_fwd<KS, M, true, true>(a, st) : launch_fwd<KS, M, false, true>(a, st)) \
+                         : (db ? launch_fwd<KS, M, true, false>(a, st) : launch_fwd<KS, M, false, false>(a, st)))
   if (ksize == 3) {
     if (mode == 0) return FWD(3, 0);
     if (mode == 1) return FWD(3, 1);
