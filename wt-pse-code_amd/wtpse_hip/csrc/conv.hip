@@ -512,8 +512,18 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_k(WgradArgs a) {
   float* Xs = smem + MB * SA;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int group = blockIdx.x % a.ngroups;
-  const int cout0 = (blockIdx.x / a.ngroups) * MB;
+  // Workgroups are dealt to the 8 XCDs round-robin by linear id.  The gridDim.x workgroups of one k-slice read the same
+  // dY / X tiles, so (when the slice count is a multiple of 8) slice ky is given to XCD ky % 8 as a whole: its tiles
+  // are then fetched into that XCD's L2 once instead of once per XCD the slice was spread over.
+  int bx = blockIdx.x, ky = blockIdx.y;
+  if ((gridDim.y & 7) == 0) {
+    const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const int k = lin >> 3;
+    ky = (lin & 7) + 8 * (k / (int)gridDim.x);
+    bx = k % (int)gridDim.x;
+  }
+  const int group = bx % a.ngroups;
+  const int cout0 = (bx / a.ngroups) * MB;
   const int cin0 = group * a.cg;
   const int HW = a.H * a.W;
   const int j = lane & (MB - 1), kl = lane / MB;
@@ -535,11 +545,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_k(WgradArgs a) {
   double db = 0.0;
 
   const int tiles_per_img = a.tiles_x * a.tiles_y;
-  for (int tile = blockIdx.y; tile < a.ntiles; tile += gridDim.y) {
+  STAMP(0);
+  STAMPV(1, (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32));
+  int it = 0;
+  for (int tile = ky; tile < a.ntiles; tile += gridDim.y, ++it) {
     const int b = tile / tiles_per_img;
     const int trem = tile - b * tiles_per_img;
     const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
     __syncthreads();
+    if (it < 8) STAMP(2 + 7 * it);
     // ---- tile loads, batched: every global load of a phase is issued before the first LDS store
     // dY tile [MB couts][256 pixels] (this thread: pixel `tid` of every channel), zero outside the image / beyond Cout
     const int gyp = ty * TH + (tid >> TWL), gxp = tx * TW + (tid & (TW - 1));
@@ -582,6 +596,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_k(WgradArgs a) {
 #pragma unroll
         for (int i = 0; i < NPOS; ++i) xv[c][i] = buf_load(rsx, voff[i], soff);
       }
+      if (it < 8) STAMP(3 + 7 * it + 2 * g);
       if (any_pro) {
         const bool relu = xfirst ? (a.pro_relu & 1) : (a.pro_relu & 2);
         const float* pro = xfirst ? a.pro0 : a.pro1;
@@ -604,8 +619,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_k(WgradArgs a) {
 #pragma unroll
         for (int i = 0; i < NPOS; ++i)
           if (lpos[i] >= 0) Xs[(g * 16 + c) * SX + lpos[i]] = xv[c][i];
+      if (it < 8) STAMP(4 + 7 * it + 2 * g);
     }
     __syncthreads();
+    if (it < 8) STAMP(7 + 7 * it);
     if (a.dbias && group == 0) {  // bias gradient: plain per-channel sum of the dY tile
       int c = tid / (256 / MB), part = tid % (256 / MB);
       constexpr int PER = MB;     // 256 pixels / (256/MB) threads
@@ -613,22 +630,46 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_k(WgradArgs a) {
       for (int i = 0; i < PER; ++i) s += Ys[c * SA + part * PER + i];
       db += s;
     }
+    // MFMA loop, software pipelined by hand: the LDS reads of step s+1 are in flight while the MFMAs of step s issue
+    // back to back (left to the compiler, every MFMA sat behind its own ds_read + s_waitcnt: 172 cycles per MFMA
+    // instead of 64, measured with tools/probe/conv_stamps.py wgrad).  sched_barrier keeps the two groups apart.
     constexpr int STEPS = 64 / KQ;
-#pragma unroll 4
-    for (int s = 0; s < STEPS; ++s) {
+    const float* yrow = Ys + j * SA + wave * 64 + kl;
+    auto lds_step = [&](int s, float& av, float (&bv)[MAXNB]) {
       const int pbase = wave * 64 + s * KQ;
       const int rowbase = (pbase >> TWL) * PITCH + (pbase & (TW - 1)) + kl;
-      const float av = Ys[j * SA + pbase + kl];
-      float bv[MAXNB];
+      av = yrow[s * KQ];
+      if constexpr (KS == 3 && NBLK == 9) {
+        // 9 blocks <=> cg == MB: block nb is tap nb of channel j, a compile-time offset from one per-lane address
+        const float* xb = Xs + j * SX + rowbase;
 #pragma unroll
-      for (int nb = 0; nb < MAXNB; ++nb) bv[nb] = Xs[boff[nb] + rowbase];
+        for (int nb = 0; nb < MAXNB; ++nb) bv[nb] = xb[(nb / 3) * PITCH + (nb % 3)];
+      } else {
 #pragma unroll
-      for (int nb = 0; nb < MAXNB; ++nb) acc[nb] = mfma(av, bv[nb], acc[nb]);
+        for (int nb = 0; nb < MAXNB; ++nb) bv[nb] = Xs[boff[nb] + rowbase];
+      }
+    };
+    float a0, a1, b0[MAXNB], b1[MAXNB];
+    lds_step(0, a0, b0);
+    for (int s = 0; s < STEPS; s += 2) {
+      lds_step(s + 1, a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int nb = 0; nb < MAXNB; ++nb) acc[nb] = mfma(a0, b0[nb], acc[nb]);
+      __builtin_amdgcn_sched_barrier(0);
+      lds_step(s + 2 < STEPS ? s + 2 : s, a0, b0);   // the last iteration re-reads a valid step; the values are unused
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int nb = 0; nb < MAXNB; ++nb) acc[nb] = mfma(a1, b1[nb], acc[nb]);
+      __builtin_amdgcn_sched_barrier(0);
     }
+    if (it < 8) STAMP(8 + 7 * it);
   }
+  STAMP(60);
+  STAMPV(62, (unsigned long long)it);
 
   // ---- cross-wave reduction through LDS, then slab[ky][co][ci][t]
-  float* slab = a.slab + (size_t)blockIdx.y * a.Cout * a.Cin * TAPS;
+  float* slab = a.slab + (size_t)ky * a.Cout * a.Cin * TAPS;
   float* red = smem;
   if constexpr (!P32) {
     __syncthreads();
@@ -673,8 +714,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_k(WgradArgs a) {
     constexpr int TPC = 256 / MB;  // threads per channel: 16 (P16) or 8 (P32), consecutive lanes
     for (int m = 1; m <= TPC / 2; m <<= 1) db += __shfl_xor(db, m, 64);
     int c = tid / TPC;
-    if ((tid % TPC) == 0 && cout0 + c < a.Cout) a.dbias[(size_t)blockIdx.y * a.Cout + cout0 + c] = (float)db;
+    if ((tid % TPC) == 0 && cout0 + c < a.Cout) a.dbias[(size_t)ky * a.Cout + cout0 + c] = (float)db;
   }
+  STAMP(61);
 }
 
 // out[i] (+)= sum_k slab[k][i]: 32 outputs x 8 k-slices per workgroup, fp64 accumulation (the slabs are partial sums of
