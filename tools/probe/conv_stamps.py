@@ -95,6 +95,13 @@ def wgrad(dll, cin, cout, hw, B):
     for n, v in zip(names, cols):
         v = np.array(v)
         print("  %-20s mean %7.0f  p10 %7.0f  p50 %7.0f  p90 %7.0f" % (n, v.mean(), *np.percentile(v, [10, 50, 90])))
+    hw_id = st[:, 1] & 0xFFFFFFFF
+    key = ((((st[:, 1] >> 32) & 0xF) * 8 + ((hw_id >> 13) & 0x7)) * 2 + ((hw_id >> 12) & 0x1)) * 16 + ((hw_id >> 8) & 0xF)
+    rows = st[key == np.unique(key)[0]]
+    t0 = rows[:, 0].min()
+    print("  timeline of the workgroups on one CU (cycles from the first start; L = load phase start, M = MFMA loop start, E = MFMA loop end):")
+    for r in rows[np.argsort(rows[:, 0])]:
+        print("   wave slot %d:" % (r[1] & 0xF), " ".join("L%d M%d E%d |" % (r[2 + 7 * t] - t0, r[7 + 7 * t] - t0, r[8 + 7 * t] - t0) for t in range(min(8, int(r[62])))))
     tot = np.array([r[61] - r[0] for r in st])
     print("  workgroup life mean %.0f, epilogue mean %.0f, tiles per workgroup %d" % (tot.mean(), np.mean([r[61] - r[60] for r in st]), st[0][62]))
 

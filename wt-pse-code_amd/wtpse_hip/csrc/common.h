@@ -47,6 +47,10 @@ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
 }
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voffset, unsigned soffset) {   // 16-byte aligned
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voffset, (int)soffset, 0));
+}
 __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned voffset, unsigned soffset) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voffset, (int)soffset, 0));  // b32 = raw bits
 }

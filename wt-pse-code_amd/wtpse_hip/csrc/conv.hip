@@ -71,7 +71,11 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
   constexpr int TW = 1 << TWL, TH = 256 / TW;
   constexpr int PITCH = TW + 2 * PAD, ROWS = TH + 2 * PAD;
   constexpr int PE = PITCH * ROWS;
-  constexpr int S = PlaneStride<PE>::value;
+  // every thread stores all of its NPOS tile positions, valid or not (positions past PE land in the plane's padding):
+  // the loader has no per-element branch, which matters because beside another wave's MFMA stream each instruction of
+  // this phase costs about one MFMA slot (tools/probe/conv_stamps.py)
+  constexpr int NPOS = (PE + 255) / 256;
+  constexpr int S = PlaneStride<NPOS * 256>::value;
   constexpr bool P16 = (MODE == 0);
   constexpr int MT = P16 ? 1 : MODE;
   constexpr int MB = P16 ? 16 : 32;
@@ -81,7 +85,9 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
   constexpr int KC = P16 ? 16 : 8;
   constexpr int KQ = P16 ? 4 : 2;
   constexpr int NACC = P16 ? 4 : 16;
-  constexpr int XS_SZ = KC * S, WS_SZ = KC * TAPS * CB;
+  constexpr int CB4 = CB / 4;
+  constexpr int NW = (KC * TAPS * CB4 + 255) / 256;   // 16-byte weight loads per thread and chunk
+  constexpr int XS_SZ = KC * S, WS_SZ = NW * 1024;     // weight slab [KC*TAPS][CB], padded to whole load rounds
   constexpr int RED_SZ = 4 * CB * 2;
   constexpr int MAIN_SZ = (XS_SZ + WS_SZ) > RED_SZ ? (XS_SZ + WS_SZ) : RED_SZ;
   __shared__ __attribute__((aligned(16))) float smem[MAIN_SZ + CB];
@@ -106,16 +112,14 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
     off[nt] = (p >> TWL) * PITCH + (p & (TW - 1));
   }
 
-  // halo-tile positions owned by this thread (fixed for the whole kernel): LDS offset within a channel plane and
-  // offset within a global channel plane (-1: zero padding / outside the image)
-  constexpr int NPOS = (PE + 255) / 256;
-  int lpos[NPOS], gpos[NPOS];
+  // halo-tile positions owned by this thread (fixed for the whole kernel): position tid + 256*i of a channel plane;
+  // gpos = offset within a global channel plane (-1: zero padding / outside the image / past the tile)
+  int gpos[NPOS];
 #pragma unroll
   for (int i = 0; i < NPOS; ++i) {
     int p = tid + 256 * i;
     int r = p / PITCH, x = p - r * PITCH;
     int gy = ty * TH + r - PAD, gx = tx * TW + x - PAD;
-    lpos[i] = p < PE ? p : -1;
     gpos[i] = (p < PE && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? gy * a.W + gx : -1;
   }
 
@@ -127,24 +131,31 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < NACC; ++r) acc[mt][nt][r] = 0.f;
 
-  constexpr int CB4 = CB / 4;
-  constexpr int NW = (KC * TAPS * CB4 + 255) / 256;
   const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(a.in0 + (size_t)b * a.C0 * HW, (unsigned)a.C0 * HW * 4u);
   const __amdgpu_buffer_rsrc_t rs1 = a.in1 ? make_rsrc(a.in1 + (size_t)b * a.C1 * HW, (unsigned)a.C1 * HW * 4u) : rs0;
   unsigned voff[NPOS];
 #pragma unroll
   for (int i = 0; i < NPOS; ++i) voff[i] = gpos[i] >= 0 ? (unsigned)gpos[i] * 4u : BUF_OOB;
+  // packed weights [CinP*TAPS][CoutP]: slab row e4 / CB4, columns cout0 + 4*(e4 % CB4); rows past the last channel
+  // (ragged last chunk) and columns past CoutP are out of range and read as zero
+  const __amdgpu_buffer_rsrc_t rsw = make_rsrc(a.wp, (unsigned)a.CinP * TAPS * (unsigned)a.CoutP * 4u);
+  unsigned woff[NW];
+#pragma unroll
+  for (int it = 0; it < NW; ++it) {
+    const int e4 = tid + 256 * it;
+    const int row = e4 / CB4, j4 = e4 - row * CB4;
+    woff[it] = (row < KC * TAPS && cout0 + j4 * 4 < a.CoutP) ? (unsigned)(row * a.CoutP + cout0 + j4 * 4) * 4u : BUF_OOB;
+  }
   const bool any_pro = a.pro0 != nullptr || a.pro1 != nullptr || a.pro_relu != 0;
   // Every global load of a chunk is issued before its first use (KC*NPOS + NW independent loads in flight per lane).
   // DB (register double-buffering, chosen by the host for grids too small to fill the chip with several workgroups
   // per CU): the loads of chunk k+1 are issued right after chunk k has been stashed in LDS and are in flight during
   // chunk k's MFMAs.  With >= 3 resident workgroups per CU other workgroups already cover that latency (measured: +0 %).
   float xv[KC][NPOS];
-  float4 wv[NW];
+  f32x4 wv[NW];
   auto issue_loads = [&](int c0) {
     // a chunk never straddles the two inputs (C0 % 16 == 0 is checked on the host); channels past Cin re-read a
     // valid plane (their packed weight rows are zero), so the unrolled load block has no per-channel conditionals
-    const int kc = min(KC, a.CinP - c0);
     const bool first = c0 < a.C0;
     const __amdgpu_buffer_rsrc_t rs = first ? rs0 : rs1;
     const int cbase = first ? c0 : c0 - a.C0;
@@ -155,18 +166,10 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
 #pragma unroll
       for (int i = 0; i < NPOS; ++i) xv[c][i] = buf_load(rs, voff[i], soff);
     }
-    const int n4 = kc * TAPS * CB4;
 #pragma unroll
-    for (int it = 0; it < NW; ++it) {
-      const int e4 = tid + 256 * it;
-      const int row = e4 / CB4, j4 = e4 - row * CB4;
-      wv[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (e4 < n4 && cout0 + j4 * 4 < a.CoutP)
-        wv[it] = *reinterpret_cast<const float4*>(a.wp + (size_t)(c0 * TAPS + row) * a.CoutP + cout0 + j4 * 4);
-    }
+    for (int it = 0; it < NW; ++it) wv[it] = buf_load4(rsw, woff[it], (unsigned)(c0 * TAPS) * (unsigned)a.CoutP * 4u);
   };
   auto stash = [&](int c0) {
-    const int kc = min(KC, a.CinP - c0);
     const bool first = c0 < a.C0;
     // zero padding applies AFTER the fused affine/ReLU, as in the reference graph
     if (any_pro) {
@@ -189,14 +192,9 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
 #pragma unroll
     for (int c = 0; c < KC; ++c)
 #pragma unroll
-      for (int i = 0; i < NPOS; ++i)
-        if (lpos[i] >= 0) Xs[c * S + lpos[i]] = xv[c][i];
-    const int n4 = kc * TAPS * CB4;
+      for (int i = 0; i < NPOS; ++i) Xs[c * S + tid + 256 * i] = xv[c][i];
 #pragma unroll
-    for (int it = 0; it < NW; ++it) {
-      const int e4 = tid + 256 * it;
-      if (e4 < n4) *reinterpret_cast<float4*>(Ws + e4 * 4) = wv[it];
-    }
+    for (int it = 0; it < NW; ++it) *reinterpret_cast<f32x4*>(Ws + (tid + 256 * it) * 4) = wv[it];
   };
 
   STAMP(0);
@@ -278,9 +276,28 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
   const __amdgpu_buffer_rsrc_t rs_o1 = a.out1 ? make_rsrc(a.out1 + (size_t)b * C1out * HW, (unsigned)C1out * HW * 4u) : rs_o0;
   const __amdgpu_buffer_rsrc_t rs_m = MASK ? make_rsrc(a.mask + (size_t)b * a.Cout * HW, (unsigned)a.Cout * HW * 4u) : rs_o0;
   const int clane = P16 ? (lane >> 4) * 4 : (lane >> 5) * 4;   // channel offset of this lane within a register's group
+  const float relu_lo = a.relu_out ? 0.f : -INFINITY;
   unsigned pvo[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) pvo[nt] = poff[nt] >= 0 ? (unsigned)(clane * HW + poff[nt]) * 4u : BUF_OOB;
+  constexpr int NSV = NACC * 2;
+  // Beside other waves' MFMA streams every instruction here costs about one MFMA slot, so the epilogue proper is
+  // minimal: per value a max, a store (and three VALU for the statistics); per register a few scalar operations for
+  // soffset and the choice of output tensor.  Ragged workgroups (tile not inside the image, cout block not inside the
+  // tensor) first zero the accumulators of their invalid (pixel, channel) pairs: the stores of those lanes are dropped
+  // by the range check anyway, and zeros do not disturb the statistics.
+  const bool full = ty * TH + TH <= a.H && tx * TW + TW <= a.W && cout0 + CB <= a.Cout;
+  if (!full) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < NACC; ++r) {
+        const bool cvalid = cout0 + (P16 ? r : (mt * 32 + (r & 3) + 8 * (r >> 2))) + clane < a.Cout;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt][r] = (cvalid && poff[nt] >= 0) ? acc[mt][nt][r] : 0.f;
+      }
+  }
+  const unsigned hw4 = (unsigned)HW * 4u;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     float mk[NACC][NT];
@@ -289,45 +306,46 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
       for (int r = 0; r < NACC; ++r) {
         const int cbase = cout0 + (P16 ? r : (mt * 32 + (r & 3) + 8 * (r >> 2)));
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          mk[r][nt] = buf_load(rs_m, pvo[nt], (unsigned)min(cbase, a.Cout) * (unsigned)HW * 4u);
+        for (int nt = 0; nt < NT; ++nt) mk[r][nt] = buf_load(rs_m, pvo[nt], (unsigned)min(cbase, a.Cout) * hw4);
       }
     }
-    // per-lane statistics of this M block: index (r*2 + k), k = 0: sum, 1: sum of squares over this lane's NT pixels
-    constexpr int NSV = NACC * 2;
-    float sv[NSV];
 #pragma unroll
     for (int r = 0; r < NACC; ++r) {
       // the channels one register holds across the wave lie in one aligned group of 8 (16 on the 16-wide path) and
       // Csplit is a multiple of 16, so the choice of output tensor is wave-uniform
       const int cbase = cout0 + (P16 ? r : (mt * 32 + (r & 3) + 8 * (r >> 2)));
-      const bool cvalid = cbase + clane < a.Cout;
       const bool second = a.out1 != nullptr && cbase >= a.Csplit;
       const __amdgpu_buffer_rsrc_t rs_o = second ? rs_o1 : rs_o0;
       // min(): soffset stays <= num_records for the zero-padded channels past Cout, so num_records - soffset cannot wrap
-      const unsigned soff = (unsigned)(second ? min(cbase, a.Cout) - a.Csplit : min(cbase, a.Csplit)) * (unsigned)HW * 4u;
-      float s1 = 0.f, s2 = 0.f;
+      const unsigned soff = (unsigned)(second ? min(cbase, a.Cout) - a.Csplit : min(cbase, a.Csplit)) * hw4;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        float v = acc[mt][nt][r];
-        if (a.relu_out) v = fmaxf(v, 0.f);
+        float v = fmaxf(acc[mt][nt][r], relu_lo);
         if (MASK && !(mk[r][nt] > 0.f)) v = 0.f;
         buf_store(rs_o, pvo[nt], soff, v);
-        if (want_stats) {
+      }
+    }
+    if (want_stats) {
+      float sv[NSV];
+#pragma unroll
+      for (int r = 0; r < NACC; ++r) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
 #pragma clang fp contract(off)   // square, then add: the partials must not depend on which pairs the compiler fuses
-          v = (cvalid && poff[nt] >= 0) ? v : 0.f;
+          const float v = fmaxf(acc[mt][nt][r], relu_lo);   // statistics are never combined with a ReLU mask (host check)
           s1 += v;
           s2 += v * v;
         }
+        sv[r * 2 + 0] = s1;
+        sv[r * 2 + 1] = s2;
       }
-      sv[r * 2 + 0] = s1;
-      sv[r * 2 + 1] = s2;
-    }
-    if (want_stats) {
-      // Butterfly "transpose" reduction over the NB lanes that hold one channel's pixels: at step s a lane hands its
-      // partner (lane ^ 2^s) the half of the values the partner will own and adds the half it receives, so the value
-      // count halves each step: NSV - 1 shuffles instead of NSV * log2(NB).  Afterwards the lane's one remaining value
-      // is the total of index  sum_s bit_s(lane) * (NSV >> (s+1)).
+      // Butterfly "transpose" reduction of the per-lane statistics sv[r*2 + k] (k = 0: sum, 1: sum of squares over this
+      // lane's NT pixels) over the NB lanes that hold one channel's pixels: at step s a lane hands its partner
+      // (lane ^ 2^s) the half of the values the partner will own and adds the half it receives, so the value count
+      // halves each step: NSV - 1 shuffles instead of NSV * log2(NB).  Afterwards the lane's one remaining value is the
+      // total of index  sum_s bit_s(lane) * (NSV >> (s+1)).  (Kept inline: through a lambda taking sv by reference the
+      // compiler turned the two-way selects into dynamic indexing of sv, thousands of compare/select pairs.)
       constexpr int LB = P16 ? 4 : 5;               // lane bits spanned by one channel's pixels
       constexpr int HB = P16 ? 3 : 5;               // halving steps = log2(NSV): NSV = 8 | 32
 #pragma unroll
@@ -348,8 +366,8 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
       int idx = 0;
 #pragma unroll
       for (int st = 0; st < HB; ++st) idx += ((lane >> st) & 1) * (NSV >> (st + 1));
-      const int k = idx & 1, r = idx >> 1;
-      const int crel = P16 ? ((lane >> 4) * 4 + r) : (mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5));
+      const int k = idx & 1, rr = idx >> 1;
+      const int crel = P16 ? ((lane >> 4) * 4 + rr) : (mt * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5));
       if (((lane & (NB - 1)) >> HB) == 0) red[(wave * CB + crel) * 2 + k] = sv[0];
     }
   }
@@ -403,6 +421,7 @@ extern "C" int wtpse_conv_fwd(const float* in0, int C0, const float* in1, int C1
   WTPSE_REQUIRE(Csplit > 0 && Csplit <= Cout && ((Csplit == Cout) == (out1 == nullptr)));
   WTPSE_REQUIRE(Csplit == Cout || Csplit % 16 == 0);   // the epilogue picks the output tensor per register, not per lane
   WTPSE_REQUIRE(!(stats && relu_out));
+  WTPSE_REQUIRE(!(stats && mask_ref));
   WTPSE_REQUIRE(!(mask_ref && out1));
   WTPSE_REQUIRE(C1 == 0 || C0 % 16 == 0);   // a channel chunk must not straddle the two inputs
   ConvArgs a;
