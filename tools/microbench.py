@@ -112,6 +112,12 @@ def main():
         x = torch.randn(B, 32, 128, 128, device=DEV)
         med, _ = timeit(lambda: ops.upsample2x_fwd(x), a.reps)
         print("upsample_fwd [%d,32,128,128]  %7.1f us  %6.0f GB/s" % (B, med, 5 * x.numel() * 4.0 / med / 1e3))
+        du = torch.randn(B, 32, 256, 256, device=DEV)
+        med, _ = timeit(lambda: ops.upsample2x_bwd(du), a.reps)
+        print("upsample_bwd [%d,32,256,256]  %7.1f us  %6.0f GB/s" % (B, med, 1.25 * du.numel() * 4.0 / med / 1e3))
+        dp = torch.randn(B, 16, 128, 128, device=DEV)
+        med, _ = timeit(lambda: ops.maxpool2_bwd(y, dp, None, False, None, True), a.reps)
+        print("maxpool2_bwd [%d,16,256,256]  %7.1f us  %6.0f GB/s" % (B, med, 2.25 * nbytes / med / 1e3))
 
 
 if __name__ == "__main__":

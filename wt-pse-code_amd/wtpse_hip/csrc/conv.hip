@@ -740,11 +740,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_k(WgradArgs a) {
 
 // out[i] (+)= sum_k slab[k][i]: 32 outputs x 8 k-slices per workgroup, fp64 accumulation (the slabs are partial sums of
 // a long, cancellation-prone reduction), fixed order -> bitwise reproducible
+// The first nblk_w workgroups fold the weight slabs, the rest (if any) the bias slabs: one launch per convolution.
 __global__ __launch_bounds__(256) void wgrad_reduce_k(const float* __restrict__ slab, int ksplit, int n,
-                                                      float* __restrict__ out, int accumulate) {
+                                                      float* __restrict__ out, int accumulate, int nblk_w,
+                                                      const float* __restrict__ slab_b, int n_b, float* __restrict__ out_b) {
   __shared__ double sh[8][32];
   const int j = threadIdx.x & 31, kq = threadIdx.x >> 5;
-  const int i = blockIdx.x * 32 + j;
+  int blk = blockIdx.x;
+  if (blk >= nblk_w) { blk -= nblk_w; slab = slab_b; n = n_b; out = out_b; }
+  const int i = blk * 32 + j;
   double s = 0.0;
   if (i < n)
     for (int k = kq; k < ksplit; k += 8) s += (double)slab[(size_t)k * n + i];
@@ -811,9 +815,8 @@ extern "C" int wtpse_conv_wgrad(const float* dy, const float* x0, int C0, const 
   int rc = wtpse_status();
   if (rc) return rc;
   const int n = Cout * a.Cin * taps;
-  hipLaunchKernelGGL(wgrad_reduce_k, dim3(ceil_div(n, 32)), dim3(256), 0, st, slab, ksplit, n, dw, accumulate);
-  if (dbias)
-    hipLaunchKernelGGL(wgrad_reduce_k, dim3(ceil_div(Cout, 32)), dim3(256), 0, st, dbias_slab, ksplit, Cout, dbias,
-                       accumulate);
+  const int nblk_w = ceil_div(n, 32), nblk_b = dbias ? ceil_div(Cout, 32) : 0;
+  hipLaunchKernelGGL(wgrad_reduce_k, dim3(nblk_w + nblk_b), dim3(256), 0, st, slab, ksplit, n, dw, accumulate, nblk_w,
+                     dbias_slab, Cout, dbias);
   return wtpse_status();
 }

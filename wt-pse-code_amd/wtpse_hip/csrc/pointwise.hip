@@ -36,6 +36,61 @@ __global__ __launch_bounds__(256) void maxpool2_fwd_k(const float* __restrict__ 
   out[i] = fmaxf(fmaxf(a, b), fmaxf(d, e));
 }
 
+// Plane-per-blockIdx.y variants of the hot pooling / upsampling kernels: 32-bit index arithmetic inside a plane (the
+// 64-bit div/mod chains of the flat kernels cost more than the memory traffic) and 16-byte accesses.  Used when the
+// row length allows it; the flat kernels above/below remain for odd shapes.  Same expression trees, bitwise equal.
+__global__ __launch_bounds__(256) void maxpool2_fwd_v_k(const float* __restrict__ x, const float* __restrict__ pro, int relu,
+                                                        float* __restrict__ out, int BC, int C, int H, int W) {
+  const int Ho = H / 2, Wo = W / 2, W4 = W / 4;   // W % 4 == 0: a thread reads 2 x 4 inputs, writes 2 outputs
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= Ho * W4) return;
+  const int k = j % W4, yo = j / W4;
+  for (int bc = blockIdx.y; bc < BC; bc += gridDim.y) {
+    const int c = bc % C;
+    const float* src = x + (size_t)bc * H * W + (size_t)(2 * yo) * W + 4 * k;
+    const float4 r0 = *reinterpret_cast<const float4*>(src), r1 = *reinterpret_cast<const float4*>(src + W);
+    float2 o;
+    o.x = fmaxf(fmaxf(act_in(r0.x, pro, c, relu), act_in(r0.y, pro, c, relu)), fmaxf(act_in(r1.x, pro, c, relu), act_in(r1.y, pro, c, relu)));
+    o.y = fmaxf(fmaxf(act_in(r0.z, pro, c, relu), act_in(r0.w, pro, c, relu)), fmaxf(act_in(r1.z, pro, c, relu), act_in(r1.w, pro, c, relu)));
+    *reinterpret_cast<float2*>(out + (size_t)bc * Ho * Wo + (size_t)yo * Wo + 2 * k) = o;
+  }
+}
+
+__device__ __forceinline__ int pool_argmax(float v0, float v1, float v2, float v3) {   // first maximum, NaN wins (as ATen)
+  int am = 0;
+  float m = v0;
+  if (v1 > m || isnan(v1)) { m = v1; am = 1; }
+  if (v2 > m || isnan(v2)) { m = v2; am = 2; }
+  if (v3 > m || isnan(v3)) { m = v3; am = 3; }
+  return am;
+}
+
+__global__ __launch_bounds__(256) void maxpool2_bwd_v_k(const float* __restrict__ x, const float* __restrict__ pro, int relu,
+                                                        const float* __restrict__ dout, float* __restrict__ dx, int accumulate,
+                                                        int BC, int C, int H, int W) {
+  const int Ho = H / 2, Wo = W / 2, W4 = W / 4;   // H even, W % 4 == 0: a thread owns two windows (2 rows x 4 columns)
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= Ho * W4) return;
+  const int k = j % W4, yo = j / W4;
+  for (int bc = blockIdx.y; bc < BC; bc += gridDim.y) {
+    const int c = bc % C;
+    const size_t off = (size_t)bc * H * W + (size_t)(2 * yo) * W + 4 * k;
+    const float4 r0 = *reinterpret_cast<const float4*>(x + off), r1 = *reinterpret_cast<const float4*>(x + off + W);
+    const float2 g = *reinterpret_cast<const float2*>(dout + (size_t)bc * Ho * Wo + (size_t)yo * Wo + 2 * k);
+    const int a0 = pool_argmax(act_in(r0.x, pro, c, relu), act_in(r0.y, pro, c, relu), act_in(r1.x, pro, c, relu), act_in(r1.y, pro, c, relu));
+    const int a1 = pool_argmax(act_in(r0.z, pro, c, relu), act_in(r0.w, pro, c, relu), act_in(r1.z, pro, c, relu), act_in(r1.w, pro, c, relu));
+    float4 d0 = make_float4(a0 == 0 ? g.x : 0.f, a0 == 1 ? g.x : 0.f, a1 == 0 ? g.y : 0.f, a1 == 1 ? g.y : 0.f);
+    float4 d1 = make_float4(a0 == 2 ? g.x : 0.f, a0 == 3 ? g.x : 0.f, a1 == 2 ? g.y : 0.f, a1 == 3 ? g.y : 0.f);
+    if (accumulate) {
+      const float4 p0 = *reinterpret_cast<const float4*>(dx + off), p1 = *reinterpret_cast<const float4*>(dx + off + W);
+      d0 = make_float4(p0.x + d0.x, p0.y + d0.y, p0.z + d0.z, p0.w + d0.w);
+      d1 = make_float4(p1.x + d1.x, p1.y + d1.y, p1.z + d1.z, p1.w + d1.w);
+    }
+    *reinterpret_cast<float4*>(dx + off) = d0;
+    *reinterpret_cast<float4*>(dx + off + W) = d1;
+  }
+}
+
 // dx[b,c,y,x] (+)= dout[b,c,y/2,x/2] if (y,x) is the first maximum of its window (row-major scan, as ATen), else 0
 __global__ __launch_bounds__(256) void maxpool2_bwd_k(const float* __restrict__ x, const float* __restrict__ pro, int relu,
                                                       const float* __restrict__ dout, float* __restrict__ dx,
@@ -94,47 +149,46 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_k(const float* __restrict_
   out[i] = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
 }
 
-// 4 consecutive outputs of one row per thread (W even): 2 x 4 input loads, one 16-byte store; bitwise the same
-// expression tree as the scalar kernel / ATen (weights 0.25/0.75, (1,0) at the clamped first column and row)
-__global__ __launch_bounds__(256) void upsample2x_fwd4_k(const float* __restrict__ x, const float* __restrict__ pro, int relu,
-                                                         float* __restrict__ out, int C, int H, int W, long long total4) {
-  const int Ho = 2 * H, Wo = 2 * W, W2 = W / 2;
-  long long i = (long long)blockIdx.x * 256 + threadIdx.x;   // over B*C*Ho*(Wo/4)
-  if (i >= total4) return;
-  int k = (int)(i % W2);
-  long long r = i / W2;
-  int yo = (int)(r % Ho);
-  long long bc = r / Ho;
-  int c = (int)(bc % C);
-  int y0, y1;
-  float ly;
-  up_src(yo, H, y0, y1, ly);
-  const int m = 2 * k;
-  const int xm1 = max(m - 1, 0), x1 = min(m + 1, W - 1), x2 = min(m + 2, W - 1);
-  const float* r0 = x + (size_t)bc * H * W + (size_t)y0 * W;
-  const float* r1 = x + (size_t)bc * H * W + (size_t)y1 * W;
-  float a[4] = {act_in(r0[xm1], pro, c, relu), act_in(r0[m], pro, c, relu), act_in(r0[x1], pro, c, relu), act_in(r0[x2], pro, c, relu)};
-  float b[4] = {act_in(r1[xm1], pro, c, relu), act_in(r1[m], pro, c, relu), act_in(r1[x1], pro, c, relu), act_in(r1[x2], pro, c, relu)};
-  float ha[4], hb[4];
-  // horizontal: out0 = xo 2m (first column of the image: weights (1, 0) on (c[0], c[1])), out1 = 2m+1, out2 = 2m+2, out3 = 2m+3
-  if (m == 0) { ha[0] = 1.f * a[1] + 0.f * a[2]; hb[0] = 1.f * b[1] + 0.f * b[2]; }
-  else        { ha[0] = 0.25f * a[0] + 0.75f * a[1]; hb[0] = 0.25f * b[0] + 0.75f * b[1]; }
-  ha[1] = 0.75f * a[1] + 0.25f * a[2]; hb[1] = 0.75f * b[1] + 0.25f * b[2];
-  ha[2] = 0.25f * a[1] + 0.75f * a[2]; hb[2] = 0.25f * b[1] + 0.75f * b[2];
-  ha[3] = 0.75f * a[2] + 0.25f * a[3]; hb[3] = 0.75f * b[2] + 0.25f * b[3];
-  float4 o;
-  o.x = (1.f - ly) * ha[0] + ly * hb[0];
-  o.y = (1.f - ly) * ha[1] + ly * hb[1];
-  o.z = (1.f - ly) * ha[2] + ly * hb[2];
-  o.w = (1.f - ly) * ha[3] + ly * hb[3];
-  *reinterpret_cast<float4*>(out + (size_t)bc * Ho * Wo + (size_t)yo * Wo + 4 * k) = o;
-}
-
 __device__ __forceinline__ float up_w(int d, int n, int k) {  // weight of source k in destination d (1-D)
   int i0, i1;
   float l1;
   up_src(d, n, i0, i1, l1);
   return (i0 == k ? 1.f - l1 : 0.f) + (i1 == k ? l1 : 0.f);
+}
+
+// 4 consecutive outputs of one row per thread (W even): 2 x 4 input loads, one 16-byte store; bitwise the same
+// expression tree as the scalar kernel / ATen (weights 0.25/0.75, (1,0) at the clamped first column and row);
+// one plane per blockIdx.y, 32-bit index arithmetic
+__global__ __launch_bounds__(256) void upsample2x_fwd4_v_k(const float* __restrict__ x, const float* __restrict__ pro, int relu,
+                                                           float* __restrict__ out, int BC, int C, int H, int W) {
+  const int Ho = 2 * H, Wo = 2 * W, W2 = W / 2;
+  const int j = blockIdx.x * 256 + threadIdx.x;   // over Ho*(Wo/4)
+  if (j >= Ho * W2) return;
+  const int k = j % W2, yo = j / W2;
+  int y0, y1;
+  float ly;
+  up_src(yo, H, y0, y1, ly);
+  const int m = 2 * k;
+  const int xm1 = max(m - 1, 0), x1 = min(m + 1, W - 1), x2 = min(m + 2, W - 1);
+  for (int bc = blockIdx.y; bc < BC; bc += gridDim.y) {
+    const int c = bc % C;
+    const float* r0 = x + (size_t)bc * H * W + (size_t)y0 * W;
+    const float* r1 = x + (size_t)bc * H * W + (size_t)y1 * W;
+    float a[4] = {act_in(r0[xm1], pro, c, relu), act_in(r0[m], pro, c, relu), act_in(r0[x1], pro, c, relu), act_in(r0[x2], pro, c, relu)};
+    float b[4] = {act_in(r1[xm1], pro, c, relu), act_in(r1[m], pro, c, relu), act_in(r1[x1], pro, c, relu), act_in(r1[x2], pro, c, relu)};
+    float ha[4], hb[4];
+    if (m == 0) { ha[0] = 1.f * a[1] + 0.f * a[2]; hb[0] = 1.f * b[1] + 0.f * b[2]; }
+    else        { ha[0] = 0.25f * a[0] + 0.75f * a[1]; hb[0] = 0.25f * b[0] + 0.75f * b[1]; }
+    ha[1] = 0.75f * a[1] + 0.25f * a[2]; hb[1] = 0.75f * b[1] + 0.25f * b[2];
+    ha[2] = 0.25f * a[1] + 0.75f * a[2]; hb[2] = 0.25f * b[1] + 0.75f * b[2];
+    ha[3] = 0.75f * a[2] + 0.25f * a[3]; hb[3] = 0.75f * b[2] + 0.25f * b[3];
+    float4 o;
+    o.x = (1.f - ly) * ha[0] + ly * hb[0];
+    o.y = (1.f - ly) * ha[1] + ly * hb[1];
+    o.z = (1.f - ly) * ha[2] + ly * hb[2];
+    o.w = (1.f - ly) * ha[3] + ly * hb[3];
+    *reinterpret_cast<float4*>(out + (size_t)bc * Ho * Wo + (size_t)yo * Wo + 4 * k) = o;
+  }
 }
 
 // adjoint of the above: gather over the <=4x4 destination pixels that read source (y,x)
@@ -166,6 +220,53 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_k(const float* __restrict_
     g += wy * rowsum;
   }
   dx[i] = accumulate ? dx[i] + g : g;
+}
+
+// plane-per-blockIdx.y form, 4 consecutive dx of one row per thread (W % 4 == 0): the 4 x 10 window of dout comes in
+// as 2 x 16-byte + 2 scalar loads per row; per output the same loops and summation order as the scalar kernel
+__global__ __launch_bounds__(256) void upsample2x_bwd_v_k(const float* __restrict__ dout, float* __restrict__ dx, int accumulate,
+                                                          int BC, int H, int W) {
+  const int Ho = 2 * H, Wo = 2 * W, W4 = W / 4;
+  const int j = blockIdx.x * 256 + threadIdx.x;   // over H*(W/4)
+  if (j >= H * W4) return;
+  const int k = j % W4, yy = j / W4;
+  const int xb = 4 * k;            // first dx column; dout columns 2*xb-1 .. 2*xb+8
+  for (int bc = blockIdx.y; bc < BC; bc += gridDim.y) {
+    const float* src = dout + (size_t)bc * Ho * Wo;
+    float g[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dy = -1; dy <= 2; ++dy) {
+      const int yo = 2 * yy + dy;
+      if (yo < 0 || yo >= Ho) continue;
+      const float wy = up_w(yo, H, yy);
+      if (wy == 0.f) continue;
+      const float* row = src + (size_t)yo * Wo + 2 * xb;
+      const float4 q0 = *reinterpret_cast<const float4*>(row), q1 = *reinterpret_cast<const float4*>(row + 4);
+      float w[10];                 // w[t] = dout[yo][2*xb - 1 + t]
+      w[0] = xb > 0 ? row[-1] : 0.f;
+      w[1] = q0.x; w[2] = q0.y; w[3] = q0.z; w[4] = q0.w; w[5] = q1.x; w[6] = q1.y; w[7] = q1.z; w[8] = q1.w;
+      w[9] = 2 * xb + 8 < Wo ? row[8] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int xx = xb + e;
+        float rowsum = 0.f;
+#pragma unroll
+        for (int dxo = -1; dxo <= 2; ++dxo) {
+          const int xo = 2 * xx + dxo;
+          if (xo < 0 || xo >= Wo) continue;
+          rowsum += up_w(xo, W, xx) * w[2 * e + dxo + 1];
+        }
+        g[e] += wy * rowsum;
+      }
+    }
+    float* dst = dx + (size_t)bc * H * W + (size_t)yy * W + xb;
+    float4 o = make_float4(g[0], g[1], g[2], g[3]);
+    if (accumulate) {
+      const float4 p = *reinterpret_cast<const float4*>(dst);
+      o = make_float4(p.x + o.x, p.y + o.y, p.z + o.z, p.w + o.w);
+    }
+    *reinterpret_cast<float4*>(dst) = o;
+  }
 }
 
 // F.interpolate(x, size=(Ho,Wo), mode="bilinear") with align_corners=False (Trainer.py:206-209): validation resizes the
@@ -467,6 +568,7 @@ __global__ __launch_bounds__(256) void randn_k(float* __restrict__ out, long lon
 // ================================================================================================ C ABI
 #define GRID1(n) dim3((unsigned)(((n) + 255) / 256))
 #define ST ((hipStream_t)stream)
+#define PLANE_GRID(per_plane, planes) dim3((unsigned)(((per_plane) + 255) / 256), (unsigned)((planes) < 32768 ? (planes) : 32768))
 static inline unsigned red_blocks(long long n) {
   long long b = (n + 256 * 16 - 1) / (256 * 16);
   if (b > 1024) b = 1024;
@@ -478,21 +580,28 @@ extern "C" int wtpse_reduce_blocks(long long n) { return (int)red_blocks(n); }
 extern "C" int wtpse_maxpool2_fwd(const float* x, const float* pro, int relu, float* out, int B, int C, int H, int W, void* stream) {
   WTPSE_REQUIRE(x && out && B > 0 && C > 0 && H >= 2 && W >= 2);
   long long total = (long long)B * C * (H / 2) * (W / 2);
-  hipLaunchKernelGGL(maxpool2_fwd_k, GRID1(total), dim3(256), 0, ST, x, pro, relu, out, C, H, W, total);
+  if (W % 4 == 0 && (((uintptr_t)x | (uintptr_t)out) & 15) == 0)
+    hipLaunchKernelGGL(maxpool2_fwd_v_k, PLANE_GRID((H / 2) * (W / 4), B * C), dim3(256), 0, ST, x, pro, relu, out, B * C, C, H, W);
+  else
+    hipLaunchKernelGGL(maxpool2_fwd_k, GRID1(total), dim3(256), 0, ST, x, pro, relu, out, C, H, W, total);
   return wtpse_status();
 }
 extern "C" int wtpse_maxpool2_bwd(const float* x, const float* pro, int relu, const float* dout, float* dx, int accumulate,
                                   int B, int C, int H, int W, void* stream) {
   WTPSE_REQUIRE(x && dout && dx && B > 0 && C > 0 && H >= 2 && W >= 2);
   long long total = (long long)B * C * H * W;
-  hipLaunchKernelGGL(maxpool2_bwd_k, GRID1(total), dim3(256), 0, ST, x, pro, relu, dout, dx, accumulate, C, H, W, total);
+  if (W % 4 == 0 && H % 2 == 0 && (((uintptr_t)x | (uintptr_t)dx | (uintptr_t)dout) & 15) == 0)
+    hipLaunchKernelGGL(maxpool2_bwd_v_k, PLANE_GRID((H / 2) * (W / 4), B * C), dim3(256), 0, ST, x, pro, relu, dout, dx, accumulate,
+                       B * C, C, H, W);
+  else
+    hipLaunchKernelGGL(maxpool2_bwd_k, GRID1(total), dim3(256), 0, ST, x, pro, relu, dout, dx, accumulate, C, H, W, total);
   return wtpse_status();
 }
 extern "C" int wtpse_upsample2x_fwd(const float* x, const float* pro, int relu, float* out, int B, int C, int H, int W, void* stream) {
   WTPSE_REQUIRE(x && out && B > 0 && C > 0 && H > 0 && W > 0);
   long long total = (long long)B * C * H * W * 4;
   if (W % 2 == 0 && W >= 2 && (((uintptr_t)out) & 15) == 0)
-    hipLaunchKernelGGL(upsample2x_fwd4_k, GRID1(total / 4), dim3(256), 0, ST, x, pro, relu, out, C, H, W, total / 4);
+    hipLaunchKernelGGL(upsample2x_fwd4_v_k, PLANE_GRID(2 * H * (W / 2), B * C), dim3(256), 0, ST, x, pro, relu, out, B * C, C, H, W);
   else
     hipLaunchKernelGGL(upsample2x_fwd_k, GRID1(total), dim3(256), 0, ST, x, pro, relu, out, C, H, W, total);
   return wtpse_status();
@@ -500,7 +609,10 @@ extern "C" int wtpse_upsample2x_fwd(const float* x, const float* pro, int relu, 
 extern "C" int wtpse_upsample2x_bwd(const float* dout, float* dx, int accumulate, int B, int C, int H, int W, void* stream) {
   WTPSE_REQUIRE(dout && dx && B > 0 && C > 0 && H > 0 && W > 0);
   long long total = (long long)B * C * H * W;
-  hipLaunchKernelGGL(upsample2x_bwd_k, GRID1(total), dim3(256), 0, ST, dout, dx, accumulate, H, W, total);
+  if (W % 4 == 0 && (((uintptr_t)dout | (uintptr_t)dx) & 15) == 0)
+    hipLaunchKernelGGL(upsample2x_bwd_v_k, PLANE_GRID(H * (W / 4), B * C), dim3(256), 0, ST, dout, dx, accumulate, B * C, H, W);
+  else
+    hipLaunchKernelGGL(upsample2x_bwd_k, GRID1(total), dim3(256), 0, ST, dout, dx, accumulate, H, W, total);
   return wtpse_status();
 }
 extern "C" int wtpse_resize_bilinear(const float* x, float* out, int B, int C, int H, int W, int Ho, int Wo, void* stream) {
