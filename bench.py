@@ -232,6 +232,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = ts.step(image, target_od, target_oc)
+    t_host = time.perf_counter() - t0            # host time to enqueue the steps (no GPU wait inside a step)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -239,7 +240,7 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    log("timed region: %.3f s for %d steps" % (dt, args.steps))
+    log("timed region: %.3f s for %d steps (host enqueue %.3f s)" % (dt, args.steps, t_host))
     losses = {k: float(v) for k, v in res.items()}
     assert all(v == v for v in losses.values()), "NaN loss: %s" % losses
 
@@ -254,6 +255,7 @@ def main():
                                     "BASELINE.json configs[1]: seg-net only") + ", 3x%dx%d, batch %d per GPU" % (H, H, B),
                        "global_batch": B * world, "image": [3, H, H], "parallelism": "dp%d" % world,
                        "bn_sync": bool(args.bn_sync), "step": "calls A-D + 4 backward + 4 Adam (Trainer.py:766-914)"},
+            "host_enqueue_ms_per_step": 1e3 * t_host / args.steps,
             "conv_tflops_end_to_end": ips * GFLOP_PER_IMAGE * (H * H / 65536.0) / 1e3 if full else None,
             "losses": losses,
         }

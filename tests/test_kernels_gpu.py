@@ -261,9 +261,10 @@ def test_wt_loss_unaligned_hw():
     close(st.losses[:2], torch.stack([off, dg]), rtol=1e-5, atol=1e-7)
 
 
-def test_attention_fuse_and_sampling():
+@pytest.mark.parametrize("shape", [(3, 8, 9, 11), (5, 2, 256, 256)])   # the second takes the many-row reduction of (dw, db)
+def test_attention_fuse_and_sampling(shape):
     o = ops()
-    B, CE, H, W = 3, 8, 9, 11
+    B, CE, H, W = shape
     z = rnd(B, 1, H, W, seed=51).requires_grad_(True)
     emb = rnd(B, CE, H, W, seed=52).requires_grad_(True)
     wb = torch.tensor([0.7, -0.2], requires_grad=True)
@@ -278,7 +279,7 @@ def test_attention_fuse_and_sampling():
     assert torch.equal(m.cpu(), (att > 0.75).float())
     dwb = torch.zeros(2, device=DEV)
     demb, dz = o.attn_fuse_bwd(dfuse.to(DEV), z.detach().to(DEV), emb.detach().to(DEV), a, wb_d.data_ptr(), 0.3, dwb.data_ptr(), True)
-    close(demb, emb.grad, what="demb"); close(dz, z.grad, what="dz"); close(dwb, wb.grad, rtol=1e-4, atol=1e-4, what="dwb")
+    close(demb, emb.grad, what="demb"); close(dz, z.grad, what="dz"); close(dwb, wb.grad, rtol=1e-4, atol=1e-4 * max(1.0, float(wb.grad.abs().max())), what="dwb")
     mu, lv, eps = rnd(B, 1, H, W, seed=54).requires_grad_(True), rnd(B, 1, H, W, seed=55).requires_grad_(True), rnd(B, 1, H, W, seed=56)
     zz = mu + torch.exp(lv / 2) * eps
     g = rnd(B, 1, H, W, seed=57)

@@ -315,6 +315,26 @@ __global__ __launch_bounds__(256) void reduce_rows_k(const float* __restrict__ p
   out[j] = accumulate ? out[j] + v : v;
 }
 
+// same for a few columns and many rows (the (dw, db) partials of the attention layer: 8192 x 2): one workgroup per
+// column, 256 fp64 partial sums folded in a fixed order
+__global__ __launch_bounds__(256) void reduce_rows_tall_k(const float* __restrict__ partial, int rows, int cols,
+                                                          float* __restrict__ out, int accumulate, float scale) {
+  __shared__ double sh[256];
+  const int j = blockIdx.x, t = threadIdx.x;
+  double s = 0.0;
+  for (int r = t; r < rows; r += 256) s += partial[(size_t)r * cols + j];
+  sh[t] = s;
+  __syncthreads();
+  for (int m = 128; m >= 1; m >>= 1) {
+    if (t < m) sh[t] += sh[t + m];
+    __syncthreads();
+  }
+  if (t == 0) {
+    float v = (float)sh[0] * scale;
+    out[j] = accumulate ? out[j] + v : v;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ shape attention + fusion
 // a_pre = w*z + b ; att = sigmoid(a_pre) ; fuse[c] = coef*emb[c] + att*emb[c] ; mask = att > 0.75
 __global__ __launch_bounds__(256) void attn_fuse_fwd_k(const float* __restrict__ z, const float* __restrict__ wb,
@@ -634,7 +654,10 @@ extern "C" int wtpse_axpy(float* dst, const float* src, float alpha, long long n
 }
 extern "C" int wtpse_reduce_rows(const float* partial, int rows, int cols, float* out, int accumulate, float scale, void* stream) {
   WTPSE_REQUIRE(partial && out && rows > 0 && cols > 0);
-  hipLaunchKernelGGL(reduce_rows_k, GRID1(cols), dim3(256), 0, ST, partial, rows, cols, out, accumulate, scale);
+  if (cols <= 64 && rows >= 1024)
+    hipLaunchKernelGGL(reduce_rows_tall_k, dim3(cols), dim3(256), 0, ST, partial, rows, cols, out, accumulate, scale);
+  else
+    hipLaunchKernelGGL(reduce_rows_k, GRID1(cols), dim3(256), 0, ST, partial, rows, cols, out, accumulate, scale);
   return wtpse_status();
 }
 extern "C" int wtpse_zero(void* p, long long nbytes, void* stream) {
@@ -657,7 +680,10 @@ extern "C" int wtpse_attn_fuse_bwd(const float* dfuse, const float* z, const flo
   long long total = (long long)B * HW;
   unsigned nb = (unsigned)((total + 255) / 256);
   hipLaunchKernelGGL(attn_fuse_bwd_k, dim3(nb), dim3(256), 0, ST, dfuse, z, emb, att, wb, coef, demb, dz, partial, CE, HW, total);
-  hipLaunchKernelGGL(reduce_rows_k, dim3(1), dim3(256), 0, ST, partial, (int)nb, 2, d_wb, accumulate, 1.f);
+  if (nb >= 1024)
+    hipLaunchKernelGGL(reduce_rows_tall_k, dim3(2), dim3(256), 0, ST, partial, (int)nb, 2, d_wb, accumulate, 1.f);
+  else
+    hipLaunchKernelGGL(reduce_rows_k, dim3(1), dim3(256), 0, ST, partial, (int)nb, 2, d_wb, accumulate, 1.f);
   return wtpse_status();
 }
 extern "C" int wtpse_reparam_fwd(const float* mu, const float* logvar, const float* eps, float* z, long long n, void* stream) {
