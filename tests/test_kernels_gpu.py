@@ -26,7 +26,9 @@ def close(a, b, rtol=1e-4, atol=1e-5, what=""):
     b = b.detach().cpu().double()
     assert a.shape == b.shape, (what, a.shape, b.shape)
     err = (a - b).abs()
-    tol = atol + rtol * b.abs()
+    # 2e-6 of the tensor's scale: an fp32 sum of ~1e3 terms that cancels to ~0 carries that much rounding noise, and the
+    # 16- and 32-wide MFMA paths (chosen by grid size) add the terms in different orders
+    tol = atol + rtol * b.abs() + 2e-6 * float(b.abs().max())
     bad = err > tol
     assert not bad.any(), f"{what}: {int(bad.sum())}/{bad.numel()} off, max err {err.max():.3e} at {int(err.argmax())}, ref scale {b.abs().max():.3e}"
 

@@ -435,6 +435,7 @@ extern "C" int wtpse_conv_fwd(const float* in0, int C0, const float* in1, int C1
   // workgroup count, and overlap each workgroup's own loads with its MFMAs (register double-buffering)
   const int tiles = fwd_tiles(B, H, W);
   if (mode == 2 && tiles * (a.CoutP / 64) < 512) mode = 1;
+  if (mode == 1 && tiles * ceil_div(a.CoutP, 32) < 384) mode = 0;   // still under two workgroups per CU: 16-cout blocks
   const int cb = mode == 0 ? 16 : 32 * mode;
   const bool db = tiles * ceil_div(a.CoutP, cb) < 768 && a.CinP > (mode == 0 ? 16 : 8);
 #define FWD(KS, M) (mask_ref ? (db ? launch_fwd<KS, M, true, true>(a, st) : launch_fwd<KS, M, false, true>(a, st)) \
