@@ -146,6 +146,25 @@ int wtpse_roi(const float* image, const float* logit, float* roi, float* od_pred
 int wtpse_adam(float* p, const float* g, float* m, float* v, long long n, double lr, double beta1, double beta2, double eps,
                int step, void* stream);
 
+/* ---- fused 1x1 heads (csrc/head.hip) ------------------------------------------------------------------------------ */
+/* The heads 32 -> 32 (ReLU) -> 8 [-> (ReLU) -> nc] as one kernel per direction: reference algorithms.py:1006-1012
+ * (mu_prior / logvar_prior, three layers, nc <= 4) and :1199-1200 (the segmentation net's `mu`, two layers: w3 = b3 = y =
+ * NULL and the 8-channel result is h2).  Weights are the plain OIHW parameters ([32][32], [8][32], [nc][8]), HW % 32 == 0.
+ * x takes the conv loaders' prologue (pro: [32][2] scale/shift or NULL, pro_relu).  h1 ([B][32][HW], post-ReLU) and h2
+ * ([B][8][HW], post-ReLU for three layers) are what the backward needs; pass NULL to skip storing them (forward only;
+ * h2 is mandatory for a two-layer head: it is the output). */
+int wtpse_head_fwd(const float* x, const float* pro, int pro_relu, const float* w1, const float* b1, const float* w2,
+                   const float* b2, const float* w3, const float* b3, int nc, float* h1, float* h2, float* y, int B, int HW,
+                   void* stream);
+/* dy: [B][nc][HW] (three layers) or [B][8][HW] (two layers: gradient of the h2 output).  dx: [B][32][HW] gradient wrt the
+ * activated input.  dparams: [32*32 + 32 + 8*32 + 8 (+ 8*nc + nc)] = (dW1, db1, dW2, db2[, dW3, db3]) contiguous, which is
+ * the order the head's parameters have in the flat gradient buffer; written, or added to when accumulate != 0.
+ * slab: scratch of wtpse_head_slabs(B, HW) * that many floats. */
+int wtpse_head_bwd(const float* dy, const float* x, const float* pro, int pro_relu, const float* h1, const float* h2,
+                   const float* w1, const float* w2, const float* w3, int nc, float* dx, float* slab, float* dparams,
+                   int accumulate, int B, int HW, void* stream);
+int wtpse_head_slabs(int B, int HW);
+
 /* ---- small utilities ------------------------------------------------------------------------------------------- */
 int wtpse_relu_mask(const float* dz, const float* ref, float* dy, int accumulate, long long n, void* stream);
 int wtpse_axpy(float* dst, const float* src, float alpha, long long n, void* stream);

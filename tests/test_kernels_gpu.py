@@ -263,6 +263,44 @@ def test_wt_loss_unaligned_hw():
     close(st.losses[:2], torch.stack([off, dg]), rtol=1e-5, atol=1e-7)
 
 
+@pytest.mark.parametrize("case", [(2, 8, 8, 1, True), (3, 16, 32, 1, False), (1, 4, 8, 3, True), (2, 16, 16, 0, True), (1, 8, 4, 0, False),
+                                  (6, 64, 64, 1, True)])
+def test_fused_head(case):
+    """csrc/head.hip: the 1x1 heads as one kernel per direction against three (two) torch convolutions."""
+    o = ops()
+    B, H, W, nc, use_pro = case
+    three = nc > 0
+    x = rnd(B, 32, H, W, seed=61)
+    pro = torch.stack([rnd(32, seed=62) * 0.5 + 1.0, rnd(32, seed=63) * 0.3], 1).contiguous() if use_pro else None
+    w1 = rnd(32, 32, 1, 1, seed=64, scale=0.3).requires_grad_(True); b1 = rnd(32, seed=65, scale=0.2).requires_grad_(True)
+    w2 = rnd(8, 32, 1, 1, seed=66, scale=0.3).requires_grad_(True); b2 = rnd(8, seed=67, scale=0.2).requires_grad_(True)
+    w3 = rnd(nc, 8, 1, 1, seed=68, scale=0.5).requires_grad_(True) if three else None
+    b3 = rnd(nc, seed=69, scale=0.2).requires_grad_(True) if three else None
+    xa = (F.relu(x * pro[:, 0].view(1, -1, 1, 1) + pro[:, 1].view(1, -1, 1, 1)) if use_pro else x.clone()).requires_grad_(True)
+    h1 = F.relu(F.conv2d(xa, w1, b1))
+    h2 = F.conv2d(h1, w2, b2)
+    out = F.conv2d(F.relu(h2), w3, b3) if three else h2
+    dy = rnd(*out.shape, seed=70)
+    out.backward(dy)
+    D = lambda t: t.detach().to(DEV).contiguous() if t is not None else None
+    got, h1d, h2d = o.head_fwd(D(x), D(pro), use_pro, D(w1), D(b1), D(w2), D(b2), D(w3), D(b3), True)
+    close(got, out, what="head out")
+    close(h1d, h1, what="h1")
+    close(h2d, F.relu(h2) if three else h2, what="h2")
+    got2, none1, h2n = o.head_fwd(D(x), D(pro), use_pro, D(w1), D(b1), D(w2), D(b2), D(w3), D(b3), False)
+    assert none1 is None and (h2n is None) == three
+    assert torch.equal(got2, got)
+    ns = 1320 + 9 * nc
+    dpar = torch.full((ns,), float("nan"), device=DEV)
+    dx = o.head_bwd(D(dy), D(x), D(pro), use_pro, h1d, h2d, D(w1), D(w2), D(w3), dpar)
+    close(dx, xa.grad, what="dx")
+    want = torch.cat([t.grad.reshape(-1) for t in (w1, b1, w2, b2) + ((w3, b3) if three else ())])
+    scale = float(want.abs().max())
+    close(dpar, want, rtol=2e-4, atol=2e-5 * max(scale, 1.0), what="head dparams")
+    o.head_bwd(D(dy), D(x), D(pro), use_pro, h1d, h2d, D(w1), D(w2), D(w3), dpar, accumulate=True)
+    close(dpar, 2 * want, rtol=2e-4, atol=4e-5 * max(scale, 1.0), what="head dparams accumulate")
+
+
 @pytest.mark.parametrize("shape", [(3, 8, 9, 11), (5, 2, 256, 256)])   # the second takes the many-row reduction of (dw, db)
 def test_attention_fuse_and_sampling(shape):
     o = ops()

@@ -101,6 +101,22 @@ def main():
         dz = torch.empty_like(z)
         med, mn = timeit(lambda: ops.wt_loss_bwd(st, dz, False), a.reps)
         print("wt_loss_bwd  [%d,16,256,256]  %7.1f us  %6.0f GB/s" % (B, med, 2 * nbytes / med / 1e3))
+    if a.only in ("", "head"):
+        x = torch.randn(B, 32, 256, 256, device=DEV)
+        pro = torch.rand(32, 2, device=DEV)
+        w1, b1 = torch.randn(32, 32, 1, 1, device=DEV) * 0.2, torch.randn(32, device=DEV)
+        w2, b2 = torch.randn(8, 32, 1, 1, device=DEV) * 0.2, torch.randn(8, device=DEV)
+        w3, b3 = torch.randn(1, 8, 1, 1, device=DEV) * 0.2, torch.randn(1, device=DEV)
+        px = x.numel() / 32
+        med, _ = timeit(lambda: ops.head_fwd(x, pro, True, w1, b1, w2, b2, w3, b3, True), a.reps)
+        print("head_fwd 32-32-8-1 +tape [%d,32,256,256]  %7.1f us  %6.0f GB/s (73 floats/px)" % (B, med, 73 * 4 * px / med / 1e3))
+        med, _ = timeit(lambda: ops.head_fwd(x, pro, True, w1, b1, w2, b2, w3, b3, False), a.reps)
+        print("head_fwd 32-32-8-1 no tape                 %7.1f us  %6.0f GB/s (33 floats/px)" % (med, 33 * 4 * px / med / 1e3))
+        y, h1, h2 = ops.head_fwd(x, pro, True, w1, b1, w2, b2, w3, b3, True)
+        dy = torch.randn_like(y)
+        dpar = torch.zeros(1320 + 9, device=DEV)
+        med, _ = timeit(lambda: ops.head_bwd(dy, x, pro, True, h1, h2, w1, w2, w3, dpar), a.reps)
+        print("head_bwd 32-32-8-1                         %7.1f us  %6.0f GB/s (105 floats/px)" % (med, 105 * 4 * px / med / 1e3))
     if a.only in ("", "pw"):
         y = torch.randn(B, 16, 256, 256, device=DEV)
         ss = torch.rand(16, 2, device=DEV)

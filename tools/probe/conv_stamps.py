@@ -107,8 +107,9 @@ def wgrad(dll, cin, cout, hw, B):
 
 
 def main():
-    args = [a for a in sys.argv[1:] if a != "wgrad"]
+    args = [a for a in sys.argv[1:] if a not in ("wgrad", "k1")]
     cin, cout, hw, B = [int(v) for v in (args[:4] + ["64", "64", "128", "32"][len(args):])]
+    ks = 1 if "k1" in sys.argv else 3
     if "wgrad" in sys.argv:
         if not os.path.isfile(OUT):
             build()
@@ -120,22 +121,22 @@ def main():
     dll = ctypes.CDLL(OUT)
     dev = torch.device("cuda:0")
     x = torch.randn(B, cin, hw, hw, device=dev)
-    w = torch.randn(cout, cin, 3, 3, device=dev) * 0.05
+    w = torch.randn(cout, cin, ks, ks, device=dev) * 0.05
     bias = torch.randn(cout, device=dev)
     cinp, coutp = (cin + 3) & ~3, (cout + 15) & ~15
-    packed = torch.zeros(cinp * 9 * coutp + 64, device=dev)
-    desc = torch.tensor([0, cout, cin, 9, 0, -1, 0, 0], dtype=torch.int32, device=dev)
+    packed = torch.zeros(cinp * ks * ks * coutp + 64, device=dev)
+    desc = torch.tensor([0, cout, cin, ks * ks, 0, -1, 0, 0], dtype=torch.int32, device=dev)
     vp = ctypes.c_void_p
     assert dll.wtpse_pack_conv_weights(vp(w.data_ptr()), vp(desc.data_ptr()), 1, vp(packed.data_ptr()), None) == 0
     y = torch.empty(B, cout, hw, hw, device=dev)
     nblk = dll.wtpse_conv_stats_blocks(B, hw, hw)
     stats = torch.zeros(nblk * cout * 2, device=dev)
-    ngrid = nblk * ((coutp + 31) // 32)           # upper bound on workgroups (32-cout blocks)
+    ngrid = nblk * ((coutp + 15) // 16)           # upper bound on workgroups (16-cout blocks)
     stamps = torch.zeros(ngrid * 64, dtype=torch.int64, device=dev)
 
     def run():
         return dll.wtpse_conv_fwd(vp(x.data_ptr()), cin, None, 0, vp(packed.data_ptr()), vp(bias.data_ptr()), None, None, 0,
-                                  vp(y.data_ptr()), None, cout, vp(stats.data_ptr()), B, hw, hw, cout, 3, 0, None, None)
+                                  vp(y.data_ptr()), None, cout, vp(stats.data_ptr()) if ks == 3 else None, B, hw, hw, cout, ks, 0, None, None)
     for _ in range(3):
         assert run() == 0
     torch.cuda.synchronize()
@@ -152,7 +153,7 @@ def main():
     key = ((xcc * 8 + se) * 2 + sh) * 16 + cu
     t0 = st[:, 0].min()
     print("workgroups %d, distinct CUs %d, kernel span %d cycles" % (len(st), len(np.unique(key)), st[:, 61].max() - t0))
-    nch = (cinp + 7) // 8
+    nch = (cinp + 7) // 8 if cout > 16 else (cinp + 15) // 16
     dur = {"load+stash": [], "barrier": [], "mfma": [], "epilogue": [], "wg": []}
     for r in st:
         for c in range(nch):

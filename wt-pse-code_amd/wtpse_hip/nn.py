@@ -504,9 +504,36 @@ def unet_bwd(net, t, dfeat, need_dx1=True):
 
 
 # ---- 1x1 heads: conv, ReLU, conv, ReLU, conv (algorithms.py:1006-1012) / conv, ReLU, conv (:1199-1200) -------------
+def _head_fusable(seq, idxs, x):
+    """The fused kernels (csrc/head.hip) cover 32 -> 32 -> 8 [-> nc <= 4] heads on maps with H*W % 32 == 0 whose parameters
+    sit back to back in the flat buffers (they do: registration order); anything else takes the per-layer path."""
+    ls = [seq[i] for i in idxs]
+    if len(ls) not in (2, 3) or (ls[0].cin, ls[0].cout, ls[1].cin, ls[1].cout) != (32, 32, 32, 8):
+        return None
+    if len(ls) == 3 and not (ls[2].cin == 8 and 1 <= ls[2].cout <= 4):
+        return None
+    if any(l.k != 1 for l in ls) or (x.t.shape[2] * x.t.shape[3]) % 32 != 0:
+        return None
+    root = ls[0]._root
+    off = root._offsets[root._pindex[id(ls[0].weight)]]
+    for l in ls:
+        for prm in (l.weight, l.bias):
+            if root._offsets[root._pindex[id(prm)]] != off:
+                return None
+            off += prm.numel()
+    return ls
+
+
 def head_fwd(seq, x, idxs, want_tape=True):
     t = Tape()
     t.x, t.acts = as_act(x), []
+    ls = _head_fusable(seq, idxs, t.x)
+    t.fused = ls is not None
+    if t.fused:
+        w3, b3 = (ls[2].weight, ls[2].bias) if len(ls) == 3 else (None, None)
+        out, t.h1, t.h2 = ops.head_fwd(t.x.t, t.x.pro, t.x.relu, ls[0].weight, ls[0].bias, ls[1].weight, ls[1].bias, w3, b3,
+                                       want_tape)
+        return out, t
     h = t.x
     for n, i in enumerate(idxs):
         last = n == len(idxs) - 1
@@ -517,6 +544,15 @@ def head_fwd(seq, x, idxs, want_tape=True):
 
 def head_bwd(seq, t, d, idxs):
     """-> gradient wrt the activated head input."""
+    if t.fused:
+        ls = [seq[i] for i in idxs]
+        root = ls[0]._root
+        views = [root.gview(prm) for l in ls for prm in (l.weight, l.bias)]      # marks them reached; contiguous range
+        total = sum(v.numel() for v in views)
+        off = root._offsets[root._pindex[id(ls[0].weight)]]
+        dparams = root._gtarget[off:off + total]
+        return ops.head_bwd(d, t.x.t, t.x.pro, t.x.relu, t.h1, t.h2, ls[0].weight, ls[1].weight,
+                            ls[2].weight if len(ls) == 3 else None, dparams)
     for n in reversed(range(len(idxs))):
         layer = seq[idxs[n]]
         inp = t.x if n == 0 else t.acts[n - 1]

@@ -222,6 +222,38 @@ def zero_(t):
     return t
 
 
+# ----------------------------------------------------------------------------------------------- fused 1x1 heads
+def head_fwd(x, pro, relu, w1, b1, w2, b2, w3, b3, want_tape=True):
+    """32 -> 32 (ReLU) -> 8 [-> (ReLU) -> nc] in one kernel.  -> (out, h1 or None, h2): out is y [B,nc,H,W] for a
+    three-layer head (w3 given), the 8-channel h2 for a two-layer head."""
+    _chk(x, "x"); _chk(pro, "pro")
+    B, C, H, W = x.shape
+    three = w3 is not None
+    nc = w3.shape[0] if three else 0
+    h1 = torch.empty((B, 32, H, W), dtype=torch.float32, device=x.device) if want_tape else None
+    h2 = torch.empty((B, 8, H, W), dtype=torch.float32, device=x.device) if (want_tape or not three) else None
+    y = torch.empty((B, nc, H, W), dtype=torch.float32, device=x.device) if three else None
+    lib().call("wtpse_head_fwd", ptr(x), ptr(pro), int(bool(relu)), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3), nc,
+               ptr(h1), ptr(h2), ptr(y), B, H * W, stream_ptr())
+    return (y if three else h2), h1, h2
+
+
+def head_bwd(dy, x, pro, relu, h1, h2, w1, w2, w3, dparams, accumulate=False):
+    """-> dx (gradient wrt the activated input); the parameter gradients land in `dparams`, the contiguous flat-buffer
+    range (dW1, db1, dW2, db2[, dW3, db3])."""
+    _chk(dy, "dy"); _chk(x, "x"); _chk(h1, "h1"); _chk(h2, "h2")
+    B, C, H, W = x.shape
+    nc = w3.shape[0] if w3 is not None else 0
+    L = lib()
+    ns = 1024 + 32 + 256 + 8 + 9 * nc
+    assert dparams.numel() == ns and dparams.is_contiguous()
+    slab = workspace("head_slab", L.query("wtpse_head_slabs", B, H * W) * ns, x.device)
+    dx = torch.empty_like(x)
+    L.call("wtpse_head_bwd", ptr(dy), ptr(x), ptr(pro), int(bool(relu)), ptr(h1), ptr(h2), ptr(w1), ptr(w2), ptr(w3), nc,
+           ptr(dx), ptr(slab), ptr(dparams), int(accumulate), B, H * W, stream_ptr())
+    return dx
+
+
 # ----------------------------------------------------------------------------------------------- attention / sampling
 def attn_fuse_fwd(z, wb_ptr, emb, coef, want_att=True, want_pre=False, want_mask=False):
     _chk(z, "z"); _chk(emb, "emb")
