@@ -106,6 +106,11 @@ int wtpse_maxpool2_bwd(const float* x, const float* pro, int relu, const float* 
 /* bilinear x2, align_corners=False; H, W are the INPUT sizes. */
 int wtpse_upsample2x_fwd(const float* x, const float* pro, int relu, float* out, int B, int C, int H, int W, void* stream);
 int wtpse_upsample2x_bwd(const float* dout, float* dx, int accumulate, int B, int C, int H, int W, void* stream);
+/* The same with the train-mode BatchNorm statistics of the OUTPUT: stats [wtpse_upsample2x_stats_blocks(B,H,W)][C][2]
+ * per-workgroup (sum, sum of squares), the layout wtpse_bn_finalize takes.  Used where the 1x1 conv of a ConvU block
+ * (algorithms.py:949-951: upsample -> conv2 -> bn2) runs in front of the upsampling instead (the two commute). W even. */
+int wtpse_upsample2x_fwd_stats(const float* x, float* out, float* stats, int B, int C, int H, int W, void* stream);
+int wtpse_upsample2x_stats_blocks(int B, int H, int W);
 
 /* F.interpolate(size=(Ho,Wo), mode="bilinear"), align_corners=False: validation resize of the logits (Trainer.py:206-209). */
 int wtpse_resize_bilinear(const float* x, float* out, int B, int C, int H, int W, int Ho, int Wo, void* stream);

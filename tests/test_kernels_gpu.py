@@ -205,6 +205,12 @@ def test_pool_and_upsample(shape):
     du = rnd(*u.shape, seed=35)
     u.backward(du)
     close(o.upsample2x_fwd(x2.detach().to(DEV)), u, what="up fwd")
+    if shape[3] % 2 == 0:   # the BatchNorm-statistics variant (conv2 moved in front of the upsampling)
+        uo, st = o.upsample2x_fwd_stats(x2.detach().to(DEV))
+        close(uo, u, what="up fwd (stats variant)")
+        tot = st.double().sum(0).cpu()
+        close(tot[:, 0], u.detach().double().sum((0, 2, 3)), rtol=1e-5, atol=1e-3, what="up stat sum")
+        close(tot[:, 1], (u.detach().double() ** 2).sum((0, 2, 3)), rtol=1e-5, atol=1e-3, what="up stat sumsq")
     close(o.upsample2x_bwd(du.to(DEV)), x2.grad, rtol=1e-4, atol=1e-5, what="up bwd")
 
 

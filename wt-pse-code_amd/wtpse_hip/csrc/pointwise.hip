@@ -159,11 +159,17 @@ __device__ __forceinline__ float up_w(int d, int n, int k) {  // weight of sourc
 // 4 consecutive outputs of one row per thread (W even): 2 x 4 input loads, one 16-byte store; bitwise the same
 // expression tree as the scalar kernel / ATen (weights 0.25/0.75, (1,0) at the clamped first column and row);
 // one plane per blockIdx.y, 32-bit index arithmetic
+// stats (optional): [B * gridDim.x][C][2] per-workgroup (sum, sum of squares) of the OUTPUT, the train-mode BatchNorm
+// statistics of a 1x1 conv that was moved in front of the upsampling (see convu_fwd in nn.py)
 __global__ __launch_bounds__(256) void upsample2x_fwd4_v_k(const float* __restrict__ x, const float* __restrict__ pro, int relu,
-                                                           float* __restrict__ out, int BC, int C, int H, int W) {
+                                                           float* __restrict__ out, float* __restrict__ stats, int BC, int C,
+                                                           int H, int W) {
+  __shared__ float sh4[4];
   const int Ho = 2 * H, Wo = 2 * W, W2 = W / 2;
-  const int j = blockIdx.x * 256 + threadIdx.x;   // over Ho*(Wo/4)
-  if (j >= Ho * W2) return;
+  const int jj = blockIdx.x * 256 + threadIdx.x;   // over Ho*(Wo/4)
+  const bool valid = jj < Ho * W2;
+  if (!valid && !stats) return;
+  const int j = valid ? jj : 0;
   const int k = j % W2, yo = j / W2;
   int y0, y1;
   float ly;
@@ -187,7 +193,18 @@ __global__ __launch_bounds__(256) void upsample2x_fwd4_v_k(const float* __restri
     o.y = (1.f - ly) * ha[1] + ly * hb[1];
     o.z = (1.f - ly) * ha[2] + ly * hb[2];
     o.w = (1.f - ly) * ha[3] + ly * hb[3];
-    *reinterpret_cast<float4*>(out + (size_t)bc * Ho * Wo + (size_t)yo * Wo + 4 * k) = o;
+    if (valid) *reinterpret_cast<float4*>(out + (size_t)bc * Ho * Wo + (size_t)yo * Wo + 4 * k) = o;
+    if (stats) {
+      float s1 = valid ? (o.x + o.y) + (o.z + o.w) : 0.f;
+      float s2 = valid ? (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w) : 0.f;
+      s1 = block_sum(s1, sh4);
+      s2 = block_sum(s2, sh4);
+      if (threadIdx.x == 0) {
+        float* dst = stats + (((size_t)(bc / C) * gridDim.x + blockIdx.x) * C + c) * 2;
+        dst[0] = s1;
+        dst[1] = s2;
+      }
+    }
   }
 }
 
@@ -621,9 +638,16 @@ extern "C" int wtpse_upsample2x_fwd(const float* x, const float* pro, int relu, 
   WTPSE_REQUIRE(x && out && B > 0 && C > 0 && H > 0 && W > 0);
   long long total = (long long)B * C * H * W * 4;
   if (W % 2 == 0 && W >= 2 && (((uintptr_t)out) & 15) == 0)
-    hipLaunchKernelGGL(upsample2x_fwd4_v_k, PLANE_GRID(2 * H * (W / 2), B * C), dim3(256), 0, ST, x, pro, relu, out, B * C, C, H, W);
+    hipLaunchKernelGGL(upsample2x_fwd4_v_k, PLANE_GRID(2 * H * (W / 2), B * C), dim3(256), 0, ST, x, pro, relu, out, nullptr, B * C, C, H, W);
   else
     hipLaunchKernelGGL(upsample2x_fwd_k, GRID1(total), dim3(256), 0, ST, x, pro, relu, out, C, H, W, total);
+  return wtpse_status();
+}
+extern "C" int wtpse_upsample2x_stats_blocks(int B, int H, int W) { return B * ((2 * H * (W / 2) + 255) / 256); }
+extern "C" int wtpse_upsample2x_fwd_stats(const float* x, float* out, float* stats, int B, int C, int H, int W, void* stream) {
+  WTPSE_REQUIRE(x && out && stats && B > 0 && C > 0 && H > 0 && W >= 2 && W % 2 == 0 && (((uintptr_t)out) & 15) == 0);
+  WTPSE_REQUIRE(B * C < 32768);   // one plane per blockIdx.y: the statistics rows are indexed by gridDim.x
+  hipLaunchKernelGGL(upsample2x_fwd4_v_k, PLANE_GRID(2 * H * (W / 2), B * C), dim3(256), 0, ST, x, nullptr, 0, out, stats, B * C, C, H, W);
   return wtpse_status();
 }
 extern "C" int wtpse_upsample2x_bwd(const float* dout, float* dx, int accumulate, int B, int C, int H, int W, void* stream) {

@@ -454,13 +454,54 @@ def convd_bwd(blk, t, dz, dx_accum=None, need_dx=True):
 
 
 # ---- ConvU (algorithms.py:941-962) ---------------------------------------------------------------------------
+# The reference runs  upsample(x2, bilinear) -> conv2 (1x1) -> bn2 -> ReLU  (algorithms.py:949-951).  A 1x1 convolution is
+# an affine map per pixel and bilinear interpolation an affine combination of pixels with weights summing to 1, so the
+# two commute exactly in real arithmetic: conv2(up(x)) = up(conv2(x)).  The conv therefore runs on the low-resolution
+# tensor (a quarter of the pixels; forward, data gradient and weight gradient alike) and the upsampling moves half as
+# many channels; BatchNorm sees the same tensor as in the reference and takes its batch statistics from the upsampling
+# kernel.  In fp32 the result differs from the reference order by rounding only (~1e-7 relative).
+def upbn_fwd(conv, bn, a0, training, want_tape=True):
+    root = conv._root
+    z, _ = _conv(conv, a0, None, False, False)                 # low resolution, pre-BatchNorm
+    if training:
+        y, stats = ops.upsample2x_fwd_stats(z)
+        B, _, H, W = y.shape
+        if root._dp is not None and root._dp.bn_sync:
+            stats, count = root._dp.sync_bn_stats(stats, B * H * W)
+        else:
+            count = B * H * W
+        ss, mean, invstd = ops.bn_finalize(stats, count, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                           bn.num_batches_tracked)
+    else:
+        y = ops.upsample2x_fwd(z)
+        ss = ops.bn_eval_coeffs(bn.weight, bn.bias, bn.running_mean, bn.running_var)
+        mean = invstd = None
+    out = Act(y, ss, True)
+    if not want_tape:
+        return out, None
+    t = Tape()
+    t.a0, t.a1, t.y, t.ss, t.mean, t.invstd, t.relu = a0, None, y, ss, mean, invstd, True
+    return out, t
+
+
+def upbn_bwd(conv, bn, t, dz):
+    """-> gradient wrt the (activated, low-resolution) conv input."""
+    root = conv._root
+    if root._dp is not None and root._dp.bn_sync:
+        dy = root._dp.bn_bwd_synced(dz, t, bn, root)
+    else:
+        dy = ops.bn_bwd(dz, t.y, t.ss, t.relu, bn.weight, t.mean, t.invstd, root.gview(bn.weight), root.gview(bn.bias))
+    dzl = ops.upsample2x_bwd(dy)
+    _wgrad(conv, dzl, t.a0, None, with_bias=False)             # bias in front of a train-mode BatchNorm: see convbn_bwd
+    return _dgrad(conv, dzl)[0]
+
+
 def convu_fwd(blk, x, prev, training, want_tape=True):
     t = Tape()
     x = as_act(x)
     if not blk.first:
         x, t.c1 = convbn_fwd(blk.conv1, blk.bn1, x, None, True, training, want_tape)
-    u = ops.upsample2x_fwd(x.t, x.pro, x.relu)
-    y, t.c2 = convbn_fwd(blk.conv2, blk.bn2, u, None, True, training, want_tape)
+    y, t.c2 = upbn_fwd(blk.conv2, blk.bn2, x, training, want_tape)
     out, t.c3 = convbn_fwd(blk.conv3, blk.bn3, prev, y, True, training, want_tape)
     return out, t
 
@@ -468,8 +509,7 @@ def convu_fwd(blk, x, prev, training, want_tape=True):
 def convu_bwd(blk, t, dout):
     """-> (dx, dprev); both wrt the activated tensors."""
     dprev, dy = convbn_bwd(blk.conv3, blk.bn3, t.c3, dout)
-    du, _ = convbn_bwd(blk.conv2, blk.bn2, t.c2, dy)
-    dx = ops.upsample2x_bwd(du)
+    dx = upbn_bwd(blk.conv2, blk.bn2, t.c2, dy)
     if not blk.first:
         dx, _ = convbn_bwd(blk.conv1, blk.bn1, t.c1, dx)
     return dx, dprev

@@ -186,6 +186,17 @@ def upsample2x_fwd(x, pro=None, relu=False):
     return out
 
 
+def upsample2x_fwd_stats(x):
+    """-> (out, stats [nblk, C, 2]): bilinear x2 plus the (sum, sum of squares) partials of the output."""
+    _chk(x, "x")
+    B, C, H, W = x.shape
+    out = torch.empty((B, C, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
+    nblk = lib().query("wtpse_upsample2x_stats_blocks", B, H, W)
+    stats = torch.empty((nblk, C, 2), dtype=torch.float32, device=x.device)
+    lib().call("wtpse_upsample2x_fwd_stats", ptr(x), ptr(out), ptr(stats), B, C, H, W, stream_ptr())
+    return out, stats
+
+
 def upsample2x_bwd(dout):
     _chk(dout, "dout")
     B, C, Ho, Wo = dout.shape
