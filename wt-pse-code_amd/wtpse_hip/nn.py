@@ -12,6 +12,7 @@ Reference blocks mirrored here: ConvD / ConvU (algorithms.py:877-962), DoubleCon
 (:416-428,1080-1117), ShapeVariationalDist_y_x (:979-1075), attention_layer (:1120-1129), heads (:1006-1012,1199-1201).
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -284,6 +285,9 @@ class HipNet(nn.Module):
         return self._gtarget[off:off + p.numel()]
 
     def end_backward(self):
+        if self.__dict__.get("_side_busy"):
+            torch.cuda.current_stream().wait_stream(_side_stream(self._gflat.device))
+            object.__setattr__(self, "_side_busy", False)
         if self._dp is not None:
             self._dp.allreduce_grads(self, self._gtarget)
         direct = self._gtarget is self._gflat
@@ -374,6 +378,38 @@ def _dgrad(layer, dy, split=None, mask_ref=None):
                         mask_ref)[:2]
 
 
+# The weight gradient of a conv+BatchNorm block depends only on dy and the saved input, and nothing downstream in the
+# backward pass reads it, so it runs on a side stream next to the data gradients that follow (small-grid launches of the
+# deep levels leave CUs idle that the other stream's workgroups fill).  end_backward() joins the side stream.
+_SIDE = {}
+WGRAD_SIDE_STREAM = os.environ.get("WTPSE_WGRAD_STREAM", "1") != "0"
+
+
+def _side_stream(device):
+    st = _SIDE.get(device)
+    if st is None:
+        st = _SIDE[device] = torch.cuda.Stream(device=device)
+    return st
+
+
+def _wgrad_side(layer, dy, a0, a1=None):
+    """_wgrad(..., with_bias=False) on the side stream.  dy must not be written again by the caller (it is a fresh
+    BatchNorm-backward result in both callers)."""
+    root = layer._root
+    if not WGRAD_SIDE_STREAM:
+        return _wgrad(layer, dy, a0, a1, with_bias=False)
+    main = torch.cuda.current_stream()
+    side = _side_stream(dy.device)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        _wgrad(layer, dy, a0, a1, with_bias=False)
+    a0 = as_act(a0)
+    for t in (dy, a0.t, a0.pro) + ((as_act(a1).t, as_act(a1).pro) if a1 is not None else ()):
+        if t is not None:
+            t.record_stream(side)       # the caching allocator must not hand these out again before the side stream is done
+    object.__setattr__(root, "_side_busy", True)
+
+
 def _wgrad(layer, dy, a0, a1=None, with_bias=True):
     root = layer._root
     a0 = as_act(a0)
@@ -419,7 +455,7 @@ def convbn_bwd(conv, bn, t, dz, need_dx=True):
         dy = ops.bn_bwd(dz, t.y, t.ss, t.relu, bn.weight, t.mean, t.invstd, root.gview(bn.weight), root.gview(bn.bias))
     # the conv bias in front of a train-mode BatchNorm has an exactly-zero gradient (sum of dy over the batch
     # vanishes); the reference carries rounding noise there. It is left at 0.
-    _wgrad(conv, dy, t.a0, t.a1, with_bias=False)
+    _wgrad_side(conv, dy, t.a0, t.a1)
     if not need_dx:
         return None, None
     split = t.a0.t.shape[1] if t.a1 is not None else None
@@ -492,7 +528,7 @@ def upbn_bwd(conv, bn, t, dz):
     else:
         dy = ops.bn_bwd(dz, t.y, t.ss, t.relu, bn.weight, t.mean, t.invstd, root.gview(bn.weight), root.gview(bn.bias))
     dzl = ops.upsample2x_bwd(dy)
-    _wgrad(conv, dzl, t.a0, None, with_bias=False)             # bias in front of a train-mode BatchNorm: see convbn_bwd
+    _wgrad_side(conv, dzl, t.a0, None)                         # bias in front of a train-mode BatchNorm: see convbn_bwd
     return _dgrad(conv, dzl)[0]
 
 
