@@ -117,6 +117,15 @@ def main():
         dpar = torch.zeros(1320 + 9, device=DEV)
         med, _ = timeit(lambda: ops.head_bwd(dy, x, pro, True, h1, h2, w1, w2, w3, dpar), a.reps)
         print("head_bwd 32-32-8-1                         %7.1f us  %6.0f GB/s (105 floats/px)" % (med, 105 * 4 * px / med / 1e3))
+    if a.only in ("", "bn"):
+        for (C, H) in ((16, 256), (32, 256), (32, 128), (64, 64), (256, 16)):
+            y = torch.randn(B, C, H, H, device=DEV)
+            dz = torch.randn_like(y)
+            ss = torch.rand(C, 2, device=DEV); gamma = torch.rand(C, device=DEV) + 0.5
+            mean = torch.zeros(C, device=DEV); invstd = torch.ones(C, device=DEV)
+            dg = torch.zeros(C, device=DEV); db = torch.zeros(C, device=DEV)
+            med, _ = timeit(lambda: ops.bn_bwd(dz, y, ss, True, gamma, mean, invstd, dg, db), a.reps)
+            print("bn_bwd (reduce+finalize+apply) [%d,%d,%d,%d]  %7.1f us  %6.0f GB/s (5 passes)" % (B, C, H, H, med, 5 * y.numel() * 4.0 / med / 1e3))
     if a.only in ("", "pw"):
         y = torch.randn(B, 16, 256, 256, device=DEV)
         ss = torch.rand(16, 2, device=DEV)

@@ -198,9 +198,11 @@ class HipNet(nn.Module):
         f = self._flat
         if f is None:
             return False
-        p0 = next(self.parameters())
-        return p0.device == f.device and p0.data_ptr() == f.data_ptr() and all(
-            p.data_ptr() == f.data_ptr() + 4 * o for p, o in zip(self.parameters(), self._offsets))
+        # first and last parameter still views of the flat buffer (a `.to()` / `load_state_dict(assign=True)` replaces all
+        # of them); walking every parameter on every entry cost ~5 ms of host time per step
+        p0, pl = self._plist[0], self._plist[-1]
+        return (p0.device == f.device and p0.data_ptr() == f.data_ptr()
+                and pl.data_ptr() == f.data_ptr() + 4 * self._offsets[-1])
 
     def _flatten(self):
         params = list(self.parameters())
@@ -222,6 +224,7 @@ class HipNet(nn.Module):
         object.__setattr__(self, "_flat", flat)
         object.__setattr__(self, "_offsets", offsets)
         object.__setattr__(self, "_pindex", {id(p): i for i, p in enumerate(params)})
+        object.__setattr__(self, "_plist", params)
         object.__setattr__(self, "_gflat", torch.zeros(total, dtype=torch.float32, device=dev))
         object.__setattr__(self, "_gwork", None)
         object.__setattr__(self, "_packed", torch.empty(self._packed_size, dtype=torch.float32, device=dev))
@@ -269,7 +272,7 @@ class HipNet(nn.Module):
         """Choose the buffer this backward writes into: the attached flat gradient when every .grad is None
         (the normal zero_grad(set_to_none=True) flow), a work buffer otherwise (accumulation semantics)."""
         self._touched.clear()
-        clean = all(p.grad is None for p in self.parameters())
+        clean = all(p.grad is None for p in self._plist)
         if clean:
             object.__setattr__(self, "_gtarget", self._gflat)
         else:

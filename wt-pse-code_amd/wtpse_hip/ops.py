@@ -7,7 +7,14 @@ from .lib import lib
 _WS = {}
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr():
+    """Raw hipStream_t of torch's current stream (the C getter: torch.cuda.current_stream() builds a Python Stream object
+    on every call, ~8 us, and this runs once per launch)."""
+    if _RAW_STREAM is not None:
+        return _RAW_STREAM(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
