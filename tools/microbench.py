@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--only", default="")
+    ap.add_argument("--no-pro", action="store_true", help="time forward / weight gradient without the BatchNorm prologue")
     ap.add_argument("--filter", default="")
     a = ap.parse_args()
     B = a.batch
@@ -72,11 +73,17 @@ def main():
         bias = torch.zeros(co, device=DEV)
         packed, wd_off = pack(w)
         dy = torch.randn(B, co, H, H, device=DEV)
+        # as inside a step: the inputs of all but the first layer carry the BatchNorm-apply + ReLU prologue
+        # (forward and weight gradient; the data gradient reads a plain dY).  --no-pro times the bare kernels.
+        use_pro = not a.no_pro and c0 > 4
+        pro0 = torch.rand(c0, 2, device=DEV) if use_pro else None
+        pro1 = torch.rand(c1, 2, device=DEV) if (use_pro and c1) else None
+        relu = 3 if use_pro else 0
         flops = 2.0 * (c0 + c1) * co * k * k * H * H * B
         flops_tot += flops
         line = "%-12s %3d+%-3d->%-3d k%d @%3d  " % (name, c0, c1, co, k, H)
         if a.only in ("", "fwd"):
-            med, mn = timeit(lambda: ops.conv_fwd(x0, x1, packed.data_ptr(), bias, co, k, want_stats=True), a.reps)
+            med, mn = timeit(lambda: ops.conv_fwd(x0, x1, packed.data_ptr(), bias, co, k, pro0, relu, want_stats=True, pro1=pro1), a.reps)
             tot["fwd"] += med
             line += "fwd %7.1f us %5.1f TF | " % (med, flops / med / 1e6)
         if a.only in ("", "dgrad") and c0 + c1 > 4:
@@ -86,7 +93,7 @@ def main():
             line += "dgrad %7.1f us %5.1f TF | " % (med, flops / med / 1e6)
         if a.only in ("", "wgrad"):
             dw = torch.empty_like(w)
-            med, mn = timeit(lambda: ops.conv_wgrad(dy, x0, x1, k, dw, None), a.reps)
+            med, mn = timeit(lambda: ops.conv_wgrad(dy, x0, x1, k, dw, None, pro0, relu, False, pro1), a.reps)
             tot["wgrad"] += med
             line += "wgrad %7.1f us %5.1f TF" % (med, flops / med / 1e6)
         print(line, flush=True)
