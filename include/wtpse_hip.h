@@ -170,6 +170,20 @@ int wtpse_head_bwd(const float* dy, const float* x, const float* pro, int pro_re
                    int accumulate, int B, int HW, void* stream);
 int wtpse_head_slabs(int B, int HW);
 
+/* ---- device-side training input pipeline (csrc/pipeline.hip) ---------------------------------- */
+/* One pass of Pillow's 8-bit separable resampling (the engine behind the reference's Image.resize calls,
+ * custom_transforms.py:342-346,375-391).  in [N][Hin][Win][C] uint8; vertical = 0: out [N][Hin][L][C], vertical = 1:
+ * out [N][L][Win][C].  bounds [T][L][2] = (first source index, tap count) and kk [T][L][ksize] = 22-bit fixed-point
+ * coefficients as Pillow's precompute_coeffs / normalize_coeffs_8bpc produce them; sample n reads table tab[n]
+ * (tab NULL: table 0 for every sample). */
+int wtpse_resample_u8(const unsigned char* in, unsigned char* out, const int* bounds, const int* kk, const int* tab, int ksize,
+                      int N, int Hin, int Win, int C, int L, int vertical, void* stream);
+/* Normalize_tf + ToTensor (custom_transforms.py:455-499,581-599) on img [N][S][S][3] uint8 and the resized disc mask od
+ * [N][S][S] uint8, read through per-sample index tables xidx / yidx [N][S] (NEAREST resize + crop of the mask):
+ * image [N][3][S][S] = img / 127.5 - 1, od_out [N][1][S][S] = (mask <= 200), oc_out = (mask <= 50). */
+int wtpse_input_finish(const unsigned char* img, const unsigned char* od, const int* xidx, const int* yidx, float* image,
+                       float* od_out, float* oc_out, int N, int S, void* stream);
+
 /* ---- small utilities ------------------------------------------------------------------------------------------- */
 int wtpse_relu_mask(const float* dz, const float* ref, float* dy, int accumulate, long long n, void* stream);
 int wtpse_axpy(float* dst, const float* src, float alpha, long long n, void* stream);

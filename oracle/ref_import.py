@@ -52,6 +52,23 @@ def load():
     return hparams_registry, algorithms, shape_networks
 
 
+def load_transforms():
+    """The reference's custom_transforms module.  Its top-level imports pull in cv2 (not installed) and scipy/matplotlib
+    names the five classes of the training pipeline never touch: cv2 is shimmed with an empty module."""
+    import matplotlib
+    matplotlib.use("Agg")
+    if "cv2" not in sys.modules:
+        sys.modules["cv2"] = types.ModuleType("cv2")
+    sys.modules.pop("custom_transforms", None)
+    sys.path.insert(0, REFERENCE_ROOT)
+    try:
+        import custom_transforms
+    finally:
+        sys.path.remove(REFERENCE_ROOT)
+    assert os.path.dirname(os.path.abspath(custom_transforms.__file__)) == os.path.abspath(REFERENCE_ROOT)
+    return custom_transforms
+
+
 @contextlib.contextmanager
 def replay_noise(queue):
     """Within the block, ``torch.randn_like(t)`` pops the next fixture tensor and
