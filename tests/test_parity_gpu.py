@@ -251,6 +251,47 @@ def test_seg_only_vs_golden(golden_dir):
     close(pred, g["segonly_pred"], atol=TOL)
 
 
+@pytest.mark.parametrize("shape,first", [((2, 64, 8, 10), False), ((2, 64, 5, 9), False), ((3, 64, 6, 7), True)])
+def test_convu_both_orders_vs_oracle(shape, first):
+    """ConvU runs its 1x1 conv in front of the upsampling when the width is even (they commute) and in the reference's
+    order otherwise: both against the oracle's ConvU (reference order) in fp64."""
+    from wtpse_hip import nn as E
+    B, C, H, W = shape
+
+    class Holder(E.HipNet):
+        def __init__(self, blk):
+            super().__init__()
+            self.blk = blk
+            self._finish_init()
+
+    planes = C if first else C // 2                      # a non-first block halves its input with conv1 first
+    h = Holder(E.ConvUBlock(planes, first=first)).to(DEV)
+    fill_state_dict(h.blk, SEED_W + 77)
+    h.ensure_ready(repack=True)
+    x = make_noise(310, shape)
+    prev = make_noise(410, (B, planes // 2, 2 * H, 2 * W))
+    y, tape = E.convu_fwd(h.blk, x.to(DEV), prev.to(DEV), True)
+    assert tape.swapped == (W % 2 == 0)
+    y = y.dense()
+    sd = {"b." + k: v.detach().cpu().double().clone().requires_grad_(v.is_floating_point() and not O.is_buffer(k))
+          for k, v in h.blk.state_dict().items()}
+    xr, pr = x.double().requires_grad_(True), prev.double().requires_grad_(True)
+    yr = O.conv_u(sd, "b.", xr, pr, first, True)
+    close(y, yr, rtol=1e-4, atol=1e-4, what="y")
+    dy = make_noise(510, tuple(y.shape))
+    yr.backward(dy.double())
+    h.begin_backward()
+    dx, dprev = E.convu_bwd(h.blk, tape, dy.to(DEV))
+    h.end_backward()
+    close(dx, xr.grad, rtol=2e-3, atol=2e-4 * float(xr.grad.abs().max()), what="dx")
+    close(dprev, pr.grad, rtol=2e-3, atol=2e-4 * float(pr.grad.abs().max()), what="dprev")
+    for k, p in h.blk.named_parameters():
+        if is_prebn_bias(k):
+            continue
+        ref = sd["b." + k].grad
+        close(p.grad, ref, rtol=5e-3, atol=5e-4 * float(ref.abs().max()) + 1e-7, what=k)
+
+
 @pytest.mark.parametrize("B,pb,H", [(3, 1, 32), (6, 2, 32), (6, 2, 64)])
 def test_gradients_calibrated(B, pb, H):
     """Every parameter gradient of call A (seg net + teacher + WT loss) and call B (student) against the oracle

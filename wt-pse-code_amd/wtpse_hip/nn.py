@@ -540,7 +540,13 @@ def convu_fwd(blk, x, prev, training, want_tape=True):
     x = as_act(x)
     if not blk.first:
         x, t.c1 = convbn_fwd(blk.conv1, blk.bn1, x, None, True, training, want_tape)
-    y, t.c2 = upbn_fwd(blk.conv2, blk.bn2, x, training, want_tape)
+    B, _, H, W = x.t.shape
+    t.swapped = W % 2 == 0 and B * blk.conv2.cout < 32768       # what wtpse_upsample2x_fwd_stats takes
+    if t.swapped:
+        y, t.c2 = upbn_fwd(blk.conv2, blk.bn2, x, training, want_tape)
+    else:                                                        # odd widths: the reference order
+        u = ops.upsample2x_fwd(x.t, x.pro, x.relu)
+        y, t.c2 = convbn_fwd(blk.conv2, blk.bn2, u, None, True, training, want_tape)
     out, t.c3 = convbn_fwd(blk.conv3, blk.bn3, prev, y, True, training, want_tape)
     return out, t
 
@@ -548,7 +554,11 @@ def convu_fwd(blk, x, prev, training, want_tape=True):
 def convu_bwd(blk, t, dout):
     """-> (dx, dprev); both wrt the activated tensors."""
     dprev, dy = convbn_bwd(blk.conv3, blk.bn3, t.c3, dout)
-    dx = upbn_bwd(blk.conv2, blk.bn2, t.c2, dy)
+    if t.swapped:
+        dx = upbn_bwd(blk.conv2, blk.bn2, t.c2, dy)
+    else:
+        du, _ = convbn_bwd(blk.conv2, blk.bn2, t.c2, dy)
+        dx = ops.upsample2x_bwd(du)
     if not blk.first:
         dx, _ = convbn_bwd(blk.conv1, blk.bn1, t.c1, dx)
     return dx, dprev
