@@ -499,6 +499,9 @@ def convd_bwd(blk, t, dz, dx_accum=None, need_dx=True):
 # tensor (a quarter of the pixels; forward, data gradient and weight gradient alike) and the upsampling moves half as
 # many channels; BatchNorm sees the same tensor as in the reference and takes its batch statistics from the upsampling
 # kernel.  In fp32 the result differs from the reference order by rounding only (~1e-7 relative).
+CONVU_CONV_FIRST = os.environ.get("WTPSE_CONVU_REFERENCE_ORDER", "0") != "1"    # =1: upsample -> conv2, as written in the reference
+
+
 def upbn_fwd(conv, bn, a0, training, want_tape=True):
     root = conv._root
     z, _ = _conv(conv, a0, None, False, False)                 # low resolution, pre-BatchNorm
@@ -541,7 +544,7 @@ def convu_fwd(blk, x, prev, training, want_tape=True):
     if not blk.first:
         x, t.c1 = convbn_fwd(blk.conv1, blk.bn1, x, None, True, training, want_tape)
     B, _, H, W = x.t.shape
-    t.swapped = W % 2 == 0 and B * blk.conv2.cout < 32768       # what wtpse_upsample2x_fwd_stats takes
+    t.swapped = CONVU_CONV_FIRST and W % 2 == 0 and B * blk.conv2.cout < 32768   # what wtpse_upsample2x_fwd_stats takes
     if t.swapped:
         y, t.c2 = upbn_fwd(blk.conv2, blk.bn2, x, training, want_tape)
     else:                                                        # odd widths: the reference order
