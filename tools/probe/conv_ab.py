@@ -1,10 +1,33 @@
 #!/usr/bin/env python3
 """Bitwise A/B of wtpse_conv_fwd between two builds of csrc/conv.hip (e.g. HEAD vs working tree) on random inputs.
-    python tools/probe/conv_ab.py tools/probe/_build/libconv_old.so wt-pse-code_amd/wtpse_hip/libwtpse_hip.so"""
+
+    python tools/probe/conv_ab.py --build-rev HEAD        # in the build container: csrc/conv.hip of that git revision
+                                                          # -> tools/probe/_build/libconv_old.so (travels with gpurun)
+    gpurun -- python tools/probe/conv_ab.py tools/probe/_build/libconv_old.so wt-pse-code_amd/wtpse_hip/libwtpse_hip.so
+
+Every fast-path rewrite of the forward kernel in round 1 was accepted only when this printed "bitwise identical"
+(outputs and BatchNorm partials) against the previous commit."""
 import ctypes
 import sys
 
 import torch
+
+if len(sys.argv) > 2 and sys.argv[1] == "--build-rev":
+    import os
+    import subprocess
+    import tempfile
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(os.path.dirname(here))
+    tmp = tempfile.mkdtemp()
+    for f in ("conv.hip", "common.h"):
+        open(os.path.join(tmp, f), "wb").write(subprocess.check_output(
+            ["git", "-C", root, "show", "%s:wt-pse-code_amd/wtpse_hip/csrc/%s" % (sys.argv[2], f)]))
+    os.makedirs(os.path.join(here, "_build"), exist_ok=True)
+    out = os.path.join(here, "_build", "libconv_old.so")
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", tmp,
+                           os.path.join(tmp, "conv.hip"), "-o", out])
+    print("built", out, "from", sys.argv[2])
+    sys.exit(0)
 
 vp = ctypes.c_void_p
 dev = torch.device("cuda:0")
