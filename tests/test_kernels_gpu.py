@@ -147,7 +147,8 @@ def test_conv_dgrad_relu_mask(case):
     close(d0, want, what="masked dgrad")
 
 
-@pytest.mark.parametrize("shape,relu", [((4, 16, 16, 32), True), ((3, 32, 9, 7), False), ((2, 64, 4, 4), True)])
+@pytest.mark.parametrize("shape,relu", [((4, 16, 16, 32), True), ((3, 32, 9, 7), False), ((2, 64, 4, 4), True),
+                                        ((4, 128, 8, 8), True), ((2, 256, 16, 16), False), ((32, 96, 32, 32), False)])   # last three: one-launch backward
 def test_batchnorm_train(shape, relu):
     o = ops()
     B, C, H, W = shape
@@ -160,6 +161,7 @@ def test_batchnorm_train(shape, relu):
     yref = F.conv2d(xin, w, bias, padding=1).requires_grad_(True)
     rm_ref, rv_ref = rm.clone(), rv.clone()
     zref = F.batch_norm(yref, rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5)
+    on_kink = zref.detach().abs() < 2e-6 if relu else torch.zeros_like(zref, dtype=torch.bool)
     if relu:
         zref = F.relu(zref)
     dz = rnd(*shape, seed=28)
@@ -177,7 +179,11 @@ def test_batchnorm_train(shape, relu):
     assert int(nbt.item()) == 1
     dg, dbt = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
     dy = o.bn_bwd(dz.to(DEV), y, ss, relu, g_d, mean, invstd, dg, dbt)
-    close(dy, yref.grad, rtol=2e-4, atol=2e-5, what="bn dy")
+    # an output within rounding of the ReLU kink may take the other branch (the fused scale/shift rounds differently from
+    # ATen's normalisation): its own gradient entry is skipped, at most a handful per million
+    assert int(on_kink.sum()) <= max(2, on_kink.numel() // 100000)      # |z| < 2e-6 on unit-scale z: ~4 per million
+    close(torch.where(on_kink.to(DEV), torch.zeros_like(dy), dy), torch.where(on_kink, torch.zeros_like(dy.cpu()), yref.grad),
+          rtol=2e-4, atol=2e-5, what="bn dy")
     close(dg, gamma.grad, rtol=2e-4, atol=2e-4, what="dgamma")
     close(dbt, beta.grad, rtol=2e-4, atol=2e-4, what="dbeta")
     ss_e = o.bn_eval_coeffs(g_d, b_d, rm_d, rv_d)

@@ -207,6 +207,77 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_k(const float* __restrict__ 
   }
 }
 
+// Small maps (the 16x16 / 32x32 levels): the three launches above cost 23-30 us of mostly launch latency for a few MB.
+// One workgroup per channel does all of it: pass 1 folds (sum dzh, sum dzh*xhat) over the channel's B*HW elements, the
+// coefficients are computed in place (same formulas as bn_bwd_finalize_k), pass 2 re-reads the channel (L2 / Infinity
+// Cache resident) and writes dy.  HW % 4 == 0, 16-byte aligned tensors.
+__global__ __launch_bounds__(1024) void bn_bwd_small_k(const float* __restrict__ dz, const float* __restrict__ y,
+                                                       const float* __restrict__ ss, int relu, const float* __restrict__ gamma,
+                                                       const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
+                                                       float* __restrict__ dy, int B, int C, int HW) {
+  __shared__ double sh[2][16];
+  __shared__ float kc[3];
+  const int c = blockIdx.x, t = threadIdx.x;
+  const float sc = ss[2 * c], sf = ss[2 * c + 1], mu = mean[c], is = invstd[c];
+  const int q = HW / 4, total = B * q;            // float4 pieces of this channel
+  float s1 = 0.f, s2 = 0.f;
+  for (int e = t; e < total; e += 1024) {
+    const int b = e / q, p = (e - b * q) * 4;
+    const size_t off = ((size_t)b * C + c) * HW + p;
+    const float4 yv = *reinterpret_cast<const float4*>(y + off);
+    float4 g = *reinterpret_cast<const float4*>(dz + off);
+    if (relu) {
+      if (!(fmaf(yv.x, sc, sf) > 0.f)) g.x = 0.f;
+      if (!(fmaf(yv.y, sc, sf) > 0.f)) g.y = 0.f;
+      if (!(fmaf(yv.z, sc, sf) > 0.f)) g.z = 0.f;
+      if (!(fmaf(yv.w, sc, sf) > 0.f)) g.w = 0.f;
+    }
+    s1 += (g.x + g.y) + (g.z + g.w);
+    s2 += (g.x * (yv.x - mu) + g.y * (yv.y - mu)) + (g.z * (yv.z - mu) + g.w * (yv.w - mu));
+  }
+  double d1 = (double)s1, d2 = (double)s2 * (double)is;
+  for (int m = 1; m < 64; m <<= 1) {
+    d1 += __shfl_xor(d1, m, 64);
+    d2 += __shfl_xor(d2, m, 64);
+  }
+  if ((t & 63) == 0) {
+    sh[0][t >> 6] = d1;
+    sh[1][t >> 6] = d2;
+  }
+  __syncthreads();
+  if (t == 0) {
+    double a1 = 0.0, a2 = 0.0;
+    for (int w = 0; w < 16; ++w) {
+      a1 += sh[0][w];
+      a2 += sh[1][w];
+    }
+    dbeta[c] = accumulate ? dbeta[c] + (float)a1 : (float)a1;
+    dgamma[c] = accumulate ? dgamma[c] + (float)a2 : (float)a2;
+    const double count = (double)B * HW;
+    const double k1 = (double)gamma[c] * is;
+    const double k2 = -(double)gamma[c] * is * is * a2 / count;
+    const double k3 = -k1 * a1 / count - k2 * mu;
+    kc[0] = (float)k1;
+    kc[1] = (float)k2;
+    kc[2] = (float)k3;
+  }
+  __syncthreads();
+  const float k1 = kc[0], k2 = kc[1], k3 = kc[2];
+  for (int e = t; e < total; e += 1024) {
+    const int b = e / q, p = (e - b * q) * 4;
+    const size_t off = ((size_t)b * C + c) * HW + p;
+    const float4 v = *reinterpret_cast<const float4*>(y + off);
+    const float4 g = *reinterpret_cast<const float4*>(dz + off);
+    float4 o;
+    o.x = fmaf(k1, (relu && !(fmaf(v.x, sc, sf) > 0.f)) ? 0.f : g.x, fmaf(k2, v.x, k3));
+    o.y = fmaf(k1, (relu && !(fmaf(v.y, sc, sf) > 0.f)) ? 0.f : g.y, fmaf(k2, v.y, k3));
+    o.z = fmaf(k1, (relu && !(fmaf(v.z, sc, sf) > 0.f)) ? 0.f : g.z, fmaf(k2, v.z, k3));
+    o.w = fmaf(k1, (relu && !(fmaf(v.w, sc, sf) > 0.f)) ? 0.f : g.w, fmaf(k2, v.w, k3));
+    *reinterpret_cast<float4*>(dy + off) = o;
+  }
+}
+
 static inline bool vec_ok(int HW, const void* a, const void* b, const void* c) {
   return HW % 4 == 0 && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & 15) == 0;
 }
@@ -256,6 +327,12 @@ extern "C" int wtpse_bn_bwd(const float* dz, const float* y, const float* scale_
   WTPSE_REQUIRE(dz && y && scale_shift && gamma && save_mean && save_invstd && partial && coef && dgamma && dbeta && dy);
   WTPSE_REQUIRE(B > 0 && C > 0 && HW > 0);
   hipStream_t st = (hipStream_t)stream;
+  // a channel of at most 32k elements with enough channels to occupy the chip: everything in one launch
+  if ((long long)B * HW <= 32768 && C >= 96 && vec_ok(HW, dz, y, dy)) {
+    hipLaunchKernelGGL(bn_bwd_small_k, dim3(C), dim3(1024), 0, st, dz, y, scale_shift, relu, gamma, save_mean, save_invstd,
+                       dgamma, dbeta, accumulate, dy, B, C, HW);
+    return wtpse_status();
+  }
   const int ns = wtpse_bn_bwd_nsplit(B, C, HW);
   if (vec_ok(HW, dz, y, nullptr))
     hipLaunchKernelGGL(bn_bwd_reduce_k<true>, dim3(C, ns), dim3(256), 0, st, dz, y, scale_shift, relu, save_mean,
