@@ -114,14 +114,30 @@ class ShapeVariationalDist_x(E.HipNet, E.UNetBody):
     def _forward_update(self, main_network, x, mask, want_tape):
         t = E.Tape()
         training = self.training
-        # teacher side: forward only (train-mode BatchNorm still advances its running statistics, as in the reference)
-        w1 = E.deepwt_fwd(main_network.wt_model, x, want_tape=False)
-        th = E.teacher_fwd(main_network.prior_dist, E.Act(w1.z2, None, True), mask, main_network.training,
-                           want_logvar=False, want_tape=False)
-        mu_t = th.mu
+        # teacher side: forward only (train-mode BatchNorm still advances its running statistics, as in the reference).
+        # It shares nothing with the student's forward but the inputs, keeps no tape and uses no scratch buffers, so it runs
+        # on a second stream beside it (the small-grid layers of the two U-Nets fill each other's idle CUs); its one
+        # result, mu_t, is handed to the main stream at the join.
+        def teacher():
+            w1 = E.deepwt_fwd(main_network.wt_model, x, want_tape=False)
+            th = E.teacher_fwd(main_network.prior_dist, E.Act(w1.z2, None, True), mask, main_network.training,
+                               want_logvar=False, want_tape=False)
+            return th.mu
+        synced = main_network._dp is not None and main_network._dp.bn_sync      # collectives stay on one stream
+        side = None if synced else E.second_stream(x.device)
+        if side is not None:
+            main = torch.cuda.current_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                mu_t = teacher()
+        else:
+            mu_t = teacher()
         # student side
         w2 = E.deepwt_fwd(self.wt_model, x, want_tape)
         mu_s = self._student_mu(E.Act(w2.z2, None, True), training, t if want_tape else None)
+        if side is not None:
+            main.wait_stream(side)
+            mu_t.record_stream(main)
         scal = torch.empty((5,), dtype=torch.float32, device=x.device)   # (kd, ins_total, ins_off, ins_diag, dom)
         ops.mse_fwd(mu_t, mu_s, out=scal[0:1])
         losses = torch.empty((2, 3), dtype=torch.float32, device=x.device)

@@ -395,6 +395,20 @@ def _side_stream(device):
     return st
 
 
+_SECOND = {}
+TEACHER_SIDE_STREAM = os.environ.get("WTPSE_TEACHER_STREAM", "1") != "0"
+
+
+def second_stream(device):
+    """Stream for forward-only work that is independent of the main schedule (the teacher in the student's update)."""
+    if not TEACHER_SIDE_STREAM:
+        return None
+    st = _SECOND.get(device)
+    if st is None:
+        st = _SECOND[device] = torch.cuda.Stream(device=device)
+    return st
+
+
 def _wgrad_side(layer, dy, a0, a1=None):
     """_wgrad(..., with_bias=False) on the side stream.  dy must not be written again by the caller (it is a fresh
     BatchNorm-backward result in both callers)."""
