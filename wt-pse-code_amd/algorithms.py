@@ -186,24 +186,44 @@ class WT_PSE(E.HipNet, E.UNetBody):
         t = E.Tape()
         t.shape_prior = bool(hp['shape_prior'])
         training = self.training
-        emb = self._embedding(inputs, training, t if want_tape else None)
         if not t.shape_prior:
+            emb = self._embedding(inputs, training, t if want_tape else None)
             out, _ = E._conv(self.outc[0], emb)
             t.emb = emb
             return (out,), t
         coef = float(hp['shape_attention_coeffient'])
-        w = E.deepwt_fwd(self.wt_model, wt_in, want_tape)
-        th = E.teacher_fwd(self.prior_dist, E.Act(w.z2, None, True), mask, training, True, want_tape)
-        eps = self.next_noise(th.mu.shape)
-        z_post = ops.reparam_fwd(th.mu, th.logvar, eps)
+        D, n = self.number_source_domain, self.per_domain_batch
+
+        def prior_chain():
+            """DeepWT -> teacher -> posterior sample, and the WT loss on the first two maps divided by
+            len([z1, z2, relu(z2)]) = 3 (algorithms.py:1259-1267).  Shares only the inputs with the embedding above."""
+            w = E.deepwt_fwd(self.wt_model, wt_in, want_tape)
+            th = E.teacher_fwd(self.prior_dist, E.Act(w.z2, None, True), mask, training, True, want_tape)
+            eps = self.next_noise(th.mu.shape)
+            z_post = ops.reparam_fwd(th.mu, th.logvar, eps)
+            losses = torch.empty((2, 3), dtype=torch.float32, device=inputs.device)
+            st1 = self._wt_loss(w.z1, D, n, losses[0])
+            st2 = self._wt_loss(w.z2, D, n, losses[1])
+            return w, th, eps, z_post, st1, st2, ops.wt_combine(losses, 3.0, 0)
+
+        # The prior chain runs on the second stream beside the segmentation U-Net (small-grid layers of the two networks
+        # fill each other's idle CUs); what the main stream reads of it afterwards (z_post, the loss scalars) is handed over
+        # at the join, everything else is only touched again by the chain's own backward, on the same stream.
+        second = None if (self._dp is not None and self._dp.exact) else E.second_stream(inputs.device)
+        if second is not None:
+            main = torch.cuda.current_stream()
+            second.wait_stream(main)
+            with torch.cuda.stream(second):
+                w, th, eps, z_post, st1, st2, scal = prior_chain()
+        emb = self._embedding(inputs, training, t if want_tape else None)
+        if second is None:
+            w, th, eps, z_post, st1, st2, scal = prior_chain()
+        else:
+            main.wait_stream(second)
+            z_post.record_stream(main)
+            scal.record_stream(main)
         att, _, att_mask, fuse = ops.attn_fuse_fwd(z_post, self.attention_layer.layer1.weight.data_ptr(), emb, coef,
                                                    True, False, True)
-        # WT loss on the first two maps, divided by len([z1, z2, relu(z2)]) = 3 (algorithms.py:1259-1267)
-        losses = torch.empty((2, 3), dtype=torch.float32, device=inputs.device)
-        D, n = self.number_source_domain, self.per_domain_batch
-        st1 = self._wt_loss(w.z1, D, n, losses[0])
-        st2 = self._wt_loss(w.z2, D, n, losses[1])
-        scal = ops.wt_combine(losses, 3.0, 0)
         out, _ = E._conv(self.outc[0], fuse)
         if want_tape:
             t.w, t.th, t.eps, t.z_post, t.att, t.emb, t.fuse, t.st1, t.st2, t.coef = w, th, eps, z_post, att, emb, fuse, st1, st2, coef
@@ -237,14 +257,31 @@ class WT_PSE(E.HipNet, E.UNetBody):
             d_wb = self.gview(al.weight)
             self.gview(al.bias)
             demb, dz_post = ops.attn_fuse_bwd(dfuse, t.z_post, t.emb, t.att, al.weight.data_ptr(), t.coef, d_wb.data_ptr(), True)
-            dlogvar = ops.reparam_bwd(dz_post, t.th.logvar, t.eps)
-            d_relu_z2 = E.teacher_bwd(self.prior_dist, t.th, dz_post, dlogvar)
-            dz2 = ops.relu_mask(d_relu_z2, t.w.z2)
             gi = d_ins.contiguous() if d_ins is not None else None
             gd = d_dom.contiguous() if d_dom is not None else None
             kw = dict(g_off=gi, g_diag=gi, g_dom=gd, w_off=w_ins / 3.0, w_diag=w_ins / 3.0, w_dom=w_dom / 3.0)
-            self._wt_loss_bwd(t.st2, dz2, **kw)
-            E.deepwt_bwd(self.wt_model, t.w, dz2, lambda dz1: self._wt_loss_bwd(t.st1, dz1, **kw))
+
+            def prior_chain_bwd():
+                dlogvar = ops.reparam_bwd(dz_post, t.th.logvar, t.eps)
+                d_relu_z2 = E.teacher_bwd(self.prior_dist, t.th, dz_post, dlogvar)
+                dz2 = ops.relu_mask(d_relu_z2, t.w.z2)
+                self._wt_loss_bwd(t.st2, dz2, **kw)
+                E.deepwt_bwd(self.wt_model, t.w, dz2, lambda dz1: self._wt_loss_bwd(t.st1, dz1, **kw))
+
+            # the prior chain's backward on the second stream beside the segmentation U-Net's (see _forward_update); it
+            # only produces parameter gradients, which end_backward() waits for
+            second = None if (self._dp is not None and self._dp.exact) else E.second_stream(dz_post.device)
+            if second is not None:
+                main = torch.cuda.current_stream()
+                second.wait_stream(main)
+                with torch.cuda.stream(second):
+                    prior_chain_bwd()
+                for g in (dz_post, gi, gd):
+                    if g is not None:
+                        g.record_stream(second)
+                object.__setattr__(self, "_second_busy", True)
+            else:
+                prior_chain_bwd()
         dfeat = E.head_bwd(self.mu, t.mu, demb, (0, 2))
         dx1 = E.unet_bwd(self, t.unet, dfeat)
         E.convd_bwd(self.inc, t.inc, dx1, need_dx=False)

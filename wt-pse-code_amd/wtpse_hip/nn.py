@@ -288,6 +288,9 @@ class HipNet(nn.Module):
         return self._gtarget[off:off + p.numel()]
 
     def end_backward(self):
+        if self.__dict__.get("_second_busy"):
+            torch.cuda.current_stream().wait_stream(_SECOND[self._gflat.device])
+            object.__setattr__(self, "_second_busy", False)
         if self.__dict__.get("_side_busy"):
             torch.cuda.current_stream().wait_stream(_side_stream(self._gflat.device))
             object.__setattr__(self, "_side_busy", False)

@@ -31,8 +31,9 @@ def _chk(t, name="tensor"):
 
 
 def workspace(tag, nfloats, device):
-    """Persistent scratch, one buffer per (device, tag), grown on demand (single-stream use)."""
-    key = (str(device), tag)
+    """Persistent scratch, one buffer per (device, stream, tag), grown on demand: independent parts of the schedule run on
+    different streams (nn.py) and must not share scratch."""
+    key = (str(device), stream_ptr(), tag)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nfloats:
         buf = torch.empty(max(int(nfloats), 1024), dtype=torch.float32, device=device)
@@ -74,9 +75,8 @@ def conv_wgrad(dy, x0, x1, ksize, dw, dbias, pro0=None, pro_relu=0, accumulate=F
     cin = C0 + C1
     L = lib()
     ks = L.query("wtpse_wgrad_ksplit", B, H, W, cin, cout)
-    sid = stream_ptr()                 # one scratch set per stream: weight gradients also run on a side stream (nn.py)
-    slab = workspace("wgrad_slab@%x" % sid, ks * cout * cin * ksize * ksize, dy.device)
-    dbs = workspace("wgrad_dbias@%x" % sid, ks * cout, dy.device) if dbias is not None else None
+    slab = workspace("wgrad_slab", ks * cout * cin * ksize * ksize, dy.device)
+    dbs = workspace("wgrad_dbias", ks * cout, dy.device) if dbias is not None else None
     L.call("wtpse_conv_wgrad", ptr(dy), ptr(x0), C0, ptr(x1), C1, ptr(pro0), ptr(pro1), int(pro_relu), ptr(slab), ptr(dbs), ks,
            ptr(dw), ptr(dbias), int(accumulate), B, H, W, cout, ksize, stream_ptr())
 
