@@ -279,7 +279,7 @@ class WT_PSE(E.HipNet, E.UNetBody):
                 for g in (dz_post, gi, gd):
                     if g is not None:
                         g.record_stream(second)
-                object.__setattr__(self, "_second_busy", True)
+                E.note_join(self, second)
             else:
                 prior_chain_bwd()
         dfeat = E.head_bwd(self.mu, t.mu, demb, (0, 2))

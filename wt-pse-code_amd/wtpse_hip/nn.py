@@ -288,12 +288,12 @@ class HipNet(nn.Module):
         return self._gtarget[off:off + p.numel()]
 
     def end_backward(self):
-        if self.__dict__.get("_second_busy"):
-            torch.cuda.current_stream().wait_stream(_SECOND[self._gflat.device])
-            object.__setattr__(self, "_second_busy", False)
-        if self.__dict__.get("_side_busy"):
-            torch.cuda.current_stream().wait_stream(_side_stream(self._gflat.device))
-            object.__setattr__(self, "_side_busy", False)
+        joins = self.__dict__.get("_join")
+        if joins:                                   # helper streams this backward put work on (weight gradients, prior chain)
+            cur = torch.cuda.current_stream()
+            for st in joins:
+                cur.wait_stream(st)
+            joins.clear()
         if self._dp is not None:
             self._dp.allreduce_grads(self, self._gtarget)
         direct = self._gtarget is self._gflat
@@ -391,10 +391,12 @@ _SIDE = {}
 WGRAD_SIDE_STREAM = os.environ.get("WTPSE_WGRAD_STREAM", "1") != "0"
 
 
-def _side_stream(device):
-    st = _SIDE.get(device)
+def _side_stream(device, owner=None):
+    """One weight-gradient stream per stream it is fed from (the training step runs two lanes, each with its own)."""
+    key = (device, ops.stream_ptr() if owner is None else owner)
+    st = _SIDE.get(key)
     if st is None:
-        st = _SIDE[device] = torch.cuda.Stream(device=device)
+        st = _SIDE[key] = torch.cuda.Stream(device=device)
     return st
 
 
@@ -406,10 +408,21 @@ def second_stream(device):
     """Stream for forward-only work that is independent of the main schedule (the teacher in the student's update)."""
     if not TEACHER_SIDE_STREAM:
         return None
-    st = _SECOND.get(device)
+    key = (device, ops.stream_ptr())          # per calling stream: the two lanes of the training step do not share it
+    st = _SECOND.get(key)
     if st is None:
-        st = _SECOND[device] = torch.cuda.Stream(device=device)
+        st = _SECOND[key] = torch.cuda.Stream(device=device)
     return st
+
+
+def note_join(root, stream):
+    """end_backward() of `root` must wait for `stream`."""
+    j = root.__dict__.get("_join")
+    if j is None:
+        j = []
+        object.__setattr__(root, "_join", j)
+    if all(s is not stream for s in j):
+        j.append(stream)
 
 
 def _wgrad_side(layer, dy, a0, a1=None):
@@ -427,7 +440,7 @@ def _wgrad_side(layer, dy, a0, a1=None):
     for t in (dy, a0.t, a0.pro) + ((as_act(a1).t, as_act(a1).pro) if a1 is not None else ()):
         if t is not None:
             t.record_stream(side)       # the caching allocator must not hand these out again before the side stream is done
-    object.__setattr__(root, "_side_busy", True)
+    note_join(root, side)
 
 
 def _wgrad(layer, dy, a0, a1=None, with_bias=True):
