@@ -271,7 +271,7 @@ def test_convu_both_orders_vs_oracle(shape, first):
     x = make_noise(310, shape)
     prev = make_noise(410, (B, planes // 2, 2 * H, 2 * W))
     y, tape = E.convu_fwd(h.blk, x.to(DEV), prev.to(DEV), True)
-    assert tape.swapped == (W % 2 == 0)
+    assert tape.swapped == (E.CONVU_CONV_FIRST and W % 2 == 0)
     y = y.dense()
     sd = {"b." + k: v.detach().cpu().double().clone().requires_grad_(v.is_floating_point() and not O.is_buffer(k))
           for k, v in h.blk.state_dict().items()}
