@@ -11,10 +11,15 @@ four Adam steps over the four networks, on one synthetic batch resident in HBM. 
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import glob
 import json
 import os
 import sys
 import time
+
+# dmabuf IPC for RCCL / cross-process device memory: HSA reads this when the runtime initialises, i.e. at the first
+# torch.cuda call, so it is set before torch is imported
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.join(ROOT, "wt-pse-code_amd")
@@ -39,7 +44,14 @@ def parse():
     ap.add_argument("--workload", choices=["full", "seg"], default="full",
                     help="full = configs[2] (seg + shape nets + WT loss); seg = configs[1] (seg-net only)")
     ap.add_argument("--bn-sync", type=int, default=0, help="1: BatchNorm statistics over the global batch (parity mode)")
+    ap.add_argument("--graph", type=int, default=1,
+                    help="1: replay the step from HIP graphs (default; exact data-parallel mode always runs eagerly), 0: eager launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-full", action="store_true",
+                    help="SURVEY.md 8d protocol in full: 3 warm-up + 10 timed iterations at B=6 and B=30 (minutes of CPU time)")
+    ap.add_argument("--roi-presteps", type=int, default=-1,
+                    help="untimed set-up steps that train the optic-disc net until its prediction (the ROI of calls C/D) is "
+                         "no longer empty; -1 = until 2-60 %% of the pixels are inside (at most 400), 0 = none")
     ap.add_argument("--no-kernel-roofline", action="store_true")
     ap.add_argument("--kernels-only", action="store_true",
                     help="run only the per-kernel roofline launches (used under rocprofv3 --pmc to measure HBM traffic)")
@@ -71,14 +83,45 @@ def time_kernel(fn, reps=20):
     return e0.elapsed_time(e1) / reps
 
 
+def dominant_kernel_share():
+    """(kernel name, share of summed kernel time) of the largest row of the newest in-step rocprofv3 summary committed
+    under profiles/ (r*_bench_b32_kernel_stats.csv): the `roofline` object names the kernel the profile names."""
+    import csv
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_b32_kernel_stats.csv")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        rows = [r for r in csv.DictReader(f) if not r["Name"].startswith("__amd_rocclr")]
+    top = max(rows, key=lambda r: float(r["Percentage"]))
+    return {"profile": os.path.relpath(files[-1], ROOT), "kernel": top["Name"].split("(")[0], "percent": float(top["Percentage"]),
+            "calls": int(top["Calls"])}
+
+
 def kernel_rooflines(B, H, dev):
-    """Live HIP-event timings of the kernels BASELINE.json names a roofline for, at the benchmark's own shapes:
-    the dominant kernel of a step — conv_fwd_k<3,2,5> (forward + data-gradient of the >= 64-channel 3x3 layers, 23 % of
-    a step in profiles/r01_bench_b32_kernel_stats.csv) on one of its FLOP-heaviest launches, up3.conv3's 3x3 64->64 at
-    half resolution (1208 MFLOP/img — SURVEY.md Appendix B) — against the fp32 MFMA peak; and the WT-loss Gram kernels
-    (compute_whitening_loss forward / backward, 16*H*W*4 bytes/img/pass) against HBM."""
+    """Live HIP-event timings of the kernels BASELINE.json names a roofline for, at the benchmark's own shapes.
+    * `wgrad`: the step's dominant kernel, conv_wgrad_k<3,true,5,9> (weight gradient of the 3x3 layers with >= 32 input
+      and output channels on maps wider than 16; 22 % of the summed kernel time in profiles/r01_bench_b32_kernel_stats.csv)
+      on its four FLOP-heaviest launches — conv3 of up1..up4, 1208 MFLOP/img each — launched as
+      the training step launches them: two inputs (the virtual concat) each with its BatchNorm-apply + ReLU prologue,
+      the k-split slabs and their fp64 fold (wgrad_reduce_k) included in the timed call.
+    * `conv`: the forward / data-gradient kernel conv_fwd_k<3,2,5> on up3.conv3 (bias + BatchNorm partials in the epilogue).
+    * the WT-loss Gram kernels (compute_whitening_loss forward / backward, 16*H*W*4 bytes/img/pass) against HBM."""
     from wtpse_hip import ops
     out = {}
+    wg = []
+    for name, C, Hc in (("up1.conv3", 256, H // 8), ("up2.conv3", 128, H // 4), ("up3.conv3", 64, H // 2), ("up4.conv3", 32, H)):
+        x0, x1 = torch.randn(B, C // 2, Hc, Hc, device=dev), torch.randn(B, C // 2, Hc, Hc, device=dev)
+        p0, p1 = torch.rand(C // 2, 2, device=dev) + 0.5, torch.rand(C // 2, 2, device=dev) + 0.5
+        dy = torch.randn(B, C, Hc, Hc, device=dev)
+        dw = torch.empty(C, C, 3, 3, device=dev)
+        ms = time_kernel(lambda: ops.conv_wgrad(dy, x0, x1, 3, dw, None, p0, 3, False, p1))
+        fl = 2.0 * C * C * 9 * Hc * Hc * B
+        wg.append({"layer": "%s %d+%d->%d @%dx%d" % (name, C // 2, C // 2, C, Hc, Hc), "ms": ms, "tflops": fl / ms / 1e9, "flop": fl})
+        del x0, x1, dy, dw
+    tot_ms, tot_fl = sum(w["ms"] for w in wg), sum(w["flop"] for w in wg)
+    out["wgrad"] = {"kernel": "conv_wgrad_k<3,true,5,9> + wgrad_reduce_k: conv3 of up1..up4 (3x3, C/2+C/2->C, C=256..32 @%d..%d), B=%d, "
+                              "BatchNorm+ReLU prologue on both inputs" % (H // 8, H, B),
+                    "ms": tot_ms / len(wg), "tflops": tot_fl / tot_ms / 1e9, "flop_per_launch": tot_fl / len(wg), "launches": wg}
     C, Hc = 64, H // 2
     x = torch.randn(B, C, Hc, Hc, device=dev)
     w = torch.randn(C, C, 3, 3, device=dev) * 0.05
@@ -125,39 +168,65 @@ def kernel_rooflines(B, H, dev):
     return out
 
 
-def cpu_baseline(H, full):
-    """The CPU restatement (oracle/, bit-checked against the reference in the build container) timed on this box's
-    host cores on a bounded sample: one full iteration at B = 6 (what `--batch-size 8` yields in the reference)."""
+def cpu_baseline(H, full, full_protocol=False):
+    """The CPU restatement (oracle/, bit-checked against the reference in the build container) timed on this box's host
+    cores: full A-D iterations (4 forward + 4 backward + 4 Adam) at B = 6 — what `--batch-size 8` yields
+    in the reference — and B = 30, and compute_whitening_loss alone on [32,16,H,H].  Default: a bounded sample
+    (1 warm-up + 3 timed at B = 6, one iteration at B = 30; ~40 s); --cpu-baseline-full: 3 warm-up + 10 timed at both."""
     from oracle import wtpse_cpu as O
     from oracle.inputs import make_inputs, make_noise
     from wtpse_hip.synth import default_hparams
     import algorithms
     import shape_networks
     hp = default_hparams(full)
-    B, pb = 6, 2
+    if not full:
+        return None
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
     cores = max(1, min(cores, 16))       # a 1-GPU box is granted 16 host cores; more threads only oversubscribe them
     torch.set_num_threads(cores)
-    sds = []
-    for i, ctor in enumerate([lambda: algorithms.WT_PSE(3, 1, hp, "cpu", False, per_domain_batch=pb),
-                              lambda: shape_networks.ShapeVariationalDist_x(hp, "cpu", 1, 3, pb) if full else None,
-                              lambda: algorithms.WT_PSE(3, 1, hp, "cpu", True, per_domain_batch=pb),
-                              lambda: shape_networks.ShapeVariationalDist_x(hp, "cpu", 1, 3, pb) if full else None]):
-        m = ctor()                       # only used as a weight container (state_dict); no compute on these modules
-        sds.append({k: v.detach().clone() for k, v in m.state_dict().items()} if m is not None else {})
-    if not full:
-        return None
-    nets = O.Nets(*sds)
-    img, od, oc = make_inputs(1, B, H, H)
-    nz = {k: make_noise(10 + j, (B, 1, H, H)) for j, k in enumerate(["a", "b_t", "b_s", "c", "d_t", "d_s"])}
-    t0 = time.time()
-    O.train_iteration(nets, hp, img, od, oc, nz, pb)
-    dt = time.time() - t0
-    return {"value": B / dt, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "1 full A-D iteration (4 fwd + 4 bwd + 4 Adam), B=6, 3x%dx%d, torch CPU fp32, %.1f s" % (H, H, dt)}
+
+    def iteration_rate(B, warm, timed):
+        pb = B // 3
+        sds = []
+        for ctor in (lambda: algorithms.WT_PSE(3, 1, hp, "cpu", False, per_domain_batch=pb),
+                     lambda: shape_networks.ShapeVariationalDist_x(hp, "cpu", 1, 3, pb),
+                     lambda: algorithms.WT_PSE(3, 1, hp, "cpu", True, per_domain_batch=pb),
+                     lambda: shape_networks.ShapeVariationalDist_x(hp, "cpu", 1, 3, pb)):
+            m = ctor()                   # only used as a weight container (state_dict); no compute on these modules
+            sds.append({k: v.detach().clone() for k, v in m.state_dict().items()})
+        nets = O.Nets(*sds)
+        img, od, oc = make_inputs(1, B, H, H)
+        nz = {k: make_noise(10 + j, (B, 1, H, H)) for j, k in enumerate(["a", "b_t", "b_s", "c", "d_t", "d_s"])}
+        ts = []
+        for i in range(warm + timed):
+            t0 = time.time()
+            O.train_iteration(nets, hp, img, od, oc, nz, pb)
+            if i >= warm:
+                ts.append(time.time() - t0)
+        ts.sort()
+        return B / ts[len(ts) // 2], ts
+
+    r6, t6 = iteration_rate(6, 3 if full_protocol else 1, 10 if full_protocol else 3)
+    r30, t30 = iteration_rate(30, 3 if full_protocol else 0, 10 if full_protocol else 1)
+    z = torch.randn(32, 16, H, H)
+    tw = []
+    for i in range(13):
+        t0 = time.time()
+        with torch.no_grad():
+            O.whitening_loss(z, 3, 10, 0.0)
+        if i >= 3:
+            tw.append(time.time() - t0)
+    tw.sort()
+    wt_gbs = z.numel() * 4.0 / tw[len(tw) // 2] / 1e9
+    return {"value": r6, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "median of %d full A-D iterations (4 fwd + 4 bwd + 4 Adam) after %d warm-up, B=6, 3x%dx%d, torch CPU fp32 "
+                      "(%.1f s each)" % (len(t6), 3 if full_protocol else 1, H, H, t6[len(t6) // 2]),
+            "b30": {"value": r30, "unit": "images/s", "sample": "median of %d iteration(s), B=30 (%.1f s each)" % (len(t30), t30[len(t30) // 2])},
+            "wt_loss_fwd": {"value": wt_gbs, "unit": "GB/s", "sample": "compute_whitening_loss forward on [32,16,%d,%d], median of 10 "
+                            "after 3 warm-up (%.1f ms)" % (H, H, 1e3 * tw[len(tw) // 2])}}
 
 
 def log(msg):
@@ -181,6 +250,10 @@ def measured_traffic():
 
 def main():
     args = parse()
+    if args.bn_sync and args.batch % 3 != 0:
+        sys.exit("--bn-sync 1 (exact data-parallel mode) draws the sampling noise of every domain's rows from one global "
+                 "Philox stream and needs a per-GPU batch that is a multiple of the 3 source domains: --batch %d is not "
+                 "(use e.g. --batch 30 or 33)" % args.batch)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -195,7 +268,6 @@ def main():
     dp = None
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -214,7 +286,7 @@ def main():
     B, H = args.batch, args.size
     pb = B // 3                                  # per-domain rows on this rank; the MMD sees 3*pb*world rows
     nets = build_nets(hp, pb, dev)
-    ts = TrainStep(*nets, hp, dp=dp)
+    ts = TrainStep(*nets, hp, dp=dp, graph=bool(args.graph))
     image, target_od, target_oc = make_batch(B, H, H, dev, seed=1 + rank)
 
     def barrier():
@@ -223,29 +295,61 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    log("nets built, batch in HBM; priming the per-stream allocator pools")
+    def timed(nsteps):
+        """barrier + sync, nsteps steps, barrier + sync; -> (seconds = max over ranks, host enqueue seconds, last losses)"""
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(nsteps):
+            res = ts.step(image, target_od, target_oc)
+        t_host = time.perf_counter() - t0        # host time to enqueue the steps (no GPU wait inside a step)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            import torch.distributed as dist
+            tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt, t_host, {k: float(v) for k, v in res.items()}
+
+    log("nets built, batch in HBM; priming the per-stream allocator pools%s" % (" and capturing the step" if ts.graph else ""))
     for i in range(2):       # part of set-up, like building the nets: the caching allocator's pools (one per stream) reach
-        ts.step(image, target_od, target_oc)    # their steady size after two steps; the W warmup steps below are the contract's
+        ts.step(image, target_od, target_oc)    # their steady size after two steps (graph mode: the capture happens here)
     torch.cuda.synchronize()
+    # Set-up, continued: at the seed-1 initial weights the optic-disc net predicts an EMPTY disc, so calls C/D would run on a
+    # constant ROI (all -1), i.e. half of the step on trivial operands, which the chip clocks higher than real data
+    # (MI355X_MICROARCH.md, DVFS).  The degenerate state is timed first (reported as `degenerate_roi`), then the nets train on
+    # the synthetic batch until the prediction covers a sensible part of the image, and the contract's W warm-up + K timed
+    # steps run in that state.
+    def od_fraction():       # the same number on every rank: the set-up loop below must take the same decisions everywhere
+        f = ts.last_od_pred.mean().reshape(1).double()
+        if world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(f)
+            f /= world
+        return float(f)
+
+    degenerate = None
+    frac = od_fraction()
+    presteps = 0
+    if args.roi_presteps != 0 and full and not (0.02 <= frac <= 0.6):
+        dt0, _, _ = timed(min(args.steps, 10))
+        degenerate = {"value": world * B * min(args.steps, 10) / dt0, "unit": "images/s", "od_pred_fraction": frac,
+                      "note": "same step, ROI of calls C/D empty (initial weights): constant operands in half of the step"}
+        limit = args.roi_presteps if args.roi_presteps > 0 else 400
+        while presteps < limit:
+            for _ in range(10):
+                ts.step(image, target_od, target_oc)
+            presteps += 10
+            frac = od_fraction()
+            if args.roi_presteps < 0 and 0.1 <= frac <= 0.6:
+                break
+        log("%d set-up steps: od_pred now covers %.3f of the pixels (target discs %.3f)" % (presteps, frac, float(target_od.mean())))
     log("warmup")
     for i in range(args.warmup):
         ts.step(image, target_od, target_oc)
         torch.cuda.synchronize()
-        log("warmup step %d done" % i)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = ts.step(image, target_od, target_oc)
-    t_host = time.perf_counter() - t0            # host time to enqueue the steps (no GPU wait inside a step)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    dt, t_host, losses = timed(args.steps)
     log("timed region: %.3f s for %d steps (host enqueue %.3f s)" % (dt, args.steps, t_host))
-    losses = {k: float(v) for k, v in res.items()}
     assert all(v == v for v in losses.values()), "NaN loss: %s" % losses
 
     if rank == 0:
@@ -255,22 +359,31 @@ def main():
             "value": ips, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("BASELINE.json configs[2]: full WT-PSE (seg+shape nets + WT loss)" if full else
+            "config": {"workload": (("BASELINE.json configs[2]: full WT-PSE (seg+shape nets + WT loss)" if H == 256 else
+                                     "BASELINE.json configs[4] per-GPU share: full WT-PSE at high resolution") if full else
                                     "BASELINE.json configs[1]: seg-net only") + ", 3x%dx%d, batch %d per GPU" % (H, H, B),
                        "global_batch": B * world, "image": [3, H, H], "parallelism": "dp%d" % world,
-                       "bn_sync": bool(args.bn_sync), "step": "calls A-D + 4 backward + 4 Adam (Trainer.py:766-914)"},
+                       "bn_sync": bool(args.bn_sync), "step": "calls A-D + 4 backward + 4 Adam (Trainer.py:766-914)",
+                       "launch": "hipGraph replay" if ts.graph else "eager",
+                       "roi": "od_pred covers %.3f of the pixels after %d untimed set-up steps" % (frac, presteps)},
             "host_enqueue_ms_per_step": 1e3 * t_host / args.steps,
             "conv_tflops_end_to_end": ips * GFLOP_PER_IMAGE * (H * H / 65536.0) / 1e3 if full else None,
             "losses": losses,
         }
+        if degenerate is not None:
+            line["degenerate_roi"] = degenerate
         if world == 1 and not args.no_kernel_roofline:
             log("kernel rooflines")
             kr = kernel_rooflines(B, H, dev)
             tr = measured_traffic() if (B, H) == (32, 256) else {}
-            c = kr["conv"]
-            line["roofline"] = {"bound": "mfma", "kernel": c["kernel"], "achieved": c["tflops"], "peak": MFMA_F32_PEAK_TF,
-                                "unit": "TFLOP/s", "frac": c["tflops"] / MFMA_F32_PEAK_TF, "traffic": tr.get("conv"),
-                                "ms_per_launch": c["ms"], "flop_per_launch": c["flop_per_launch"]}
+            wg, c = kr["wgrad"], kr["conv"]
+            line["roofline"] = {"bound": "mfma", "kernel": wg["kernel"], "achieved": wg["tflops"], "peak": MFMA_F32_PEAK_TF,
+                                "unit": "TFLOP/s", "frac": wg["tflops"] / MFMA_F32_PEAK_TF, "traffic": tr.get("wgrad"),
+                                "ms_per_launch": wg["ms"], "flop_per_launch": wg["flop_per_launch"],
+                                "launches": wg["launches"], "dominant_in_profile": dominant_kernel_share()}
+            line["roofline_conv_fwd"] = {"bound": "mfma", "kernel": c["kernel"], "achieved": c["tflops"], "peak": MFMA_F32_PEAK_TF,
+                                         "unit": "TFLOP/s", "frac": c["tflops"] / MFMA_F32_PEAK_TF, "traffic": tr.get("conv"),
+                                         "ms_per_launch": c["ms"], "flop_per_launch": c["flop_per_launch"]}
             for k in ("wt_fwd", "wt_bwd"):
                 w = kr[k]
                 line["roofline_" + k] = {"bound": "hbm", "kernel": w["kernel"], "achieved": w["gbs"], "peak": HBM_PEAK_GBS,
@@ -278,7 +391,7 @@ def main():
                                          "ms_per_launch": w["ms"], "bytes_per_launch": w["bytes_per_launch"]}
         if world == 1 and not args.no_cpu_baseline:
             log("cpu baseline")
-            line["cpu_baseline"] = cpu_baseline(H, full)
+            line["cpu_baseline"] = cpu_baseline(H, full, args.cpu_baseline_full)
             log("done")
         print(json.dumps(line))
     if world > 1:

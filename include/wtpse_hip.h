@@ -131,8 +131,13 @@ int wtpse_exp_half(const float* logvar, float* std_, long long n, void* stream);
 int wtpse_reparam_student(const float* mu, const float* std_, const float* eps, float* z, long long n, void* stream);
 /* if any element is NaN: nan_to_num the whole tensor.  flag: one device int (scratch). No host sync. */
 int wtpse_nan_scrub(float* x, long long n, int* flag, void* stream);
-/* Philox4x32-10 + Box-Muller; element i depends only on (seed, offset + i): offset = global element index (multiple of 4). */
-int wtpse_randn(float* out, long long n, unsigned long long seed, unsigned long long offset, void* stream);
+/* Philox4x32-10 + Box-Muller; element i depends only on (seed, position + i): position = offset + *offset_dev (offset_dev
+ * NULL: 0) = global element index, a multiple of 4.  Keeping the running position in device memory lets a captured
+ * launch (hipGraph) draw fresh numbers on every replay. */
+int wtpse_randn(float* out, long long n, unsigned long long seed, unsigned long long offset,
+                const unsigned long long* offset_dev, void* stream);
+/* *counter += inc on the stream (int32 counter, or uint64 when is64): step / stream-position counters of captured launches. */
+int wtpse_counter_add(void* counter, long long inc, int is64, void* stream);
 
 /* ---- caller-side losses and optimiser (Trainer.py:19,787,842-871; shape_networks.py:596-597; train.py:120-138) --- */
 /* `partial` scratch: wtpse_reduce_blocks(n) floats (x2 for wtpse_pos_weight).  g: device scalar upstream gradient or NULL. */
@@ -148,8 +153,10 @@ int wtpse_bce_logits_pw_bwd(const float* x, const float* mask, const float* t, c
 int wtpse_mse_fwd(const float* a, const float* b, long long n, float* partial, float* loss, void* stream);
 int wtpse_mse_bwd(const float* a, const float* b, const float* g, float w, long long n, float* da, void* stream);
 int wtpse_roi(const float* image, const float* logit, float* roi, float* od_pred, int B, int C, int HW, void* stream);
+/* torch.optim.Adam (no weight decay / amsgrad), step number t = step + *step_dev (step_dev NULL: t = step; otherwise a
+ * device int holding the number of completed steps, so that a captured launch stays valid when replayed). */
 int wtpse_adam(float* p, const float* g, float* m, float* v, long long n, double lr, double beta1, double beta2, double eps,
-               int step, void* stream);
+               int step, const int* step_dev, void* stream);
 
 /* ---- fused 1x1 heads (csrc/head.hip) ------------------------------------------------------------------------------ */
 /* The heads 32 -> 32 (ReLU) -> 8 [-> (ReLU) -> nc] as one kernel per direction: reference algorithms.py:1006-1012
@@ -189,6 +196,10 @@ int wtpse_relu_mask(const float* dz, const float* ref, float* dy, int accumulate
 int wtpse_axpy(float* dst, const float* src, float alpha, long long n, void* stream);
 int wtpse_reduce_rows(const float* partial, int rows, int cols, float* out, int accumulate, float scale, void* stream);
 int wtpse_zero(void* p, long long nbytes, void* stream);
+
+/* Fingerprint (hex) of the sources and of this header the library was compiled from; the binding refuses a library
+ * whose fingerprint differs from the tree's (a stale .so after a signature change would otherwise go unnoticed). */
+const char* wtpse_source_hash(void);
 
 #ifdef __cplusplus
 }

@@ -8,12 +8,15 @@ for p in (ROOT, os.path.join(ROOT, "wt-pse-code_amd"), os.path.join(ROOT, "tests
         sys.path.insert(0, p)
 
 
-def _init(rank, world, port):
+def _init(rank, world, port, backend="gloo", device=None):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # before anything initialises HSA
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
 
 def host_logic(rank, world, port, out_dir):
@@ -81,9 +84,77 @@ def gpu_exact(rank, world, port, out_dir, B_g, pb_g, H):
     dist.destroy_process_group()
 
 
+def nccl_rccl(rank, world, port, out_dir, B_g, pb_g, H):
+    """RCCL leg (backend "nccl"), one GPU per rank: all-reduce AVG, broadcast_params, the exact-mode calls A/B of
+    gpu_exact, and one TrainStep in each mode.  world = 1 runs it on a single GPU (the collectives still go through
+    RCCL); world = 2 needs two GPUs."""
+    import torch
+    import torch.distributed as dist
+    from wtpse_hip import ops
+    from wtpse_hip.dp import DataParallel, local_rows
+    from wtpse_hip.step import TrainStep
+    from oracle.filler import fill_state_dict
+    from oracle.inputs import make_inputs, make_noise
+    from test_parity_gpu import build_nets, HP
+    dev = torch.device("cuda", rank % max(torch.cuda.device_count(), 1))
+    torch.cuda.set_device(dev)
+    _init(rank, world, port, "nccl", dev)
+    res = {}
+    dp = DataParallel(world, rank, dev, bn_sync=True)
+    assert dp._avg_native
+    g = torch.full((1000,), float(rank + 1), device=dev)
+    dp.allreduce_grads(None, g)
+    res["mean"] = bool(torch.allclose(g.cpu(), torch.full((1000,), (world + 1) / 2.0)))
+    s = dp.allreduce_sum(torch.tensor([1.0, 2.0], device=dev) * (rank + 1))
+    res["sum"] = bool(torch.allclose(s.cpu(), torch.tensor([1.0, 2.0]) * world * (world + 1) / 2))
+    n_l = pb_g // world
+    rows = local_rows(pb_g, 3, world, rank)
+    img, od, oc = make_inputs(600, B_g, H, H)
+    eps = make_noise(700, (B_g, 1, H, H))
+    # exact mode, calls A and B (as gpu_exact), gradient exchange over RCCL
+    main, shape, main_oc, shape_oc = build_nets(n_l)
+    if rank > 0:                                  # broadcast_params must overwrite these with rank 0's
+        for i, n in enumerate((main, shape, main_oc, shape_oc)):
+            fill_state_dict(n, 999 + i)
+    for n in (main, shape, main_oc, shape_oc):
+        n.train()
+        n.ensure_ready(repack=True)
+        object.__setattr__(n, "_dp", dp)
+    dp.broadcast_params([main, shape, main_oc, shape_oc])
+    ref_main, _, _, _ = build_nets(n_l)
+    res["bcast"] = bool(torch.equal(main.flat_params().cpu(), ref_main.to(dev).flat_params().cpu()))
+    x, m = img[rows].to(dev).contiguous(), od[rows].to(dev).contiguous()
+    main.set_noise([eps[rows]])
+    r, tape = main._forward_update(x, m, x, want_tape=True)
+    out, _, scal = r
+    main._backward_update(tape, ops.bce_sigmoid_bwd(out, m), None, None, w_ins=1.0, w_dom=1.0)
+    res["g_main"] = main.flat_grads().detach().cpu().clone()
+    res["scal_main"] = scal.detach().cpu().clone()
+    res["out"] = out.detach().cpu()
+    s2, tape2 = shape._forward_update(main, x, m, want_tape=True)
+    shape._backward_update(tape2, None, None, None, None)
+    res["g_shape"] = shape.flat_grads().detach().cpu().clone()
+    res["rows"] = rows
+    # one full training step per mode through the harness (Adam on the averaged gradients)
+    for mode in (True, False):
+        nets = build_nets(n_l)
+        dpm = DataParallel(world, rank, dev, bn_sync=mode)
+        ts = TrainStep(*nets, HP, dp=dpm)
+        lo = ts.step(img[rows].to(dev), od[rows].to(dev), oc[rows].to(dev))
+        torch.cuda.synchronize()
+        tag = "exact" if mode else "ddp"
+        res["losses_" + tag] = {k: float(v) for k, v in lo.items()}
+        res["params_" + tag] = [n.flat_params().detach().cpu().clone() for n in nets]
+    torch.save(res, os.path.join(out_dir, "r%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 if __name__ == "__main__":
     fn, rank, world, port, out_dir = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
     if fn == "host":
         host_logic(rank, world, port, out_dir)
+    elif fn == "nccl":
+        nccl_rccl(rank, world, port, out_dir, *[int(a) for a in sys.argv[6:9]])
     else:
         gpu_exact(rank, world, port, out_dir, *[int(a) for a in sys.argv[6:9]])

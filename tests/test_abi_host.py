@@ -22,6 +22,9 @@ def test_library_exports_every_declared_symbol():
     for name in protos:
         assert hasattr(dll, name), name
     assert set(lib().protos) == set(protos)
+    fn = dll.wtpse_source_hash
+    fn.restype = ctypes.c_char_p
+    assert fn().decode() == build.source_hash() == build.built_hash()
     # sizing helpers are host-only and may be called without a GPU
     L = lib()
     assert L.query("wtpse_conv_stats_blocks", 32, 256, 256) == 32 * 32 * 8
@@ -29,6 +32,15 @@ def test_library_exports_every_declared_symbol():
     assert L.query("wtpse_wt_split", 32, 65536, 0) >= 1
     # argument validation happens before any launch
     assert L.raw("wtpse_conv_fwd")(0, 16, 0, 0, 0, 0, 0, 0, 0, 0, 0, 16, 0, 1, 8, 8, 16, 3, 0, 0, 0) == -1
+
+
+def test_stale_library_is_refused(monkeypatch):
+    """A library compiled from other sources than the tree's must not be bound (silent ABI mismatch otherwise)."""
+    from wtpse_hip import build, lib as L
+    build.build()
+    monkeypatch.setattr(build, "source_hash", lambda: "0" * 32)
+    with pytest.raises(L.WtpseError):
+        L._Lib()
 
 
 def test_dropin_surface_matches_reference():

@@ -397,6 +397,14 @@ def test_losses_roi_adam():
         opt.step()
         o.adam_step(pd, gr.to(DEV), md, vd, 5e-4, 0.9, 0.99, 1e-8, step)
     close(pd, p.detach(), rtol=1e-6, atol=1e-7, what="adam")
+    # the same three steps with the step number in device memory (what a captured launch uses)
+    pd2, md2, vd2 = rnd(1000, seed=68).to(DEV), torch.zeros(1000, device=DEV), torch.zeros(1000, device=DEV)
+    t_dev = torch.zeros(1, dtype=torch.int32, device=DEV)
+    for step in range(1, 4):
+        o.adam_step(pd2, rnd(1000, seed=70 + step).to(DEV), md2, vd2, 5e-4, 0.9, 0.99, 1e-8, 1, t_dev)
+        o.counter_add(t_dev, 1)
+    assert int(t_dev) == 3
+    close(pd2, pd, rtol=1e-6, atol=1e-7, what="adam, device step counter")
 
 
 def test_randn_stream_properties():
@@ -407,6 +415,11 @@ def test_randn_stream_properties():
     # a shard that starts at global element 4096 reproduces the same stream (data-parallel noise)
     b = o.randn((1000,), DEV, seed=7, offset=4096)
     assert torch.equal(a[4096:5096].cpu(), b.cpu())
+    # the stream position may live in device memory (captured launches): offset + *counter
+    ctr = torch.zeros(1, dtype=torch.int64, device=DEV)
+    o.counter_add(ctr, 4000)
+    c = o.randn((1000,), DEV, seed=7, offset=96, offset_dev=ctr)
+    assert torch.equal(b.cpu(), c.cpu())
     assert not torch.equal(a[:1000].cpu(), o.randn((1000,), DEV, seed=8, offset=0).cpu())
 
 

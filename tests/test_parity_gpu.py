@@ -292,10 +292,12 @@ def test_convu_both_orders_vs_oracle(shape, first):
         close(p.grad, ref, rtol=5e-3, atol=5e-4 * float(ref.abs().max()) + 1e-7, what=k)
 
 
-@pytest.mark.parametrize("B,pb,H", [(3, 1, 32), (6, 2, 32), (6, 2, 64)])
+@pytest.mark.parametrize("B,pb,H", [(3, 1, 32), (6, 2, 32), (6, 2, 64), (6, 2, 256)])
 def test_gradients_calibrated(B, pb, H):
     """Every parameter gradient of call A (seg net + teacher + WT loss) and call B (student) against the oracle
-    evaluated in fp64, with the oracle's own fp32 run as the yardstick."""
+    evaluated in fp64, with the oracle's own fp32 run as the yardstick.  The 256x256 case runs the backward kernels in
+    the instantiations the benchmark uses (weight gradients at ksplit 512 + slab fold, the big-map BatchNorm backward,
+    the bilinear adjoint and the fused heads at full resolution)."""
     img, od, _ = make_inputs(600, B, H, H)
     eps = make_noise(700, (B, 1, H, H))
     main, shape, _, _ = build_nets(pb)
@@ -489,4 +491,62 @@ def test_wt_loss_full_size_properties():
     dG = torch.sign(G) * triu / (120.0 * B) + torch.sign(G - eye) * eye / (16.0 * B)
     rhs = 2.0 * (dG * Gz).sum()
     lhs = (dz.double() * zd.double()).sum().cpu()
+    assert abs(float(lhs - rhs)) <= 1e-4 * abs(float(rhs)) + 1e-7, (float(lhs), float(rhs))
+
+
+# ---------------------------------------------------------------- BASELINE.json configs[4]: 3x512x512
+def test_update_predict_512_vs_oracle():
+    """512x512 (configs[4]'s resolution), B=3: train-mode logits + WT-loss values of `update()` and eval-mode `predict()`
+    logits against the CPU oracle on the same inputs, at the 1e-4 bar."""
+    B, pb, H = 3, 1, 512
+    img, od, _ = make_inputs(87, B, H, H)
+    eps = make_noise(88, (B, 1, H, H))
+    main, shape, _, _ = build_nets(pb)
+    sd_main = {k: v.detach().cpu().clone() for k, v in main.state_dict().items()}
+    sd_shape = {k: v.detach().cpu().clone() for k, v in shape.state_dict().items()}
+    main.train()
+    main.set_noise([eps])
+    with torch.no_grad():
+        out, _, _, ins, dom = main.update(img.to(DEV), od.to(DEV), two_stage_inputs=img.to(DEV), two_step=True)
+        ref_out, _, _, ref_ins, ref_dom = O.wt_pse_update(dict(sd_main), HP, img, od, img, True, eps, 3, pb)
+    close(out, ref_out, atol=TOL, what="logits@512")
+    close(ins, ref_ins, rtol=1e-4, atol=1e-6, what="ins@512")
+    close(dom, ref_dom, rtol=1e-3, atol=1e-6, what="dom@512")
+    main.eval(); shape.eval()
+    with torch.no_grad():
+        pred, _ = main.predict(shape, img.to(DEV))
+        ref_pred, _ = O.wt_pse_predict(sd_main, sd_shape, HP, img, False)
+    close(pred, ref_pred, atol=TOL, what="predict@512")
+
+
+def test_wt_loss_512_vs_oracle_and_properties():
+    """[16,16,512,512] — the per-GPU WT-loss input of configs[4] (B=128 over 8 GPUs): forward values and dL/dz against
+    the oracle (autograd of the restated loss), the scale law and the adjoint identity of the 256x256 test."""
+    from wtpse_hip import ops
+    B, pb = 16, 5
+    g = torch.Generator().manual_seed(6)
+    z = torch.randn(B, 16, 512, 512, generator=g) * 0.5
+    zd = z.to(DEV)
+    st = ops.wt_loss_fwd(zd, 3, pb, 0.0)
+    zr = z.clone().requires_grad_(True)
+    off, dg, dom = O.whitening_loss(zr, 3, pb, 0.0)
+    close(st.losses[0], off, rtol=1e-4, atol=1e-7, what="off")
+    close(st.losses[1], dg, rtol=1e-4, atol=1e-7, what="diag")
+    close(st.losses[2], dom, rtol=2e-3, atol=1e-6, what="dom")
+    (off + dg + dom).backward()
+    dz = torch.empty_like(zd)
+    ops.wt_loss_bwd(st, dz, False)
+    ref = zr.grad
+    err = float((dz.cpu() - ref).norm() / ref.norm())
+    assert err < 1e-4, "dL/dz @512: relative L2 error %.3e" % err
+    st2 = ops.wt_loss_fwd((zd * 2.0).contiguous(), 3, pb, 0.0)
+    close(st2.offdiag, st.offdiag * 4.0, rtol=1e-4, atol=1e-7, what="scale law")
+    dz0 = torch.empty_like(zd)
+    ops.wt_loss_bwd(st, dz0, False, w_dom=0.0)
+    G = st.gram.view(B, 16, 16).double().cpu()
+    eye = torch.eye(16, dtype=torch.float64)
+    triu = torch.ones(16, 16, dtype=torch.float64).triu(1)
+    dG = torch.sign(G) * triu / (120.0 * B) + torch.sign(G - eye) * eye / (16.0 * B)
+    rhs = 2.0 * (dG * (G - 1e-5 * eye)).sum()
+    lhs = (dz0.double() * zd.double()).sum().cpu()
     assert abs(float(lhs - rhs)) <= 1e-4 * abs(float(rhs)) + 1e-7, (float(lhs), float(rhs))

@@ -552,9 +552,24 @@ __global__ __launch_bounds__(256) void roi_k(const float* __restrict__ image, co
 }
 
 // ------------------------------------------------------------------------------------------------ Adam (torch.optim.Adam semantics, no weight decay / amsgrad)
+// step_dev (optional): device int holding the number of COMPLETED optimiser steps; the bias corrections are then formed
+// here from t = step + *step_dev (one thread per block, in double as on the host), so that a captured launch stays valid
+// when it is replayed (hipGraph): nothing that changes from step to step is passed by value.
 __global__ __launch_bounds__(256) void adam_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                               float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
-                                              float bc1, float bc2_sqrt) {
+                                              float bc1, float bc2_sqrt, int step, const int* __restrict__ step_dev,
+                                              double b1d, double b2d) {
+  if (step_dev) {
+    __shared__ float bc[2];
+    if (threadIdx.x == 0) {
+      const double t = (double)(step + *step_dev);
+      bc[0] = (float)(1.0 - pow(b1d, t));
+      bc[1] = (float)sqrt(1.0 - pow(b2d, t));
+    }
+    __syncthreads();
+    bc1 = bc[0];
+    bc2_sqrt = bc[1];
+  }
   long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   float gi = g[i];
@@ -576,8 +591,11 @@ __device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_
 }
 // element i of the stream (seed, offset) depends only on (seed, offset + i/4): any sharding of the rows
 // over ranks reproduces the single-device stream when each rank passes its global element offset
+// offset_dev (optional): device counter added to `offset` (the stream position lives in device memory so that a
+// captured launch draws fresh numbers on every replay)
 __global__ __launch_bounds__(256) void randn_k(float* __restrict__ out, long long n, unsigned long long seed,
-                                               unsigned long long offset) {
+                                               unsigned long long offset, const unsigned long long* __restrict__ offset_dev) {
+  if (offset_dev) offset += *offset_dev;
   long long q = (long long)blockIdx.x * 256 + threadIdx.x;  // one Philox block = 4 normals
   long long base = q * 4;
   if (base >= n) return;
@@ -798,16 +816,26 @@ extern "C" int wtpse_roi(const float* image, const float* logit, float* roi, flo
   return wtpse_status();
 }
 extern "C" int wtpse_adam(float* p, const float* g, float* m, float* v, long long n, double lr, double beta1, double beta2,
-                          double eps, int step, void* stream) {
+                          double eps, int step, const int* step_dev, void* stream) {
   WTPSE_REQUIRE(p && g && m && v && n > 0 && step >= 1);
   float bc1 = (float)(1.0 - pow(beta1, (double)step));
   float bc2s = (float)sqrt(1.0 - pow(beta2, (double)step));
   hipLaunchKernelGGL(adam_k, GRID1(n), dim3(256), 0, ST, p, g, m, v, n, (float)lr, (float)beta1, (float)beta2, (float)eps, bc1,
-                     bc2s);
+                     bc2s, step, step_dev, beta1, beta2);
   return wtpse_status();
 }
-extern "C" int wtpse_randn(float* out, long long n, unsigned long long seed, unsigned long long offset, void* stream) {
+extern "C" int wtpse_randn(float* out, long long n, unsigned long long seed, unsigned long long offset,
+                           const unsigned long long* offset_dev, void* stream) {
   WTPSE_REQUIRE(out && n > 0 && offset % 4 == 0);
-  hipLaunchKernelGGL(randn_k, GRID1((n + 3) / 4), dim3(256), 0, ST, out, n, seed, offset);
+  hipLaunchKernelGGL(randn_k, GRID1((n + 3) / 4), dim3(256), 0, ST, out, n, seed, offset, offset_dev);
+  return wtpse_status();
+}
+__global__ void counter_add_k(void* ctr, long long inc, int is64) {
+  if (is64) *(unsigned long long*)ctr += (unsigned long long)inc;
+  else *(int*)ctr += (int)inc;
+}
+extern "C" int wtpse_counter_add(void* counter, long long inc, int is64, void* stream) {
+  WTPSE_REQUIRE(counter);
+  hipLaunchKernelGGL(counter_add_k, dim3(1), dim3(1), 0, ST, counter, inc, is64);
   return wtpse_status();
 }

@@ -167,15 +167,16 @@ class DataParallel:
 
     # -------------------------------------------------------------------------------------------- sampling noise
     def noise(self, shape, seed, counter):
-        """-> (eps [B_local, ...], elements consumed from the global stream).  Exact mode: row r of the local batch
-        takes the slice of the single global stream that belongs to its global row, so G ranks reproduce G = 1."""
+        """-> (eps [B_local, ...], elements consumed from the global stream); `counter`: device uint64 position of the
+        stream (the caller advances it).  Exact mode: row r of the local batch takes the slice of the single global
+        stream that belongs to its global row, so G ranks reproduce G = 1."""
         B = int(shape[0])
         per_row = 1
         for s in shape[1:]:
             per_row *= int(s)
         if not self.exact:
             n = B * per_row
-            return ops.randn(shape, self.device, seed + 7919 * (self.rank + 1), counter), (n + 3) & ~3
+            return ops.randn(shape, self.device, seed + 7919 * (self.rank + 1), 0, counter), (n + 3) & ~3
         assert per_row % 4 == 0, "rows must be a multiple of 4 elements for the global Philox stream"
         D = self.domains
         n_l = B // D
@@ -186,5 +187,5 @@ class DataParallel:
             g0 = d * n_g + self.rank * n_l
             seg = out[d * n_l:(d + 1) * n_l]
             ops.lib().call("wtpse_randn", seg.data_ptr(), n_l * per_row, int(seed) & 0xFFFFFFFFFFFFFFFF,
-                           counter + g0 * per_row, ops.stream_ptr())
+                           g0 * per_row, counter.data_ptr(), ops.stream_ptr())
         return out, D * n_g * per_row

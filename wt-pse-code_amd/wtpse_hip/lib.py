@@ -60,6 +60,18 @@ class _Lib:
         except ImportError:
             pass
         self._dll = ctypes.CDLL(LIB_PATH)
+        # a library built from other sources than the ones in the tree (stale .so after an edit, changed signature)
+        # would be a silent ABI mismatch: only missing symbols are detected by the binding below
+        from . import build
+        fn = getattr(self._dll, "wtpse_source_hash", None)
+        have = None
+        if fn is not None:
+            fn.restype = ctypes.c_char_p
+            have = fn().decode()
+        want = build.source_hash()
+        if have != want:
+            raise WtpseError("libwtpse_hip.so was built from different sources (library %s, tree %s): rebuild it with "
+                             "`python -c 'import __graft_entry__ as g; g.build()'`" % (have, want))
         self.protos = parse_header()
         for name, argtypes in self.protos.items():
             fn = getattr(self._dll, name)        # AttributeError if the header and the library disagree

@@ -175,7 +175,7 @@ class HipNet(nn.Module):
         object.__setattr__(self, "_touched", [])
         object.__setattr__(self, "_noise_queue", [])
         object.__setattr__(self, "_noise_seed", 0x5eed)
-        object.__setattr__(self, "_noise_counter", 0)
+        object.__setattr__(self, "_noise_ctr", None)
         object.__setattr__(self, "_dp", None)
         object.__setattr__(self, "_flag", None)
         object.__setattr__(self, "_packed_valid", False)
@@ -234,6 +234,10 @@ class HipNet(nn.Module):
         object.__setattr__(self, "_desc", torch.tensor(desc, dtype=torch.int32).to(dev))
         object.__setattr__(self, "_packed_version", -1)
         object.__setattr__(self, "_flag", torch.zeros(1, dtype=torch.int32, device=dev))
+        # position in this network's Philox stream.  It lives in device memory (advanced by a one-thread launch after each
+        # draw) so that nothing that changes from step to step is passed to a kernel by value: a captured step (hipGraph)
+        # then draws fresh noise on every replay, and eager and captured runs see the same stream.
+        object.__setattr__(self, "_noise_ctr", torch.zeros(1, dtype=torch.int64, device=dev))
         for b in self.buffers():
             if b.device != dev:
                 raise RuntimeError("parameters and buffers live on different devices")
@@ -294,7 +298,7 @@ class HipNet(nn.Module):
             for st in joins:
                 cur.wait_stream(st)
             joins.clear()
-        if self._dp is not None:
+        if self._dp is not None and not self.__dict__.get("_defer_allreduce"):     # the step harness issues it itself
             self._dp.allreduce_grads(self, self._gtarget)
         direct = self._gtarget is self._gflat
         if direct and not self._attach_grads:   # the step harness reads the flat buffer itself
@@ -317,24 +321,25 @@ class HipNet(nn.Module):
         object.__setattr__(self, "_noise_queue", list(tensors))
 
     def seed_noise(self, seed):
+        self.ensure_ready()
         object.__setattr__(self, "_noise_seed", int(seed))
-        object.__setattr__(self, "_noise_counter", 0)
+        ops.zero_(self._noise_ctr)
 
     def next_noise(self, shape):
         if self._noise_queue:
             e = self._noise_queue.pop(0)
             assert tuple(e.shape) == tuple(shape), (e.shape, shape)
             return e.to(self._flat.device, torch.float32).contiguous()
-        off = self._noise_counter
+        ctr = self._noise_ctr
         if self._dp is not None:   # exact mode: one global stream indexed by global row (any sharding reproduces G = 1)
-            eps, used = self._dp.noise(tuple(int(v) for v in shape), self._noise_seed, off)
-            object.__setattr__(self, "_noise_counter", off + used)
-            return eps
-        n = 1
-        for s in shape:
-            n *= int(s)
-        object.__setattr__(self, "_noise_counter", off + ((n + 3) & ~3))
-        return ops.randn(shape, self._flat.device, self._noise_seed, off)
+            eps, used = self._dp.noise(tuple(int(v) for v in shape), self._noise_seed, ctr)
+        else:
+            n = 1
+            for s in shape:
+                n *= int(s)
+            eps, used = ops.randn(shape, self._flat.device, self._noise_seed, 0, ctr), (n + 3) & ~3
+        ops.counter_add(ctr, used)
+        return eps
 
 
 # ================================================================================================ block schedules

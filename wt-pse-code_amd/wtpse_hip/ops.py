@@ -323,10 +323,16 @@ def nan_scrub_(x, flag):
     return x
 
 
-def randn(shape, device, seed, offset=0):
+def randn(shape, device, seed, offset=0, offset_dev=None):
+    """Standard normals from the Philox stream `seed` at position offset + *offset_dev (device uint64 counter or None)."""
     out = torch.empty(shape, dtype=torch.float32, device=device)
-    lib().call("wtpse_randn", ptr(out), out.numel(), int(seed) & 0xFFFFFFFFFFFFFFFF, int(offset), stream_ptr())
+    lib().call("wtpse_randn", ptr(out), out.numel(), int(seed) & 0xFFFFFFFFFFFFFFFF, int(offset), ptr(offset_dev), stream_ptr())
     return out
+
+
+def counter_add(counter, inc):
+    """*counter += inc on the current stream (device int32 or int64 scalar tensor)."""
+    lib().call("wtpse_counter_add", ptr(counter), int(inc), int(counter.dtype == torch.int64), stream_ptr())
 
 
 # ----------------------------------------------------------------------------------------------- losses / optimiser
@@ -395,6 +401,7 @@ def roi(image, logit):
     return out, od
 
 
-def adam_step(p, g, m, v, lr, beta1, beta2, eps, step):
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, step_dev=None):
+    """Step number t = step + *step_dev (step_dev: device int32 count of completed steps, or None)."""
     lib().call("wtpse_adam", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
-               int(step), stream_ptr())
+               int(step), ptr(step_dev), stream_ptr())

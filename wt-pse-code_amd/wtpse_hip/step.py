@@ -12,6 +12,13 @@ four networks of train.py:91-138, in the reference's order:
 Differences from the reference loop that cannot change a result: no per-iteration `.item()` host syncs or
 tensorboard scalars (losses stay on the device), fused Adam over the flat parameter buffer instead of ~390
 per-tensor updates, and the dead work listed in shape_networks.py's header is skipped.
+
+hipGraph: a step is ~1 900 kernel launches from one Python thread (tens of milliseconds of host time, about as long
+as the GPU needs for them).  `TrainStep(..., graph=True)` captures the step once into HIP graphs and replays them:
+the C ABI allocates nothing, never synchronises and takes nothing that changes from step to step by value (Adam's step
+number and the Philox stream position live in device memory), so every launch is capture-legal.  With data-parallel
+training the gradient all-reduces stay outside the graphs (RCCL runs them eagerly between the replayed segments):
+a step is then five graphs with four collectives between them.
 """
 import torch
 
@@ -19,27 +26,36 @@ from . import ops
 
 
 class FlatAdam:
-    """torch.optim.Adam(lr, betas, eps=1e-8, weight_decay=0) over a network's flat buffers: one launch per step."""
+    """torch.optim.Adam(lr, betas, eps=1e-8, weight_decay=0) over a network's flat buffers: one launch per step.
+    The step count is a device integer (see wtpse_adam in include/wtpse_hip.h)."""
 
     def __init__(self, net, lr=5e-4, betas=(0.9, 0.99), eps=1e-8):
         self.net, self.lr, self.betas, self.eps = net, lr, betas, eps
-        self.t = 0
-        self.m = self.v = None
+        self.m = self.v = self.t_dev = None
+
+    def ready(self):
+        if self.m is None:
+            p = self.net.flat_params()
+            self.m = ops.zero_(torch.empty_like(p))
+            self.v = ops.zero_(torch.empty_like(p))
+            self.t_dev = torch.zeros(1, dtype=torch.int32, device=p.device)      # completed steps
 
     def step(self):
         net = self.net
         p, g = net.flat_params(), net.flat_grads()
-        if self.m is None:
-            self.m = ops.zero_(torch.empty_like(p))
-            self.v = ops.zero_(torch.empty_like(p))
-        self.t += 1
-        ops.adam_step(p, g, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.t)
+        self.ready()
+        ops.adam_step(p, g, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, 1, self.t_dev)
+        ops.counter_add(self.t_dev, 1)
         net.invalidate_packed()
         net.ensure_ready()
 
+    @property
+    def t(self):
+        return 0 if self.t_dev is None else int(self.t_dev.item())
+
 
 class TrainStep:
-    def __init__(self, model_od, shape_od, model_oc, shape_oc, hparams, lr=5e-4, betas=(0.9, 0.99), dp=None):
+    def __init__(self, model_od, shape_od, model_oc, shape_oc, hparams, lr=5e-4, betas=(0.9, 0.99), dp=None, graph=False):
         self.hp = hparams
         self.full = bool(hparams['whitening'])
         self.nets = [model_od, model_oc] + ([shape_od, shape_oc] if self.full else [])
@@ -51,12 +67,22 @@ class TrainStep:
             object.__setattr__(n, "_packed_valid", True)     # this harness owns the optimiser and repacks after each step
             object.__setattr__(n, "_attach_grads", False)
             object.__setattr__(n, "_dp", dp)
+            object.__setattr__(n, "_defer_allreduce", True)  # the gradient exchange is issued here, between backward and Adam
         if dp is not None:
             dp.broadcast_params(self.nets)
         self.opt = {id(n): FlatAdam(n, lr, betas) for n in self.nets}
+        for o in self.opt.values():
+            o.ready()
+        self.last_od_pred = None
+        # exact data-parallel mode runs ~100 small collectives inside every forward: it stays eager
+        self.graph = bool(graph) and not (dp is not None and dp.exact)
+        self._graphs = None
+        self._static = None
 
+    # ------------------------------------------------------------------------------------------------ schedule
     def _seg_call(self, model, x, target, noise, od_pred):
-        """forward + loss + backward + Adam of one segmentation network; -> (logits, losses dict of device scalars)."""
+        """forward + loss + backward of one segmentation network, then (after the caller's gradient exchange) Adam.
+        Generator: yields the network whose flat gradient is ready to be exchanged; returns (logits, losses)."""
         gi, gd = float(self.hp['instance_wt_gm']), float(self.hp['domain_wt_gm'])
         if noise is not None:
             model.set_noise([noise])
@@ -72,6 +98,8 @@ class TrainStep:
             loss = ops.bce_logits_pw_fwd(out, od_pred, target, pw)
             d_out = ops.bce_logits_pw_bwd(out, od_pred, target, pw)
         model._backward_update(tape, d_out, None, None, w_ins=gi, w_dom=gd)
+        del tape
+        yield model
         self.opt[id(model)].step()
         r = {"seg": loss}
         if self.full:
@@ -84,28 +112,78 @@ class TrainStep:
         for _ in range(int(self.hp['multi-turn'])):
             scal, tape = shape._forward_update(model, x, target, want_tape=True)
             shape._backward_update(tape, None, None, None, None, w_kd=1.0, w_off=gi, w_diag=gi, w_dom=gd)
+            del tape
+            yield shape
             self.opt[id(shape)].step()
             r = {"kd": scal[0], "ins_total": scal[1], "ins_off": scal[2], "ins_diag": scal[3], "dom": scal[4]}
         return r
 
-    def step(self, image, target_od, target_oc, noise=None):
-        """image [B,3,H,W] in [-1,1], targets [B,1,H,W] in {0,1}; all device fp32, rows domain-major.
-        noise: optional {'a': eps, 'c': eps} standard-normal [B,1,H,W] (parity runs); default Philox.
-        Returns {name: 0-dim device tensor}; nothing is synchronised with the host."""
-        noise = noise or {}
-        image = image.contiguous()
-        out, ra = self._seg_call(self.model_od, image, target_od, noise.get("a"), None)
+    def _schedule(self, image, target_od, target_oc, noise):
+        """The step as a generator that yields at the points where a network's gradient is complete and not yet used."""
+        out, ra = yield from self._seg_call(self.model_od, image, target_od, noise.get("a"), None)
         res = {"seg_od": ra["seg"]}
         if self.full:
             res.update(ins_od=ra["ins"], dom_od=ra["dom"])
-            rb = self._shape_call(self.shape_od, self.model_od, image, target_od)
+            rb = yield from self._shape_call(self.shape_od, self.model_od, image, target_od)
             res.update(kd_od=rb["kd"], ins_shape_od=rb["ins_total"], ins_ij_od=rb["ins_off"], ins_ii_od=rb["ins_diag"],
                        dom_shape_od=rb["dom"])
         roi, od_pred = ops.roi(image, out)
-        out_oc, rc = self._seg_call(self.model_oc, roi, target_oc, noise.get("c"), od_pred)
+        self.last_od_pred = od_pred          # [B,1,H,W] in {0,1}: lets a caller see how much of the image the ROI keeps
+        out_oc, rc = yield from self._seg_call(self.model_oc, roi, target_oc, noise.get("c"), od_pred)
         res["seg_oc"] = rc["seg"]
         if self.full:
             res.update(ins_oc=rc["ins"], dom_oc=rc["dom"])
-            rd = self._shape_call(self.shape_oc, self.model_oc, roi, target_oc)
+            rd = yield from self._shape_call(self.shape_oc, self.model_oc, roi, target_oc)
             res.update(kd_oc=rd["kd"], ins_shape_oc=rd["ins_total"], dom_shape_oc=rd["dom"])
         return res
+
+    def _exchange(self, net):
+        if self.dp is not None:
+            self.dp.allreduce_grads(net, net.flat_grads())
+
+    # ------------------------------------------------------------------------------------------------ hipGraph
+    def _capture(self, image, target_od, target_oc):
+        """Record the step into HIP graphs (one per stretch between gradient exchanges).  Nothing executes while a stretch
+        is recorded; the eager collectives between two stretches run on stale buffers and are harmless."""
+        self._static = tuple(t.clone() for t in (image, target_od, target_oc))
+        pool = torch.cuda.graph_pool_handle()
+        cap_stream = torch.cuda.Stream(device=image.device)
+        gen = self._schedule(*self._static, {})
+        graphs, res = [], None
+        done = False
+        while not done:
+            g = torch.cuda.CUDAGraph()
+            net = None
+            with torch.cuda.graph(g, pool=pool, stream=cap_stream):
+                try:
+                    net = next(gen)
+                except StopIteration as stop:
+                    res, done = stop.value, True
+            graphs.append((g, net))
+            if net is not None:
+                self._exchange(net)
+        self._graphs, self._result = graphs, res
+
+    def step(self, image, target_od, target_oc, noise=None):
+        """image [B,3,H,W] in [-1,1], targets [B,1,H,W] in {0,1}; all device fp32, rows domain-major.
+        noise: optional {'a': eps, 'c': eps} standard-normal [B,1,H,W] (parity runs); default Philox.
+        Returns {name: 0-dim device tensor}; nothing is synchronised with the host.  With graph=True the returned tensors
+        are the graphs' own output buffers: read them before the next step() overwrites them."""
+        image = image.contiguous()
+        if self.graph and not noise:
+            if self._graphs is None:
+                self._capture(image, target_od, target_oc)
+            for dst, src in zip(self._static, (image, target_od, target_oc)):
+                if dst.data_ptr() != src.data_ptr():
+                    dst.copy_(src)
+            for g, net in self._graphs:
+                g.replay()
+                if net is not None:
+                    self._exchange(net)
+            return self._result
+        gen = self._schedule(image, target_od, target_oc, noise or {})
+        try:
+            while True:
+                self._exchange(next(gen))
+        except StopIteration as stop:
+            return stop.value
