@@ -44,8 +44,9 @@ def parse():
     ap.add_argument("--workload", choices=["full", "seg"], default="full",
                     help="full = configs[2] (seg + shape nets + WT loss); seg = configs[1] (seg-net only)")
     ap.add_argument("--bn-sync", type=int, default=0, help="1: BatchNorm statistics over the global batch (parity mode)")
-    ap.add_argument("--graph", type=int, default=1,
-                    help="1: replay the step from HIP graphs (default; exact data-parallel mode always runs eagerly), 0: eager launches")
+    ap.add_argument("--graph", type=int, default=0,
+                    help="1: replay the step from HIP graphs (TrainStep(graph=True)); 0 (default): eager launches — measured on "
+                         "ROCm 7.0's runtime a replay costs the host 40-60 ms per step and serialises the streams (88 vs 80 ms/step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-full", action="store_true",
                     help="SURVEY.md 8d protocol in full: 3 warm-up + 10 timed iterations at B=6 and B=30 (minutes of CPU time)")
