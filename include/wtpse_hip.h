@@ -41,6 +41,17 @@ int wtpse_conv_fwd(const float* in0, int C0, const float* in1, int C1, const flo
                    int B, int H, int W, int Cout, int ksize, int relu_out, const float* mask_ref, void* stream);
 int wtpse_conv_stats_blocks(int B, int H, int W);
 
+/* The same convolution on the BF16 matrix cores at fp32 accuracy (csrc/conv_x3.hip): every fp32 operand is split into three
+ * bf16 terms and the product formed from the six leading cross terms with fp32 accumulation (6 bf16 MFMAs instead of 8 fp32
+ * MFMAs per 32x32x16 block).  Same contract as wtpse_conv_fwd; requires Cout > 16.  `wpacked`: the weights pre-split by
+ * wtpse_pack_conv_weights_x3 — desc as for wtpse_pack_conv_weights with offsets {xf_off, xd_off} in unsigned shorts; per
+ * conv and direction ceil16(K) * ceil32(rows) * taps * 3 unsigned shorts (forward: rows = Cout, K = Cin; data gradient:
+ * rows = Cin, K = Cout), layout [K chunk 16][row block 32][tap][term 3][k half 2][row 32][8 k]. */
+int wtpse_pack_conv_weights_x3(const float* params, const int* desc, int n_desc, unsigned short* packed, void* stream);
+int wtpse_conv_fwd_x3(const float* in0, int C0, const float* in1, int C1, const unsigned short* wpacked, const float* bias,
+                      const float* pro0, const float* pro1, int pro_relu, float* out0, float* out1, int Csplit, float* stats,
+                      int B, int H, int W, int Cout, int ksize, int relu_out, const float* mask_ref, void* stream);
+
 /* dW[Cout][C0+C1][k][k] (+)= sum dY * X, dbias (+)= sum dY (dbias/dbias_slab NULL: skip).  slab: [ksplit][Cout*Cin*k*k],
  * dbias_slab: [ksplit][Cout], ksplit = wtpse_wgrad_ksplit(...).  x inputs take the same prologue as the forward. */
 int wtpse_conv_wgrad(const float* dy, const float* x0, int C0, const float* x1, int C1, const float* pro0,

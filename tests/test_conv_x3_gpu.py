@@ -1,0 +1,109 @@
+"""The split-bf16 ("x3") convolution — fp32 operands as three bf16 terms, six bf16 MFMAs per product, fp32 accumulation
+(csrc/conv_x3.hip) — against stock PyTorch fp32/fp64 convolutions on the host, at the SAME tolerance as the fp32-MFMA kernel
+(tests/test_kernels_gpu.py::test_conv_forward), and against the fp64 result with the fp32-MFMA kernel as the yardstick."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from test_kernels_gpu import close, rnd, ops, pack, DEV
+
+pytestmark = pytest.mark.gpu
+
+
+def pack_x3(w):
+    """OIHW -> (packed uint16 buffer, xf_off, xd_off) through wtpse_pack_conv_weights_x3."""
+    o = ops()
+    co, ci, k, _ = w.shape
+    t = k * k
+    xf = o.x3_packed_size(co, ci, t)
+    xd = o.x3_packed_size(ci, co, t)
+    flat = w.reshape(-1).contiguous().to(DEV)
+    packed = torch.full((xf + xd,), 0x7FC0, dtype=torch.int16, device=DEV)      # bf16 NaN everywhere
+    desc = torch.tensor([0, co, ci, t, 0, xf, 0, 0], dtype=torch.int32, device=DEV)
+    o.lib().call("wtpse_pack_conv_weights_x3", flat.data_ptr(), desc.data_ptr(), 1, packed.data_ptr(), o.stream_ptr())
+    return packed, 0, xf
+
+
+X3_CASES = [
+    # B, C0, C1, Cout, H, W, k
+    (2, 16, 0, 32, 16, 16, 3),     # MT 1, 16x16 tile, one chunk
+    (2, 32, 0, 64, 8, 8, 3),       # image smaller than a tile
+    (1, 64, 64, 128, 16, 16, 3),   # concat, several cout blocks
+    (2, 16, 16, 32, 24, 48, 3),    # concat, ragged 8x32 tiles
+    (2, 256, 0, 128, 4, 4, 1),     # 1x1, multi-chunk
+    (1, 128, 0, 256, 2, 2, 3),     # deepest level of the 32x32 test network
+    (2, 40, 0, 96, 12, 20, 3),     # non-power-of-two channels: ragged chunk (40 -> 48) and 3 cout blocks
+    (2, 3, 0, 32, 20, 40, 3),      # 3-channel input padded to one chunk
+    (20, 32, 32, 64, 32, 64, 3),   # enough tiles for the 64-cout (MT 2) variant
+]
+
+
+@pytest.mark.parametrize("case", X3_CASES)
+def test_conv_x3_forward(case):
+    o = ops()
+    B, C0, C1, Co, H, W, k = case
+    x0 = rnd(B, C0, H, W, seed=1)
+    x1 = rnd(B, C1, H, W, seed=2) if C1 else None
+    w = rnd(Co, C0 + C1, k, k, seed=3, scale=0.2)
+    b = rnd(Co, seed=4)
+    xin = torch.cat([x0, x1], 1) if C1 else x0
+    ref = F.conv2d(xin, w, b, padding=k // 2)
+    packed, xf, _ = pack_x3(w)
+    y, _, stats = o.conv_fwd_x3(x0.to(DEV), x1.to(DEV) if C1 else None, packed.data_ptr() + 2 * xf, b.to(DEV), Co, k,
+                                want_stats=True)
+    close(y, ref, what="conv x3")
+    s = stats.double().sum(0).cpu()
+    close(s[:, 0], ref.double().sum((0, 2, 3)), rtol=1e-4, atol=1e-3, what="stat sum")
+    close(s[:, 1], (ref.double() ** 2).sum((0, 2, 3)), rtol=1e-4, atol=1e-3, what="stat sumsq")
+    yr, _, _ = o.conv_fwd_x3(x0.to(DEV), x1.to(DEV) if C1 else None, packed.data_ptr() + 2 * xf, None, Co, k, relu_out=True)
+    close(yr, F.relu(ref - b.view(1, -1, 1, 1)), what="conv x3 relu nobias")
+    # accuracy against fp64, with the fp32-MFMA kernel as the yardstick
+    ref64 = F.conv2d(xin.double(), w.double(), b.double(), padding=k // 2)
+    pk, wf, _ = pack(w)
+    y32, _, _ = o.conv_fwd(x0.to(DEV), x1.to(DEV) if C1 else None, pk.data_ptr() + 4 * wf, b.to(DEV), Co, k)
+    e3 = float((y.cpu().double() - ref64).norm() / ref64.norm())
+    e32 = float((y32.cpu().double() - ref64).norm() / ref64.norm())
+    print("relative L2 error vs fp64: x3 %.2e, fp32 MFMA %.2e" % (e3, e32))
+    assert e3 <= 2.0 * e32 + 2e-8, (e3, e32)
+
+
+@pytest.mark.parametrize("case", [(2, 16, 16, 32, 16, 32, 3), (1, 32, 32, 64, 8, 16, 1), (20, 32, 32, 64, 32, 64, 3)])
+def test_conv_x3_prologue(case):
+    o = ops()
+    B, C0, C1, Co, H, W, k = case
+    x0 = rnd(B, C0, H, W, seed=5)
+    x1 = rnd(B, C1, H, W, seed=6) if C1 else None
+    pro = torch.stack([rnd(C0 + C1, seed=7) * 0.5 + 1.0, rnd(C0 + C1, seed=8)], 1).contiguous()
+    w = rnd(Co, C0 + C1, k, k, seed=9, scale=0.2)
+    xin = torch.cat([x0, x1], 1) if C1 else x0
+    act = xin * pro[:, 0].view(1, -1, 1, 1) + pro[:, 1].view(1, -1, 1, 1)
+    act = torch.cat([F.relu(act[:, :C0]), act[:, C0:]], 1)
+    ref = F.conv2d(act, w, None, padding=k // 2)
+    packed, xf, _ = pack_x3(w)
+    y, _, _ = o.conv_fwd_x3(x0.to(DEV), x1.to(DEV) if C1 else None, packed.data_ptr() + 2 * xf, None, Co, k,
+                            pro0=pro[:C0].contiguous().to(DEV), pro1=(pro[C0:].contiguous().to(DEV) if C1 else None), pro_relu=1)
+    close(y, ref, what="prologue x3")
+
+
+@pytest.mark.parametrize("case", [(2, 32, 0, 32, 16, 16, 3), (1, 64, 64, 128, 16, 16, 3), (2, 32, 32, 64, 24, 48, 3),
+                                  (2, 256, 0, 128, 4, 4, 1), (2, 40, 0, 96, 12, 20, 3)])
+def test_conv_x3_dgrad(case):
+    """Data gradient = the same kernel on dY with the transposed, tap-flipped weights; split output (gradient of a concat)
+    and the fused ReLU mask."""
+    o = ops()
+    B, C0, C1, Co, H, W, k = case
+    x0 = rnd(B, C0, H, W, seed=11).requires_grad_(True)
+    x1 = rnd(B, C1, H, W, seed=12).requires_grad_(True) if C1 else None
+    w = rnd(Co, C0 + C1, k, k, seed=13, scale=0.2)
+    dy = rnd(B, Co, H, W, seed=15)
+    y = F.conv2d(torch.cat([x0, x1], 1) if C1 else x0, w, None, padding=k // 2)
+    y.backward(dy)
+    packed, _, xd = pack_x3(w)
+    d0, d1, _ = o.conv_fwd_x3(dy.to(DEV), None, packed.data_ptr() + 2 * xd, None, C0 + C1, k, split=(C0 if C1 else None))
+    close(d0, x0.grad, what="dgrad0 x3")
+    if C1:
+        close(d1, x1.grad, what="dgrad1 x3")
+    else:
+        ref_act = rnd(B, C0, H, W, seed=16)
+        dm, _, _ = o.conv_fwd_x3(dy.to(DEV), None, packed.data_ptr() + 2 * xd, None, C0, k, mask_ref=ref_act.to(DEV))
+        close(dm, x0.grad * (ref_act > 0).float(), what="dgrad x3 + relu mask")

@@ -1,0 +1,433 @@
+// 3x3 / 1x1 convolution, fp32 in / fp32 out, on the BF16 matrix cores of gfx950 at fp32 accuracy ("x3" path).
+//
+// Same contract as conv.hip's conv_fwd_k (forward and data gradient of the nn.Conv2d dispatches of the reference hot path,
+// algorithms.py:882-888,926-933 ...; same loader / epilogue fusions), different arithmetic.  The fp32-input MFMA runs at
+// 1/16 of the bf16 rate, so every fp32 operand x is split into three bf16 terms x = x0 + x1 + x2 (x0, x1: the top 16 bits of
+// x and of the remainder, exact by construction; x2: the remainder rounded to nearest even) and the product is formed from
+// the six leading cross terms
+//       a*b ~= a0*b0 + (a0*b1 + a1*b0) + (a0*b2 + a1*b1 + a2*b0)
+// each a v_mfma_f32_32x32x16_bf16 with fp32 accumulation: every bf16 x bf16 product is exact in fp32, the dropped terms are
+// below 2^-22 |a b|, and the accumulated error measures the same as the fp32 MFMA's (tests/test_kernels_gpu.py, CPU
+// emulation in DESIGN.md).  Six bf16 MFMAs (6 x 32 cycles) replace eight fp32 MFMAs (8 x 64 cycles) per 32x32x16 block.
+//
+// GEMM orientation as in conv.hip: D[cout][pixel] += sum_tap W_tap[cout][cin] * X[cin][pixel + tap], one GEMM per tap with
+// K = 16 input channels per MFMA.  Operand images in LDS (bf16, 16-byte rows of 8 consecutive k so that one ds_read_b128 is a
+// lane's fragment, and consecutive lanes read consecutive 16-byte slots: conflict-free):
+//     Xs[term 3][k-half 2][halo position][8 cin]      the 16-channel chunk of the input tile, split on the way in
+//     Ws[tap 3][term 3][k-half 2][cout CB][8 cin]     one kernel row of the weights (pre-split by the pack kernel)
+#include "common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+
+struct ConvX3Args {
+  const float* in0;
+  const float* in1;
+  const unsigned short* wx;   // packed split weights, see pack_weights_x3_k
+  const float* bias;
+  const float* pro0;
+  const float* pro1;
+  float* out0;
+  float* out1;
+  float* stats;
+  const float* mask;
+  int B, H, W;
+  int C0, C1, Cin, CinP;      // CinP: multiple of 16
+  int Cout, CoutP, Csplit;    // CoutP: multiple of 32
+  int pro_relu, relu_out;
+  int tiles_x, tiles_y;
+};
+
+__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// x -> (hi, mid) as raw fp32 bit patterns whose top 16 bits are the bf16 terms, and lo as a float to be rounded
+__device__ __forceinline__ void split3(float x, unsigned& hi, unsigned& mid, float& lo) {
+  hi = __builtin_bit_cast(unsigned, x) & 0xFFFF0000u;
+  const float r1 = x - __builtin_bit_cast(float, hi);                  // exact
+  mid = __builtin_bit_cast(unsigned, r1) & 0xFFFF0000u;
+  lo = r1 - __builtin_bit_cast(float, mid);                            // exact; rounded to bf16 by the caller
+}
+__device__ __forceinline__ unsigned pack_top(unsigned a, unsigned b) {  // (a >> 16) | (b & 0xFFFF0000)
+  return __builtin_amdgcn_perm(b, a, 0x07060302u);
+}
+__device__ __forceinline__ unsigned pack_rne(float a, float b) {
+  bf16x2 v = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(unsigned, v);
+}
+
+template <int KS, int MT, int TWL, bool MASK>
+__global__ __launch_bounds__(256, 2) void conv_x3_k(ConvX3Args a) {
+  constexpr int TAPS = KS * KS, PAD = KS / 2;
+  constexpr int TW = 1 << TWL, TH = 256 / TW;
+  constexpr int PITCH = TW + 2 * PAD, ROWS = TH + 2 * PAD;
+  constexpr int PE = PITCH * ROWS;
+  constexpr int NPOS = (PE + 255) / 256;
+  constexpr int PEP = (PE + 7) & ~7;
+  constexpr int CB = 32 * MT;
+  constexpr int NT = 2, NACC = 16;
+  constexpr int KC = 16;
+  constexpr int XS_U4 = 6 * PEP;                   // 16-byte slots
+  constexpr int WS_U4 = KS * 6 * CB;               // one kernel row (KS taps)
+  constexpr int NW = (WS_U4 + 255) / 256;          // 16-byte weight loads per thread and kernel row
+  constexpr int RED_F = 4 * CB * 2;
+  constexpr int MAIN_U4 = (XS_U4 + WS_U4) > (RED_F + 3) / 4 ? (XS_U4 + WS_U4) : (RED_F + 3) / 4;
+  __shared__ u32x4v smem[MAIN_U4 + CB / 4];
+  u32x4v* Xs = smem;
+  u32x4v* Ws = smem + XS_U4;
+  float* bias_s = reinterpret_cast<float*>(smem + MAIN_U4);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r32 = lane & 31, h = lane >> 5;
+  int bx = blockIdx.x;
+  const int tx = bx % a.tiles_x;
+  bx /= a.tiles_x;
+  const int ty = bx % a.tiles_y;
+  const int b = bx / a.tiles_y;
+  const int cout0 = blockIdx.y * CB;
+  const int HW = a.H * a.W;
+  if (tid < CB) bias_s[tid] = (a.bias && cout0 + tid < a.Cout) ? a.bias[cout0 + tid] : 0.f;
+
+  int off[NT];                                    // halo position of this lane's pixel (tap 0,0 corner)
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int p = wave * 64 + nt * 32 + r32;
+    off[nt] = (p >> TWL) * PITCH + (p & (TW - 1));
+  }
+  int gpos[NPOS];
+  unsigned voff[NPOS];
+#pragma unroll
+  for (int i = 0; i < NPOS; ++i) {
+    const int p = tid + 256 * i;
+    const int r = p / PITCH, x = p - r * PITCH;
+    const int gy = ty * TH + r - PAD, gx = tx * TW + x - PAD;
+    gpos[i] = (p < PE && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? gy * a.W + gx : -1;
+    voff[i] = gpos[i] >= 0 ? (unsigned)gpos[i] * 4u : BUF_OOB;
+  }
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < NACC; ++r) acc[mt][nt][r] = 0.f;
+
+  const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(a.in0 + (size_t)b * a.C0 * HW, (unsigned)a.C0 * HW * 4u);
+  const __amdgpu_buffer_rsrc_t rs1 = a.in1 ? make_rsrc(a.in1 + (size_t)b * a.C1 * HW, (unsigned)a.C1 * HW * 4u) : rs0;
+  // packed weights: [chunk][cout block of 32][tap][term][half][32][8] bf16 = 16-byte slots [chunk][cb][tap][term*2+half][32]
+  const int ncb32 = a.CoutP / 32;
+  const __amdgpu_buffer_rsrc_t rsw = make_rsrc(a.wx, (unsigned)(a.CinP / 16) * ncb32 * TAPS * 6u * 32u * 16u);
+  const bool any_pro = a.pro0 != nullptr || a.pro1 != nullptr || a.pro_relu != 0;
+
+  for (int c0 = 0; c0 < a.CinP; c0 += KC) {
+    // ---- input chunk: 16 channels x NPOS halo positions per thread, split into three bf16 terms on the way into LDS
+    const bool first = c0 < a.C0;
+    const __amdgpu_buffer_rsrc_t rs = first ? rs0 : rs1;
+    const int cbase = first ? c0 : c0 - a.C0;
+    const int cmax = (first ? a.C0 : a.C1) - 1;
+    float xv[KC][NPOS];
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+      const unsigned soff = (unsigned)min(cbase + c, cmax) * (unsigned)HW * 4u;
+#pragma unroll
+      for (int i = 0; i < NPOS; ++i) xv[c][i] = buf_load(rs, voff[i], soff);
+    }
+    if (any_pro) {
+      const bool relu = first ? (a.pro_relu & 1) : (a.pro_relu & 2);
+      const float* pro = first ? a.pro0 : a.pro1;
+#pragma unroll
+      for (int c = 0; c < KC; ++c) {
+        const int cg = min(cbase + c, cmax);
+        const float sc = pro ? pro[2 * cg] : 1.f, sh = pro ? pro[2 * cg + 1] : 0.f;
+#pragma unroll
+        for (int i = 0; i < NPOS; ++i) {
+          float v = fmaf(xv[c][i], sc, sh);
+          if (relu) v = fmaxf(v, 0.f);
+          xv[c][i] = gpos[i] >= 0 ? v : 0.f;
+        }
+      }
+    }
+    __syncthreads();   // the previous chunk's MFMAs are done with Xs (and Ws)
+#pragma unroll
+    for (int i = 0; i < NPOS; ++i) {
+      const int p = tid + 256 * i;
+      if (NPOS * 256 == PEP || p < PE) {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          u32x4v t0, t1, t2;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            unsigned h0, m0, h1, m1;
+            float l0, l1;
+            // channels past Cin re-read a valid plane; their packed weight rows are zero
+            split3(xv[hh * 8 + 2 * j][i], h0, m0, l0);
+            split3(xv[hh * 8 + 2 * j + 1][i], h1, m1, l1);
+            t0[j] = pack_top(h0, h1);
+            t1[j] = pack_top(m0, m1);
+            t2[j] = pack_rne(l0, l1);
+          }
+          Xs[(0 * 2 + hh) * PEP + p] = t0;
+          Xs[(1 * 2 + hh) * PEP + p] = t1;
+          Xs[(2 * 2 + hh) * PEP + p] = t2;
+        }
+      }
+    }
+    const unsigned wchunk = (unsigned)((c0 / 16) * ncb32 + cout0 / 32) * (unsigned)(TAPS * 6 * 32);   // in 16-byte slots
+#pragma unroll
+    for (int ky = 0; ky < KS; ++ky) {
+      // ---- one kernel row of weights: LDS slot s = ((tl*6 + q) * CB + co), tl = tap within the row, q = term*2 + half
+      u32x4v wv[NW];
+#pragma unroll
+      for (int it = 0; it < NW; ++it) {
+        const int s = tid + 256 * it;
+        const int co = s % CB, q6 = (s / CB) % 6, tl = s / (CB * 6);
+        const int cb = co >> 5;                     // which 32-cout block of the packed layout
+        const unsigned g = wchunk + (unsigned)cb * (TAPS * 6 * 32) + (unsigned)(((ky * KS + tl) * 6 + q6) * 32 + (co & 31));
+        const bool ok = s < WS_U4 && cout0 + co < a.CoutP;
+        wv[it] = __builtin_bit_cast(u32x4v, buf_load4(rsw, ok ? g * 16u : BUF_OOB, 0));
+      }
+      if (ky > 0) __syncthreads();   // the previous row's MFMAs are done with Ws
+#pragma unroll
+      for (int it = 0; it < NW; ++it)
+        if (NW * 256 == WS_U4 || tid + 256 * it < WS_U4) Ws[tid + 256 * it] = wv[it];
+      __syncthreads();
+      // ---- MFMAs of this kernel row
+#pragma unroll
+      for (int tl = 0; tl < KS; ++tl) {
+        const int toff = ky * PITCH + tl;
+        bf16x8 af[MT][3], bfr[NT][3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            af[mt][t] = __builtin_bit_cast(bf16x8, Ws[((tl * 6) + t * 2 + h) * CB + mt * 32 + r32]);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            bfr[nt][t] = __builtin_bit_cast(bf16x8, Xs[(t * 2 + h) * PEP + off[nt] + toff]);
+        }
+        // smallest cross terms first
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            f32x16 c = acc[mt][nt];
+            c = mfma_bf16(af[mt][0], bfr[nt][2], c);
+            c = mfma_bf16(af[mt][1], bfr[nt][1], c);
+            c = mfma_bf16(af[mt][2], bfr[nt][0], c);
+            c = mfma_bf16(af[mt][0], bfr[nt][1], c);
+            c = mfma_bf16(af[mt][1], bfr[nt][0], c);
+            c = mfma_bf16(af[mt][0], bfr[nt][0], c);
+            acc[mt][nt] = c;
+          }
+      }
+    }
+  }
+
+  // ---- epilogue (as conv.hip): + bias, ReLU / ReLU mask, branch-free buffer stores, BatchNorm (sum, sum^2) partials
+  if (a.bias) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < NACC; ++r) {
+        const float bz = bias_s[mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt][r] += bz;
+      }
+  }
+  const bool want_stats = a.stats != nullptr;
+  if (want_stats) __syncthreads();
+  float* red = reinterpret_cast<float*>(smem);    // [4 waves][CB][2]
+  const int C1out = a.Cout - a.Csplit;
+  int poff[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int p = wave * 64 + nt * 32 + r32;
+    const int gy = ty * TH + (p >> TWL), gx = tx * TW + (p & (TW - 1));
+    poff[nt] = (gy < a.H && gx < a.W) ? gy * a.W + gx : -1;
+  }
+  const __amdgpu_buffer_rsrc_t rs_o0 = make_rsrc(a.out0 + (size_t)b * a.Csplit * HW, (unsigned)a.Csplit * HW * 4u);
+  const __amdgpu_buffer_rsrc_t rs_o1 = a.out1 ? make_rsrc(a.out1 + (size_t)b * C1out * HW, (unsigned)C1out * HW * 4u) : rs_o0;
+  const __amdgpu_buffer_rsrc_t rs_m = MASK ? make_rsrc(a.mask + (size_t)b * a.Cout * HW, (unsigned)a.Cout * HW * 4u) : rs_o0;
+  const int clane = h * 4;
+  const float relu_lo = a.relu_out ? 0.f : -INFINITY;
+  unsigned pvo[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) pvo[nt] = poff[nt] >= 0 ? (unsigned)(clane * HW + poff[nt]) * 4u : BUF_OOB;
+  constexpr int NSV = NACC * 2;
+  const bool full = ty * TH + TH <= a.H && tx * TW + TW <= a.W && cout0 + CB <= a.Cout;
+  if (!full) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < NACC; ++r) {
+        const bool cvalid = cout0 + mt * 32 + (r & 3) + 8 * (r >> 2) + clane < a.Cout;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt][r] = (cvalid && poff[nt] >= 0) ? acc[mt][nt][r] : 0.f;
+      }
+  }
+  const unsigned hw4 = (unsigned)HW * 4u;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    float mk[NACC][NT];
+    if (MASK) {
+#pragma unroll
+      for (int r = 0; r < NACC; ++r) {
+        const int cbase = cout0 + mt * 32 + (r & 3) + 8 * (r >> 2);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) mk[r][nt] = buf_load(rs_m, pvo[nt], (unsigned)min(cbase, a.Cout) * hw4);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < NACC; ++r) {
+      const int cbase = cout0 + mt * 32 + (r & 3) + 8 * (r >> 2);
+      const bool second = a.out1 != nullptr && cbase >= a.Csplit;
+      const __amdgpu_buffer_rsrc_t rs_o = second ? rs_o1 : rs_o0;
+      const unsigned soff = (unsigned)(second ? min(cbase, a.Cout) - a.Csplit : min(cbase, a.Csplit)) * hw4;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        float v = fmaxf(acc[mt][nt][r], relu_lo);
+        if (MASK && !(mk[r][nt] > 0.f)) v = 0.f;
+        buf_store(rs_o, pvo[nt], soff, v);
+      }
+    }
+    if (want_stats) {
+      float sv[NSV];
+#pragma unroll
+      for (int r = 0; r < NACC; ++r) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma clang fp contract(off)
+          const float v = fmaxf(acc[mt][nt][r], relu_lo);
+          s1 += v;
+          s2 += v * v;
+        }
+        sv[r * 2 + 0] = s1;
+        sv[r * 2 + 1] = s2;
+      }
+      // butterfly transpose-reduction over the 32 lanes that hold one channel's pixels (see conv.hip)
+#pragma unroll
+      for (int st = 0; st < 5; ++st) {
+        const int half = NSV >> (st + 1);
+        const bool up = (lane >> st) & 1;
+#pragma unroll
+        for (int i = 0; i < NSV / 2; ++i) {
+          if (i < half) {
+            float keep = up ? sv[i + half] : sv[i];
+            float send = up ? sv[i] : sv[i + half];
+            sv[i] = keep + __shfl_xor(send, 1 << st, 64);
+          }
+        }
+      }
+      int idx = 0;
+#pragma unroll
+      for (int st = 0; st < 5; ++st) idx += ((lane >> st) & 1) * (NSV >> (st + 1));
+      const int k = idx & 1, rr = idx >> 1;
+      const int crel = mt * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h;
+      red[(wave * CB + crel) * 2 + k] = sv[0];
+    }
+  }
+  if (want_stats) {
+    __syncthreads();
+    if (tid < CB * 2) {
+      const int crel = tid >> 1;
+      if (cout0 + crel < a.Cout) {
+        const float s = red[tid] + red[CB * 2 + tid] + red[2 * CB * 2 + tid] + red[3 * CB * 2 + tid];
+        a.stats[((size_t)blockIdx.x * a.Cout + cout0 + crel) * 2 + (tid & 1)] = s;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight packing for the x3 path: OIHW fp32 -> bf16 triples in the kernel's LDS image order.
+//   forward : rows = Cout, k = Cin, tap t          element = w[co][ci][t]
+//   dgrad   : rows = Cin,  k = Cout, tap T-1-t     element = w[co][ci][T-1-t]   (the data gradient is the forward kernel on dY)
+// layout: [k chunk of 16][row block of 32][tap][term 3][k half 2][row 32][8 k] (unsigned short); zero padded.
+// desc: n_desc x 8 ints {w_off, Cout, Cin, taps, xf_off, xd_off(-1: none), 0, 0}; x*_off in unsigned shorts.
+__global__ __launch_bounds__(256) void pack_weights_x3_k(const float* __restrict__ params, const int* __restrict__ desc,
+                                                         unsigned short* __restrict__ packed) {
+  const int* d = desc + blockIdx.y * 8;
+  const int w_off = d[0], Co = d[1], Ci = d[2], T = d[3];
+  const float* w = params + w_off;
+  for (int dir = 0; dir < 2; ++dir) {
+    const int base = d[4 + dir];
+    if (base < 0) continue;
+    const int R = dir == 0 ? Co : Ci, K = dir == 0 ? Ci : Co;
+    const int RP = (R + 31) & ~31, KP = (K + 15) & ~15;
+    const int n = KP * RP * T;                     // (row, k, tap) triples
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+      // e enumerates [chunk][rb][tap][half][row32][k8]
+      const int k8 = e & 7, row32 = (e >> 3) & 31, hh = (e >> 8) & 1;
+      int q = e >> 9;
+      const int t = q % T; q /= T;
+      const int rb = q % (RP / 32), chunk = q / (RP / 32);
+      const int row = rb * 32 + row32, k = chunk * 16 + hh * 8 + k8;
+      float v = 0.f;
+      if (row < R && k < K) v = dir == 0 ? w[(row * Ci + k) * T + t] : w[(k * Ci + row) * T + (T - 1 - t)];
+      unsigned hi, mid;
+      float lo;
+      split3(v, hi, mid, lo);
+      const unsigned lo16 = pack_rne(lo, 0.f) & 0xFFFFu;
+      const size_t slot = ((((size_t)chunk * (RP / 32) + rb) * T + t) * 6);
+      unsigned short* o = packed + base;
+      o[((slot + 0 * 2 + hh) * 32 + row32) * 8 + k8] = (unsigned short)(hi >> 16);
+      o[((slot + 1 * 2 + hh) * 32 + row32) * 8 + k8] = (unsigned short)(mid >> 16);
+      o[((slot + 2 * 2 + hh) * 32 + row32) * 8 + k8] = (unsigned short)lo16;
+    }
+  }
+}
+
+extern "C" int wtpse_pack_conv_weights_x3(const float* params, const int* desc, int n_desc, unsigned short* packed, void* stream) {
+  WTPSE_REQUIRE(params && desc && packed && n_desc > 0);
+  hipLaunchKernelGGL(pack_weights_x3_k, dim3(16, n_desc), dim3(256), 0, (hipStream_t)stream, params, desc, packed);
+  return wtpse_status();
+}
+
+template <int KS, int MT, bool MASK>
+static int launch_x3(const ConvX3Args& a, hipStream_t st) {
+  ConvX3Args args = a;
+  const bool narrow = a.W <= 16;
+  const int TW = narrow ? 16 : 32, TH = 256 / TW;
+  args.tiles_x = ceil_div(a.W, TW);
+  args.tiles_y = ceil_div(a.H, TH);
+  dim3 grid((unsigned)(a.B * args.tiles_x * args.tiles_y), (unsigned)ceil_div(a.CoutP, 32 * MT));
+  if (narrow)
+    hipLaunchKernelGGL((conv_x3_k<KS, MT, 4, MASK>), grid, dim3(256), 0, st, args);
+  else
+    hipLaunchKernelGGL((conv_x3_k<KS, MT, 5, MASK>), grid, dim3(256), 0, st, args);
+  return wtpse_status();
+}
+
+// Same contract as wtpse_conv_fwd (include/wtpse_hip.h) with `wpacked` in the x3 layout; requires Cout > 16.
+extern "C" int wtpse_conv_fwd_x3(const float* in0, int C0, const float* in1, int C1, const unsigned short* wpacked,
+                                 const float* bias, const float* pro0, const float* pro1, int pro_relu, float* out0, float* out1,
+                                 int Csplit, float* stats, int B, int H, int W, int Cout, int ksize, int relu_out,
+                                 const float* mask_ref, void* stream) {
+  WTPSE_REQUIRE(in0 && wpacked && out0 && B > 0 && H > 0 && W > 0 && C0 > 0 && C1 >= 0 && Cout > 16);
+  WTPSE_REQUIRE(ksize == 1 || ksize == 3);
+  WTPSE_REQUIRE((C1 == 0) == (in1 == nullptr));
+  WTPSE_REQUIRE(Csplit > 0 && Csplit <= Cout && ((Csplit == Cout) == (out1 == nullptr)));
+  WTPSE_REQUIRE(Csplit == Cout || Csplit % 16 == 0);
+  WTPSE_REQUIRE(!(stats && relu_out));
+  WTPSE_REQUIRE(!(stats && mask_ref));
+  WTPSE_REQUIRE(!(mask_ref && out1));
+  WTPSE_REQUIRE(C1 == 0 || C0 % 16 == 0);
+  ConvX3Args a;
+  a.in0 = in0; a.in1 = in1; a.wx = wpacked; a.bias = bias; a.pro0 = pro0; a.pro1 = pro1; a.out0 = out0; a.out1 = out1;
+  a.stats = stats; a.mask = mask_ref;
+  a.B = B; a.H = H; a.W = W; a.C0 = C0; a.C1 = C1; a.Cin = C0 + C1; a.CinP = (a.Cin + 15) & ~15;
+  a.Cout = Cout; a.CoutP = (Cout + 31) & ~31; a.Csplit = Csplit; a.pro_relu = pro_relu; a.relu_out = relu_out;
+  a.tiles_x = a.tiles_y = 0;
+  hipStream_t st = (hipStream_t)stream;
+  const int TW = W <= 16 ? 16 : 32, TH = 256 / TW;
+  const int tiles = B * ceil_div(W, TW) * ceil_div(H, TH);
+  const bool mt2 = (a.CoutP % 64 == 0) && tiles * (a.CoutP / 64) >= 512;
+#define X3(KS, M) (mask_ref ? launch_x3<KS, M, true>(a, st) : launch_x3<KS, M, false>(a, st))
+  if (ksize == 3) return mt2 ? X3(3, 2) : X3(3, 1);
+  return mt2 ? X3(1, 2) : X3(1, 1);
+#undef X3
+}

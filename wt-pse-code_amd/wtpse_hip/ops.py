@@ -66,6 +66,35 @@ def conv_fwd(in0, in1, wpacked_ptr, bias, cout, ksize, pro0=None, pro_relu=0, re
     return out0, out1, stats
 
 
+def x3_packed_size(rows, k, taps):
+    """unsigned shorts of one direction of one conv in the x3 layout (include/wtpse_hip.h)."""
+    return ((k + 15) & ~15) * ((rows + 31) & ~31) * taps * 3
+
+
+def conv_fwd_x3(in0, in1, wpacked_ptr, bias, cout, ksize, pro0=None, pro_relu=0, relu_out=False, want_stats=False,
+                split=None, mask_ref=None, pro1=None):
+    """conv_fwd on the BF16 matrix cores at fp32 accuracy (csrc/conv_x3.hip); `wpacked_ptr` points into the x3-packed weights."""
+    _chk(in0, "in0"); _chk(in1, "in1"); _chk(pro0, "pro0"); _chk(pro1, "pro1")
+    B, C0, H, W = in0.shape
+    C1 = 0 if in1 is None else in1.shape[1]
+    L = lib()
+    if split is None:
+        out0 = torch.empty((B, cout, H, W), dtype=torch.float32, device=in0.device)
+        out1 = None
+        csplit = cout
+    else:
+        csplit = int(split)
+        out0 = torch.empty((B, csplit, H, W), dtype=torch.float32, device=in0.device)
+        out1 = torch.empty((B, cout - csplit, H, W), dtype=torch.float32, device=in0.device)
+    stats = None
+    if want_stats:
+        nblk = L.query("wtpse_conv_stats_blocks", B, H, W)
+        stats = torch.empty((nblk, cout, 2), dtype=torch.float32, device=in0.device)
+    L.call("wtpse_conv_fwd_x3", ptr(in0), C0, ptr(in1), C1, wpacked_ptr, ptr(bias), ptr(pro0), ptr(pro1), int(pro_relu), ptr(out0),
+           ptr(out1), csplit, ptr(stats), B, H, W, cout, ksize, int(relu_out), ptr(mask_ref), stream_ptr())
+    return out0, out1, stats
+
+
 def conv_wgrad(dy, x0, x1, ksize, dw, dbias, pro0=None, pro_relu=0, accumulate=False, pro1=None):
     """dw / dbias are views into the flat gradient buffer ([Cout,Cin,k,k] / [Cout] or None)."""
     _chk(dy, "dy"); _chk(x0, "x0"); _chk(x1, "x1")
