@@ -20,30 +20,35 @@ def pack_x3(w):
     return packed, xf
 
 
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-tot = [0.0, 0.0, 0.0, 0.0]
-for c0, c1, co, H, k, name in SHAPES:
-    if co <= 16 or c0 + c1 < 16:
-        continue
-    x0 = torch.randn(B, c0, H, H, device=DEV)
-    x1 = torch.randn(B, c1, H, H, device=DEV) if c1 else None
-    w = torch.randn(co, c0 + c1, k, k, device=DEV) * 0.05
-    bias = torch.zeros(co, device=DEV)
-    packed, wd_off = pack(w)
-    px, xd_off = pack_x3(w)
-    dy = torch.randn(B, co, H, H, device=DEV)
-    pro0 = torch.rand(c0, 2, device=DEV)
-    pro1 = torch.rand(c1, 2, device=DEV) if c1 else None
-    flops = 2.0 * (c0 + c1) * co * k * k * H * H * B
-    f32, _ = timeit(lambda: ops.conv_fwd(x0, x1, packed.data_ptr(), bias, co, k, pro0, 3, want_stats=True, pro1=pro1), 10)
-    f3, _ = timeit(lambda: ops.conv_fwd_x3(x0, x1, px.data_ptr(), bias, co, k, pro0, 3, want_stats=True, pro1=pro1), 10)
-    line = "%-12s %3d+%-3d->%-3d k%d @%3d  fwd fp32 %7.1f us %5.1f TF | x3 %7.1f us %5.1f TF (%.2fx)" % (
-        name, c0, c1, co, k, H, f32, flops / f32 / 1e6, f3, flops / f3 / 1e6, f32 / f3)
-    tot[0] += f32; tot[1] += f3
-    if c0 + c1 > 16:
-        d32, _ = timeit(lambda: ops.conv_fwd(dy, None, packed.data_ptr() + 4 * wd_off, None, c0 + c1, k, split=(c0 if c1 else None)), 10)
-        d3, _ = timeit(lambda: ops.conv_fwd_x3(dy, None, px.data_ptr() + 2 * xd_off, None, c0 + c1, k, split=(c0 if c1 else None)), 10)
-        line += " || dgrad fp32 %7.1f us %5.1f TF | x3 %7.1f us %5.1f TF (%.2fx)" % (d32, flops / d32 / 1e6, d3, flops / d3 / 1e6, d32 / d3)
-        tot[2] += d32; tot[3] += d3
-    print(line, flush=True)
-print("sum: fwd fp32 %.0f us, x3 %.0f us; dgrad fp32 %.0f us, x3 %.0f us" % tuple(tot))
+def main():
+  B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+  tot = [0.0, 0.0, 0.0, 0.0]
+  for c0, c1, co, H, k, name in SHAPES:
+      if co <= 16 or c0 + c1 < 16:
+          continue
+      x0 = torch.randn(B, c0, H, H, device=DEV)
+      x1 = torch.randn(B, c1, H, H, device=DEV) if c1 else None
+      w = torch.randn(co, c0 + c1, k, k, device=DEV) * 0.05
+      bias = torch.zeros(co, device=DEV)
+      packed, wd_off = pack(w)
+      px, xd_off = pack_x3(w)
+      dy = torch.randn(B, co, H, H, device=DEV)
+      pro0 = torch.rand(c0, 2, device=DEV)
+      pro1 = torch.rand(c1, 2, device=DEV) if c1 else None
+      flops = 2.0 * (c0 + c1) * co * k * k * H * H * B
+      f32, _ = timeit(lambda: ops.conv_fwd(x0, x1, packed.data_ptr(), bias, co, k, pro0, 3, want_stats=True, pro1=pro1), 10)
+      f3, _ = timeit(lambda: ops.conv_fwd_x3(x0, x1, px.data_ptr(), bias, co, k, pro0, 3, want_stats=True, pro1=pro1), 10)
+      line = "%-12s %3d+%-3d->%-3d k%d @%3d  fwd fp32 %7.1f us %5.1f TF | x3 %7.1f us %5.1f TF (%.2fx)" % (
+          name, c0, c1, co, k, H, f32, flops / f32 / 1e6, f3, flops / f3 / 1e6, f32 / f3)
+      tot[0] += f32; tot[1] += f3
+      if c0 + c1 > 16:
+          d32, _ = timeit(lambda: ops.conv_fwd(dy, None, packed.data_ptr() + 4 * wd_off, None, c0 + c1, k, split=(c0 if c1 else None)), 10)
+          d3, _ = timeit(lambda: ops.conv_fwd_x3(dy, None, px.data_ptr() + 2 * xd_off, None, c0 + c1, k, split=(c0 if c1 else None)), 10)
+          line += " || dgrad fp32 %7.1f us %5.1f TF | x3 %7.1f us %5.1f TF (%.2fx)" % (d32, flops / d32 / 1e6, d3, flops / d3 / 1e6, d32 / d3)
+          tot[2] += d32; tot[3] += d3
+      print(line, flush=True)
+  print("sum: fwd fp32 %.0f us, x3 %.0f us; dgrad fp32 %.0f us, x3 %.0f us" % tuple(tot))
+
+
+if __name__ == "__main__":
+    main()

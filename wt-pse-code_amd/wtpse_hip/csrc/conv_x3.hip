@@ -64,7 +64,6 @@ __global__ __launch_bounds__(256, 2) void conv_x3_k(ConvX3Args a) {
   constexpr int TW = 1 << TWL, TH = 256 / TW;
   constexpr int PITCH = TW + 2 * PAD, ROWS = TH + 2 * PAD;
   constexpr int PE = PITCH * ROWS;
-  constexpr int NPOS = (PE + 255) / 256;
   constexpr int PEP = (PE + 7) & ~7;
   constexpr int CB = 32 * MT;
   constexpr int NT = 2, NACC = 16;
@@ -73,7 +72,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_k(ConvX3Args a) {
   constexpr int WS_U4 = KS * 6 * CB;               // one kernel row (KS taps)
   constexpr int NW = (WS_U4 + 255) / 256;          // 16-byte weight loads per thread and kernel row
   constexpr int RED_F = 4 * CB * 2;
-  constexpr int MAIN_U4 = (XS_U4 + WS_U4) > (RED_F + 3) / 4 ? (XS_U4 + WS_U4) : (RED_F + 3) / 4;
+  constexpr int MAIN_U4 = (XS_U4 + 2 * WS_U4) > (RED_F + 3) / 4 ? (XS_U4 + 2 * WS_U4) : (RED_F + 3) / 4;
   __shared__ u32x4v smem[MAIN_U4 + CB / 4];
   u32x4v* Xs = smem;
   u32x4v* Ws = smem + XS_U4;
@@ -96,15 +95,24 @@ __global__ __launch_bounds__(256, 2) void conv_x3_k(ConvX3Args a) {
     const int p = wave * 64 + nt * 32 + r32;
     off[nt] = (p >> TWL) * PITCH + (p & (TW - 1));
   }
-  int gpos[NPOS];
-  unsigned voff[NPOS];
+  // Loader work items: (halo position, k-half) = 8 channels of one position.  The two halves are laid out as
+  // [half][positions padded to whole waves], dealt to the waves in blocks of 64, so that every thread gets the same number of
+  // items (NIT) and a wave's half is uniform (scalar channel offsets and prologue coefficients).
+  constexpr int PB = (PE + 63) / 64;               // 64-position blocks per half
+  constexpr int NIT = (2 * PB + 3) / 4;            // items per thread
+  int ipos[NIT], ihalf[NIT];
+  unsigned voff[NIT];
+  bool iin[NIT];
 #pragma unroll
-  for (int i = 0; i < NPOS; ++i) {
-    const int p = tid + 256 * i;
+  for (int i = 0; i < NIT; ++i) {
+    const int blk = __builtin_amdgcn_readfirstlane(i * 4 + wave);
+    ihalf[i] = blk >= PB ? 1 : 0;
+    const int p = (blk - ihalf[i] * PB) * 64 + lane;
+    ipos[i] = (blk < 2 * PB && p < PE) ? p : -1;
     const int r = p / PITCH, x = p - r * PITCH;
     const int gy = ty * TH + r - PAD, gx = tx * TW + x - PAD;
-    gpos[i] = (p < PE && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? gy * a.W + gx : -1;
-    voff[i] = gpos[i] >= 0 ? (unsigned)gpos[i] * 4u : BUF_OOB;
+    iin[i] = ipos[i] >= 0 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+    voff[i] = iin[i] ? (unsigned)(gy * a.W + gx) * 4u + (unsigned)ihalf[i] * 8u * (unsigned)HW * 4u : BUF_OOB;
   }
 
   f32x16 acc[MT][NT];
@@ -120,81 +128,106 @@ __global__ __launch_bounds__(256, 2) void conv_x3_k(ConvX3Args a) {
   // packed weights: [chunk][cout block of 32][tap][term][half][32][8] bf16 = 16-byte slots [chunk][cb][tap][term*2+half][32]
   const int ncb32 = a.CoutP / 32;
   const __amdgpu_buffer_rsrc_t rsw = make_rsrc(a.wx, (unsigned)(a.CinP / 16) * ncb32 * TAPS * 6u * 32u * 16u);
+  // (per-lane offset + scalar offset: a lane is out of range when voffset >= num_records - soffset, see common.h)
   const bool any_pro = a.pro0 != nullptr || a.pro1 != nullptr || a.pro_relu != 0;
 
-  for (int c0 = 0; c0 < a.CinP; c0 += KC) {
-    // ---- input chunk: 16 channels x NPOS halo positions per thread, split into three bf16 terms on the way into LDS
+  // Software pipeline over "rows" (one kernel row of one 16-channel chunk = KS taps = KS*MT*NT*6 MFMAs per wave): the global
+  // loads of the next row's weights — and, on a chunk's last row, of the next chunk's input tile — are issued before the
+  // row's MFMAs and land in registers behind them; the weights go to the other half of a double-buffered LDS slab right
+  // after the MFMAs (one barrier per row), the input tile is split and stored once every wave has left the chunk.
+  float xv[NIT][8];
+  u32x4v wv[NW];
+  auto issue_x = [&](int c0) {
     const bool first = c0 < a.C0;
     const __amdgpu_buffer_rsrc_t rs = first ? rs0 : rs1;
     const int cbase = first ? c0 : c0 - a.C0;
-    const int cmax = (first ? a.C0 : a.C1) - 1;
-    float xv[KC][NPOS];
+    const int cn = first ? a.C0 : a.C1;
 #pragma unroll
-    for (int c = 0; c < KC; ++c) {
-      const unsigned soff = (unsigned)min(cbase + c, cmax) * (unsigned)HW * 4u;
+    for (int j = 0; j < 8; ++j) {
+      // channels past the end of the tensor are out of the buffer's range and read as zero (their packed weight rows are
+      // zero too); min() keeps the scalar offset <= num_records so that the range check cannot wrap
+      const unsigned soff = (unsigned)min(cbase + j, cn) * (unsigned)HW * 4u;
 #pragma unroll
-      for (int i = 0; i < NPOS; ++i) xv[c][i] = buf_load(rs, voff[i], soff);
+      for (int i = 0; i < NIT; ++i) xv[i][j] = buf_load(rs, voff[i], soff);
     }
-    if (any_pro) {
+  };
+  auto stash_x = [&](int c0) {
+    if (any_pro) {   // zero padding applies AFTER the fused affine/ReLU, as in the reference graph
+      const bool first = c0 < a.C0;
+      const int cbase = first ? c0 : c0 - a.C0;
+      const int cmax = (first ? a.C0 : a.C1) - 1;
       const bool relu = first ? (a.pro_relu & 1) : (a.pro_relu & 2);
       const float* pro = first ? a.pro0 : a.pro1;
 #pragma unroll
-      for (int c = 0; c < KC; ++c) {
-        const int cg = min(cbase + c, cmax);
-        const float sc = pro ? pro[2 * cg] : 1.f, sh = pro ? pro[2 * cg + 1] : 0.f;
+      for (int i = 0; i < NIT; ++i)
 #pragma unroll
-        for (int i = 0; i < NPOS; ++i) {
-          float v = fmaf(xv[c][i], sc, sh);
+        for (int j = 0; j < 8; ++j) {
+          const int cg = min(cbase + ihalf[i] * 8 + j, cmax);
+          const float sc = pro ? pro[2 * cg] : 1.f, sh = pro ? pro[2 * cg + 1] : 0.f;
+          float v = fmaf(xv[i][j], sc, sh);
           if (relu) v = fmaxf(v, 0.f);
-          xv[c][i] = gpos[i] >= 0 ? v : 0.f;
+          xv[i][j] = iin[i] ? v : 0.f;
         }
+    }
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      if (ipos[i] >= 0) {
+        u32x4v t0, t1, t2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          unsigned h0, m0, h1, m1;
+          float l0, l1;
+          split3(xv[i][2 * j], h0, m0, l0);
+          split3(xv[i][2 * j + 1], h1, m1, l1);
+          t0[j] = pack_top(h0, h1);
+          t1[j] = pack_top(m0, m1);
+          t2[j] = pack_rne(l0, l1);
+        }
+        Xs[(0 * 2 + ihalf[i]) * PEP + ipos[i]] = t0;
+        Xs[(1 * 2 + ihalf[i]) * PEP + ipos[i]] = t1;
+        Xs[(2 * 2 + ihalf[i]) * PEP + ipos[i]] = t2;
       }
     }
-    __syncthreads();   // the previous chunk's MFMAs are done with Xs (and Ws)
+  };
+  // one kernel row of weights: LDS slot s = ((tl*6 + q) * CB + co), tl = tap within the row, q = term*2 + half
+  unsigned wslot[NW];
 #pragma unroll
-    for (int i = 0; i < NPOS; ++i) {
-      const int p = tid + 256 * i;
-      if (NPOS * 256 == PEP || p < PE) {
+  for (int it = 0; it < NW; ++it) {
+    const int s = tid + 256 * it;
+    const int co = s % CB, q6 = (s / CB) % 6, tl = s / (CB * 6);
+    const bool ok = s < WS_U4 && cout0 + co < a.CoutP;
+    wslot[it] = ok ? (unsigned)(((co >> 5) * (TAPS * 6 * 32) + (tl * 6 + q6) * 32 + (co & 31)) * 16) : BUF_OOB;
+  }
+  auto issue_w = [&](int chunk, int ky) {
+    const unsigned base = ((unsigned)(chunk * ncb32 + cout0 / 32) * (unsigned)(TAPS * 6 * 32) + (unsigned)(ky * KS * 6 * 32)) * 16u;
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-          u32x4v t0, t1, t2;
+    for (int it = 0; it < NW; ++it) wv[it] = __builtin_bit_cast(u32x4v, buf_load4(rsw, wslot[it], base));
+  };
+  auto stash_w = [&](int buf) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            unsigned h0, m0, h1, m1;
-            float l0, l1;
-            // channels past Cin re-read a valid plane; their packed weight rows are zero
-            split3(xv[hh * 8 + 2 * j][i], h0, m0, l0);
-            split3(xv[hh * 8 + 2 * j + 1][i], h1, m1, l1);
-            t0[j] = pack_top(h0, h1);
-            t1[j] = pack_top(m0, m1);
-            t2[j] = pack_rne(l0, l1);
-          }
-          Xs[(0 * 2 + hh) * PEP + p] = t0;
-          Xs[(1 * 2 + hh) * PEP + p] = t1;
-          Xs[(2 * 2 + hh) * PEP + p] = t2;
-        }
-      }
-    }
-    const unsigned wchunk = (unsigned)((c0 / 16) * ncb32 + cout0 / 32) * (unsigned)(TAPS * 6 * 32);   // in 16-byte slots
+    for (int it = 0; it < NW; ++it)
+      if (NW * 256 == WS_U4 || tid + 256 * it < WS_U4) Ws[buf * WS_U4 + tid + 256 * it] = wv[it];
+  };
+
+  const int nchunks = a.CinP / KC;
+  issue_x(0);
+  issue_w(0, 0);
+  stash_x(0);
+  stash_w(0);
+  __syncthreads();
+  int buf = 0;
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
 #pragma unroll
     for (int ky = 0; ky < KS; ++ky) {
-      // ---- one kernel row of weights: LDS slot s = ((tl*6 + q) * CB + co), tl = tap within the row, q = term*2 + half
-      u32x4v wv[NW];
-#pragma unroll
-      for (int it = 0; it < NW; ++it) {
-        const int s = tid + 256 * it;
-        const int co = s % CB, q6 = (s / CB) % 6, tl = s / (CB * 6);
-        const int cb = co >> 5;                     // which 32-cout block of the packed layout
-        const unsigned g = wchunk + (unsigned)cb * (TAPS * 6 * 32) + (unsigned)(((ky * KS + tl) * 6 + q6) * 32 + (co & 31));
-        const bool ok = s < WS_U4 && cout0 + co < a.CoutP;
-        wv[it] = __builtin_bit_cast(u32x4v, buf_load4(rsw, ok ? g * 16u : BUF_OOB, 0));
-      }
-      if (ky > 0) __syncthreads();   // the previous row's MFMAs are done with Ws
-#pragma unroll
-      for (int it = 0; it < NW; ++it)
-        if (NW * 256 == WS_U4 || tid + 256 * it < WS_U4) Ws[tid + 256 * it] = wv[it];
-      __syncthreads();
+      const bool last_row = ky == KS - 1;
+      const bool more = !last_row || chunk + 1 < nchunks;
+      if (more) issue_w(last_row ? chunk + 1 : chunk, last_row ? 0 : ky + 1);
+      if (last_row && more) issue_x((chunk + 1) * KC);
+      // keep the loads in front of the MFMAs (left alone, the scheduler sinks them to their first use behind the row,
+      // where their latency is exposed)
+      __builtin_amdgcn_sched_barrier(0);
       // ---- MFMAs of this kernel row
+      const u32x4v* Wb = Ws + buf * WS_U4;
 #pragma unroll
       for (int tl = 0; tl < KS; ++tl) {
         const int toff = ky * PITCH + tl;
@@ -203,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_k(ConvX3Args a) {
         for (int t = 0; t < 3; ++t) {
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
-            af[mt][t] = __builtin_bit_cast(bf16x8, Ws[((tl * 6) + t * 2 + h) * CB + mt * 32 + r32]);
+            af[mt][t] = __builtin_bit_cast(bf16x8, Wb[((tl * 6) + t * 2 + h) * CB + mt * 32 + r32]);
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
             bfr[nt][t] = __builtin_bit_cast(bf16x8, Xs[(t * 2 + h) * PEP + off[nt] + toff]);
@@ -223,6 +256,14 @@ __global__ __launch_bounds__(256, 2) void conv_x3_k(ConvX3Args a) {
             acc[mt][nt] = c;
           }
       }
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) stash_w(buf ^ 1);       // the other half: its readers passed the barrier at the end of the previous row
+      if (last_row && more) {
+        __syncthreads();                // every wave is done with this chunk's input tile
+        stash_x((chunk + 1) * KC);
+      }
+      __syncthreads();
+      buf ^= 1;
     }
   }
 
@@ -316,8 +357,12 @@ __global__ __launch_bounds__(256, 2) void conv_x3_k(ConvX3Args a) {
 #pragma unroll
         for (int i = 0; i < NSV / 2; ++i) {
           if (i < half) {
-            float keep = up ? sv[i + half] : sv[i];
-            float send = up ? sv[i] : sv[i + half];
+            // the empty asm makes the two operands opaque values: otherwise the select of two array elements is rewritten
+            // into one element with a selected (dynamic) index, and the register array into 32-way compare/select chains
+            float lo = sv[i], hi = sv[i + half];
+            asm volatile("" : "+v"(lo), "+v"(hi));
+            const float keep = up ? hi : lo;
+            const float send = up ? lo : hi;
             sv[i] = keep + __shfl_xor(send, 1 << st, 64);
           }
         }
