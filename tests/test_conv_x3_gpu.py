@@ -86,6 +86,7 @@ def test_conv_x3_prologue(case):
 
 
 @pytest.mark.parametrize("case", [(2, 32, 0, 32, 16, 16, 3), (1, 64, 64, 128, 16, 16, 3), (2, 32, 32, 64, 24, 48, 3),
+                                  (4, 32, 32, 64, 16, 16, 3),
                                   (2, 256, 0, 128, 4, 4, 1), (2, 40, 0, 96, 12, 20, 3)])
 def test_conv_x3_dgrad(case):
     """Data gradient = the same kernel on dY with the transposed, tap-flipped weights; split output (gradient of a concat)

@@ -2,12 +2,12 @@
 //
 // Same contract as conv.hip's conv_fwd_k (forward and data gradient of the nn.Conv2d dispatches of the reference hot path,
 // algorithms.py:882-888,926-933 ...; same loader / epilogue fusions), different arithmetic.  The fp32-input MFMA runs at
-// 1/16 of the bf16 rate, so every fp32 operand x is split into three bf16 terms x = x0 + x1 + x2 (x0, x1: the top 16 bits of
-// x and of the remainder, exact by construction; x2: the remainder rounded to nearest even) and the product is formed from
-// the six leading cross terms
+// 1/16 of the bf16 rate, so every fp32 operand x is split into three bf16 terms x = x0 + x1 + x2 (each the round-to-nearest-even
+// bf16 of what the previous terms left; the remainders are exact in fp32) and the product is formed from the six leading
+// cross terms
 //       a*b ~= a0*b0 + (a0*b1 + a1*b0) + (a0*b2 + a1*b1 + a2*b0)
 // each a v_mfma_f32_32x32x16_bf16 with fp32 accumulation: every bf16 x bf16 product is exact in fp32, the dropped terms are
-// below 2^-22 |a b|, and the accumulated error measures the same as the fp32 MFMA's (tests/test_kernels_gpu.py, CPU
+// below 2^-24 |a b| and unbiased, and the accumulated error measures the same as the fp32 MFMA's (tests/test_kernels_gpu.py, CPU
 // emulation in DESIGN.md).  Six bf16 MFMAs (6 x 32 cycles) replace eight fp32 MFMAs (8 x 64 cycles) per 32x32x16 block.
 //
 // GEMM orientation as in conv.hip: D[cout][pixel] += sum_tap W_tap[cout][cin] * X[cin][pixel + tap], one GEMM per tap with
@@ -43,19 +43,23 @@ __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
-// x -> (hi, mid) as raw fp32 bit patterns whose top 16 bits are the bf16 terms, and lo as a float to be rounded
-__device__ __forceinline__ void split3(float x, unsigned& hi, unsigned& mid, float& lo) {
-  hi = __builtin_bit_cast(unsigned, x) & 0xFFFF0000u;
-  const float r1 = x - __builtin_bit_cast(float, hi);                  // exact
-  mid = __builtin_bit_cast(unsigned, r1) & 0xFFFF0000u;
-  lo = r1 - __builtin_bit_cast(float, mid);                            // exact; rounded to bf16 by the caller
-}
-__device__ __forceinline__ unsigned pack_top(unsigned a, unsigned b) {  // (a >> 16) | (b & 0xFFFF0000)
-  return __builtin_amdgcn_perm(b, a, 0x07060302u);
-}
+// (a, b) -> three dwords, each holding the bf16 pair (term_i(a), term_i(b)), i = 0, 1, 2.  Every term is rounded to nearest
+// even (v_cvt_pk_bf16_f32) and the remainder formed exactly in fp32, so a = a0 + a1 + a2 up to 2^-25 |a| with terms of
+// alternating sign: the dropped cross terms (a1*b2 + a2*b1 + a2*b2 ~ 2^-25 |a b|) are unbiased.  (Truncating splits — mask off
+// the low 16 bits — cost the same number of instructions but leave every term with the sign of its operand: the dropped terms
+// then bias each product towards zero by ~2^-23, a coherent error that the network amplified 10x more than fp32 rounding.)
 __device__ __forceinline__ unsigned pack_rne(float a, float b) {
   bf16x2 v = {(__bf16)a, (__bf16)b};
   return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ void split3_pair(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2) {
+  p0 = pack_rne(a, b);
+  const float ra = a - __builtin_bit_cast(float, p0 << 16);
+  const float rb = b - __builtin_bit_cast(float, p0 & 0xFFFF0000u);
+  p1 = pack_rne(ra, rb);
+  const float sa = ra - __builtin_bit_cast(float, p1 << 16);
+  const float sb = rb - __builtin_bit_cast(float, p1 & 0xFFFF0000u);
+  p2 = pack_rne(sa, sb);
 }
 
 template <int KS, int MT, int TWL, bool MASK>
@@ -175,13 +179,11 @@ __global__ __launch_bounds__(256, 2) void conv_x3_k(ConvX3Args a) {
         u32x4v t0, t1, t2;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          unsigned h0, m0, h1, m1;
-          float l0, l1;
-          split3(xv[i][2 * j], h0, m0, l0);
-          split3(xv[i][2 * j + 1], h1, m1, l1);
-          t0[j] = pack_top(h0, h1);
-          t1[j] = pack_top(m0, m1);
-          t2[j] = pack_rne(l0, l1);
+          unsigned q0, q1, q2;
+          split3_pair(xv[i][2 * j], xv[i][2 * j + 1], q0, q1, q2);
+          t0[j] = q0;
+          t1[j] = q1;
+          t2[j] = q2;
         }
         Xs[(0 * 2 + ihalf[i]) * PEP + ipos[i]] = t0;
         Xs[(1 * 2 + ihalf[i]) * PEP + ipos[i]] = t1;
@@ -413,22 +415,20 @@ __global__ __launch_bounds__(256) void pack_weights_x3_k(const float* __restrict
       const int row = rb * 32 + row32, k = chunk * 16 + hh * 8 + k8;
       float v = 0.f;
       if (row < R && k < K) v = dir == 0 ? w[(row * Ci + k) * T + t] : w[(k * Ci + row) * T + (T - 1 - t)];
-      unsigned hi, mid;
-      float lo;
-      split3(v, hi, mid, lo);
-      const unsigned lo16 = pack_rne(lo, 0.f) & 0xFFFFu;
+      unsigned q0, q1, q2;
+      split3_pair(v, 0.f, q0, q1, q2);
       const size_t slot = ((((size_t)chunk * (RP / 32) + rb) * T + t) * 6);
       unsigned short* o = packed + base;
-      o[((slot + 0 * 2 + hh) * 32 + row32) * 8 + k8] = (unsigned short)(hi >> 16);
-      o[((slot + 1 * 2 + hh) * 32 + row32) * 8 + k8] = (unsigned short)(mid >> 16);
-      o[((slot + 2 * 2 + hh) * 32 + row32) * 8 + k8] = (unsigned short)lo16;
+      o[((slot + 0 * 2 + hh) * 32 + row32) * 8 + k8] = (unsigned short)(q0 & 0xFFFFu);
+      o[((slot + 1 * 2 + hh) * 32 + row32) * 8 + k8] = (unsigned short)(q1 & 0xFFFFu);
+      o[((slot + 2 * 2 + hh) * 32 + row32) * 8 + k8] = (unsigned short)(q2 & 0xFFFFu);
     }
   }
 }
 
 extern "C" int wtpse_pack_conv_weights_x3(const float* params, const int* desc, int n_desc, unsigned short* packed, void* stream) {
   WTPSE_REQUIRE(params && desc && packed && n_desc > 0);
-  hipLaunchKernelGGL(pack_weights_x3_k, dim3(16, n_desc), dim3(256), 0, (hipStream_t)stream, params, desc, packed);
+  hipLaunchKernelGGL(pack_weights_x3_k, dim3(48, n_desc), dim3(256), 0, (hipStream_t)stream, params, desc, packed);
   return wtpse_status();
 }
 

@@ -33,6 +33,7 @@ class ConvP(nn.Module):
         bound = 1.0 / math.sqrt(cin * k * k)
         nn.init.uniform_(self.bias, -bound, bound)
         self.wf_off = self.wd_off = -1
+        self.xf_off = self.xd_off = -1      # offsets (unsigned shorts) into the root's x3-packed weights; -1: fp32-MFMA path
 
 
 class BNP(nn.Module):
@@ -170,6 +171,8 @@ class HipNet(nn.Module):
         object.__setattr__(self, "_gflat", None)
         object.__setattr__(self, "_gwork", None)
         object.__setattr__(self, "_packed", None)
+        object.__setattr__(self, "_x3", None)
+        object.__setattr__(self, "_xdesc", None)
         object.__setattr__(self, "_packed_version", -1)
         object.__setattr__(self, "_desc", None)
         object.__setattr__(self, "_touched", [])
@@ -192,6 +195,21 @@ class HipNet(nn.Module):
             c.wd_off = off
             off += ((c.cout + 3) & ~3) * t * ((c.cin + 15) & ~15)
         self._packed_size = off
+        # weights of the layers that run on the split-bf16 ("x3") convolution (csrc/conv_x3.hip), pre-split into bf16 triples
+        off = 0
+        self._x3_convs = []
+        for c in self._convs:
+            fwd = x3_eligible(c.cin, c.cout, c.k) and os.environ.get("WTPSE_X3_FWD", "1") != "0"
+            bwd = x3_eligible(c.cout, c.cin, c.k) and os.environ.get("WTPSE_X3_DGRAD", "1") != "0"
+            if fwd:
+                c.xf_off = off
+                off += ops.x3_packed_size(c.cout, c.cin, c.k * c.k)
+            if bwd:
+                c.xd_off = off
+                off += ops.x3_packed_size(c.cin, c.cout, c.k * c.k)
+            if fwd or bwd:
+                self._x3_convs.append(c)
+        self._x3_size = off
 
     # ---- flat storage --------------------------------------------------------------------------------------
     def _is_flat(self):
@@ -233,6 +251,11 @@ class HipNet(nn.Module):
             desc += [self._offsets[self._pindex[id(c.weight)]], c.cout, c.cin, c.k * c.k, c.wf_off, c.wd_off, 0, 0]
         object.__setattr__(self, "_desc", torch.tensor(desc, dtype=torch.int32).to(dev))
         object.__setattr__(self, "_packed_version", -1)
+        object.__setattr__(self, "_x3", torch.empty(max(self._x3_size, 8), dtype=torch.int16, device=dev))
+        xdesc = []
+        for c in self._x3_convs:
+            xdesc += [self._offsets[self._pindex[id(c.weight)]], c.cout, c.cin, c.k * c.k, c.xf_off, c.xd_off, 0, 0]
+        object.__setattr__(self, "_xdesc", torch.tensor(xdesc, dtype=torch.int32).to(dev) if xdesc else None)
         object.__setattr__(self, "_flag", torch.zeros(1, dtype=torch.int32, device=dev))
         # position in this network's Philox stream.  It lives in device memory (advanced by a one-thread launch after each
         # draw) so that nothing that changes from step to step is passed to a kernel by value: a captured step (hipGraph)
@@ -252,6 +275,9 @@ class HipNet(nn.Module):
         if self._packed_version < 0 or (repack and not self._packed_valid):
             ops.lib().call("wtpse_pack_conv_weights", self._flat.data_ptr(), self._desc.data_ptr(), len(self._convs),
                            self._packed.data_ptr(), ops.stream_ptr())
+            if self._xdesc is not None:
+                ops.lib().call("wtpse_pack_conv_weights_x3", self._flat.data_ptr(), self._xdesc.data_ptr(), len(self._x3_convs),
+                               self._x3.data_ptr(), ops.stream_ptr())
             object.__setattr__(self, "_packed_version", 1)
 
     def invalidate_packed(self):
@@ -259,6 +285,9 @@ class HipNet(nn.Module):
 
     def packed_ptr(self, off):
         return self._packed.data_ptr() + 4 * off
+
+    def x3_ptr(self, off):
+        return self._x3.data_ptr() + 2 * off
 
     def flat_params(self):
         self.ensure_ready()
@@ -372,10 +401,27 @@ def _relu_bits(a0, a1):
     return (1 if a0.relu else 0) | (2 if (a1 is not None and a1.relu) else 0)
 
 
+# Convolutions with more than 16 output channels and a K dimension of at least 16 run on the bf16 matrix cores at fp32
+# accuracy (three bf16 terms per fp32 operand, six products, fp32 accumulation: csrc/conv_x3.hip — 1.3-1.8x the fp32-MFMA
+# kernel on these layers); the 16-output-channel layers, the 1-/3-channel input layers and the small 1x1 convs stay on the
+# fp32-input MFMA (csrc/conv.hip).  WTPSE_X3=0 routes everything to the fp32-input MFMA.
+X3 = os.environ.get("WTPSE_X3", "1") != "0"
+
+
+def x3_eligible(k_dim, rows, ksize):
+    """rows = output channels of the launch (Cout forward, Cin for a data gradient), k_dim = its reduction channels."""
+    return X3 and rows > 16 and k_dim >= 16 and (ksize == 3 or k_dim >= 64)
+
+
 def _conv(layer, a0, a1=None, relu_out=False, want_stats=False):
     root = layer._root
     a0 = as_act(a0)
     a1 = as_act(a1) if a1 is not None else None
+    if layer.xf_off >= 0:
+        y, _, stats = ops.conv_fwd_x3(a0.t, a1.t if a1 is not None else None, root.x3_ptr(layer.xf_off), layer.bias, layer.cout,
+                                      layer.k, a0.pro, _relu_bits(a0, a1), relu_out, want_stats, None, None,
+                                      a1.pro if a1 is not None else None)
+        return y, stats
     y, _, stats = ops.conv_fwd(a0.t, a1.t if a1 is not None else None, root.packed_ptr(layer.wf_off), layer.bias, layer.cout,
                                layer.k, a0.pro, _relu_bits(a0, a1), relu_out, want_stats, None, None,
                                a1.pro if a1 is not None else None)
@@ -385,6 +431,9 @@ def _conv(layer, a0, a1=None, relu_out=False, want_stats=False):
 def _dgrad(layer, dy, split=None, mask_ref=None):
     """Data gradient; mask_ref fuses the ReLU backward of the tensor the gradient flows into (d * [ref > 0])."""
     root = layer._root
+    if layer.xd_off >= 0:
+        return ops.conv_fwd_x3(dy, None, root.x3_ptr(layer.xd_off), None, layer.cin, layer.k, None, 0, False, False, split,
+                               mask_ref)[:2]
     return ops.conv_fwd(dy, None, root.packed_ptr(layer.wd_off), None, layer.cin, layer.k, None, 0, False, False, split,
                         mask_ref)[:2]
 
