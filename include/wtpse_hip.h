@@ -58,6 +58,15 @@ int wtpse_conv_wgrad(const float* dy, const float* x0, int C0, const float* x1, 
                      const float* pro1, int pro_relu, float* slab, float* dbias_slab, int ksplit, float* dw, float* dbias, int accumulate, int B, int H,
                      int W, int Cout, int ksize, void* stream);
 int wtpse_wgrad_ksplit(int B, int H, int W, int Cin, int Cout);
+/* The weight gradient in the x3 arithmetic of wtpse_conv_fwd_x3 (csrc/conv_x3.hip: dY and X kept pixel-major in LDS as bf16
+ * triples, fragments fetched with the transposing LDS read).  3x3 convs with Cin, Cout multiples of 32 (C0 % 8 == 0 for a
+ * concat): wtpse_wgrad_x3_supported().  No bias gradient (the conv+BatchNorm layers it serves have none).
+ * slab: [ksplit][Cout*Cin*9], ksplit = wtpse_wgrad_x3_ksplit(...). */
+int wtpse_wgrad_x3_supported(int Cin, int Cout, int ksize, int C0);
+int wtpse_wgrad_x3_ksplit(int B, int H, int W, int Cin, int Cout);
+int wtpse_conv_wgrad_x3(const float* dy, const float* x0, int C0, const float* x1, int C1, const float* pro0,
+                        const float* pro1, int pro_relu, float* slab, int ksplit, float* dw, int accumulate, int B, int H, int W,
+                        int Cout, int ksize, void* stream);
 
 /* ---- BatchNorm2d, eps 1e-5, momentum 0.1 (algorithms.py:862-864) ---------------------------------------------- */
 /* train mode: fold the conv epilogue's partials -> scale_shift[C][2], save_mean/invstd[C]; update running stats

@@ -108,3 +108,42 @@ def test_conv_x3_dgrad(case):
         ref_act = rnd(B, C0, H, W, seed=16)
         dm, _, _ = o.conv_fwd_x3(dy.to(DEV), None, packed.data_ptr() + 2 * xd, None, C0, k, mask_ref=ref_act.to(DEV))
         close(dm, x0.grad * (ref_act > 0).float(), what="dgrad x3 + relu mask")
+
+
+@pytest.mark.parametrize("case", [
+    (2, 32, 0, 32, 16, 32, 3),     # 32x32 block (the 4 waves split the pixels), one 128-pixel tile per 4 rows
+    (3, 32, 0, 32, 20, 40, 3),     # ragged tiles
+    (2, 64, 0, 64, 16, 16, 3),     # 64x64 block (waves = quadrants), 16-wide tiles
+    (2, 32, 32, 64, 24, 48, 3),    # concat, quadrants, ragged 2x32 tiles
+    (2, 64, 0, 32, 12, 36, 3),     # Cout 32: 32x32 blocks over a 64-channel input
+    (1, 128, 128, 256, 8, 8, 3),   # many blocks, image smaller than a tile
+    (4, 96, 0, 64, 32, 32, 3),     # 96 input channels: 32x32 blocks
+    (20, 32, 32, 64, 32, 64, 3),   # several tiles per workgroup
+])
+def test_conv_x3_wgrad(case):
+    o = ops()
+    B, C0, C1, Co, H, W, k = case
+    x0 = rnd(B, C0, H, W, seed=11)
+    x1 = rnd(B, C1, H, W, seed=12) if C1 else None
+    w = rnd(Co, C0 + C1, k, k, seed=13, scale=0.2).requires_grad_(True)
+    dy = rnd(B, Co, H, W, seed=15)
+    pro = torch.stack([rnd(C0 + C1, seed=7) * 0.5 + 1.0, rnd(C0 + C1, seed=8)], 1).contiguous()
+    xin = torch.cat([x0, x1], 1) if C1 else x0
+    act = F.relu(xin * pro[:, 0].view(1, -1, 1, 1) + pro[:, 1].view(1, -1, 1, 1))
+    F.conv2d(act.double(), w.double(), None, padding=k // 2).backward(dy.double())
+    ref64 = w.grad.double()
+    assert o.wgrad_x3_supported(C0 + C1, Co, k, C0 if C1 else 8)
+    dw = torch.full_like(w.detach(), float("nan")).to(DEV)
+    args = (dy.to(DEV), x0.to(DEV), x1.to(DEV) if C1 else None, k)
+    kw = dict(pro0=pro[:C0].contiguous().to(DEV), pro_relu=3, pro1=(pro[C0:].contiguous().to(DEV) if C1 else None))
+    o.conv_wgrad_x3(*args, dw, **kw)
+    scale = float(ref64.abs().max())
+    close(dw, ref64, rtol=2e-4, atol=2e-5 * max(scale, 1.0), what="wgrad x3")
+    dw32 = torch.empty_like(dw)
+    o.conv_wgrad(*args, dw32, None, kw["pro0"], 3, False, kw["pro1"])
+    e3 = float((dw.cpu().double() - ref64).norm() / ref64.norm())
+    e32 = float((dw32.cpu().double() - ref64).norm() / ref64.norm())
+    print("relative L2 error vs fp64: x3 %.2e, fp32 MFMA %.2e" % (e3, e32))
+    assert e3 <= 2.0 * e32 + 2e-8, (e3, e32)
+    o.conv_wgrad_x3(*args, dw, accumulate=True, **kw)
+    close(dw, 2 * ref64, rtol=2e-4, atol=4e-5 * max(scale, 1.0), what="wgrad x3 accumulate")

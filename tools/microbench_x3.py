@@ -22,7 +22,7 @@ def pack_x3(w):
 
 def main():
   B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-  tot = [0.0, 0.0, 0.0, 0.0]
+  tot = [0.0] * 6
   for c0, c1, co, H, k, name in SHAPES:
       if co <= 16 or c0 + c1 < 16:
           continue
@@ -46,8 +46,15 @@ def main():
           d3, _ = timeit(lambda: ops.conv_fwd_x3(dy, None, px.data_ptr() + 2 * xd_off, None, c0 + c1, k, split=(c0 if c1 else None)), 10)
           line += " || dgrad fp32 %7.1f us %5.1f TF | x3 %7.1f us %5.1f TF (%.2fx)" % (d32, flops / d32 / 1e6, d3, flops / d3 / 1e6, d32 / d3)
           tot[2] += d32; tot[3] += d3
+      if ops.wgrad_x3_supported(c0 + c1, co, k, c0 if c1 else 8):
+          dw = torch.empty_like(w)
+          w32, _ = timeit(lambda: ops.conv_wgrad(dy, x0, x1, k, dw, None, pro0, 3, False, pro1), 10)
+          w3, _ = timeit(lambda: ops.conv_wgrad_x3(dy, x0, x1, k, dw, pro0, 3, False, pro1), 10)
+          line += " || wgrad fp32 %7.1f us %5.1f TF | x3 %7.1f us %5.1f TF (%.2fx)" % (w32, flops / w32 / 1e6, w3, flops / w3 / 1e6, w32 / w3)
+          tot[4] += w32; tot[5] += w3
       print(line, flush=True)
-  print("sum: fwd fp32 %.0f us, x3 %.0f us; dgrad fp32 %.0f us, x3 %.0f us" % tuple(tot))
+  print("wgrad (supported layers): fp32 %.0f us, x3 %.0f us" % (tot[4], tot[5]))
+  print("sum: fwd fp32 %.0f us, x3 %.0f us; dgrad fp32 %.0f us, x3 %.0f us" % tuple(tot[:4]))
 
 
 if __name__ == "__main__":

@@ -761,6 +761,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_k(const float* __restrict__ 
   }
 }
 
+// fold of the k-split slabs for other translation units (conv_x3.hip)
+extern "C" void wtpse_wgrad_reduce_launch(const float* slab, int ksplit, int n, float* dw, int accumulate, void* stream) {
+  hipLaunchKernelGGL(wgrad_reduce_k, dim3(ceil_div(n, 32)), dim3(256), 0, (hipStream_t)stream, slab, ksplit, n, dw, accumulate,
+                     ceil_div(n, 32), (const float*)nullptr, 0, (float*)nullptr);
+}
+
 extern "C" int wtpse_wgrad_ksplit(int B, int H, int W, int Cin, int Cout) {
   const int TW = W <= 16 ? 16 : 32, TH = 256 / TW;
   const int ntiles = B * ceil_div(W, TW) * ceil_div(H, TH);

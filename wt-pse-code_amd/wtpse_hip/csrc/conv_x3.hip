@@ -476,3 +476,315 @@ extern "C" int wtpse_conv_fwd_x3(const float* in0, int C0, const float* in1, int
   return mt2 ? X3(1, 2) : X3(1, 1);
 #undef X3
 }
+
+// ================================================================================================
+// Weight gradient on the bf16 matrix cores (x3 arithmetic):  dW[co][ci][t] = sum_{b,y,x} dY[b,co,y,x] * X[b,ci,y+dy-1,x+dx-1]
+// (conv weight gradients of the reference hot path: autograd of algorithms.py:882-888,926-933).  GEMM with K = pixels:
+// A = dY[co][pixel], B = X[ci][pixel + tap]; one accumulator tile [32 co][32 ci] per tap.  The bf16 MFMA wants 8
+// consecutive k (pixels) per lane and NCHW gives 8 consecutive pixels only at aligned addresses, while the taps shift B by
+// -1/0/+1 pixels.  So both operands are kept PIXEL-major in LDS ([8-channel group][pixel][8 ch], bf16 triples, written by
+// the same split-on-load loader as the forward kernel) and read with ds_read_b64_tr_b16: a 16-lane group fetches a block of
+// 4 pixels x 16 channels and receives it channel-major, i.e. 4 consecutive k of "its" channel — a tap is then just a
+// different starting pixel.  Plane strides are = 4 or 12 (mod 16) 16-byte slots: the 4 planes a 32-lane half touches land
+// on disjoint banks.
+//   Q  (64 co x 64 ci per workgroup): the 4 waves are the quadrants; every wave walks all k-steps of a 64-pixel tile.
+//   !Q (32 co x 32 ci):               the 4 waves split the k-steps of a 128-pixel tile; partial sums meet in LDS at the end.
+// Accumulators persist over a workgroup's tiles (strided by the k-split); per-workgroup slabs are folded by wgrad_reduce_k.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+struct WgradX3Args {
+  const float* dy;
+  const float* x0;
+  const float* x1;
+  const float* pro0;
+  const float* pro1;
+  float* slab;    // [ksplit][Cout][Cin][taps]
+  int B, H, W, C0, C1, Cin, Cout;
+  int pro_relu;
+  int tiles_x, tiles_y, ntiles;
+  int nci;        // ci blocks
+};
+
+__device__ __forceinline__ bf16x8 lds_tr8(const u32x4v* base, int byte_off) {
+  // two transposed reads: pixels +0..3 and +4..7 (4 slots = 64 bytes further)
+  typedef s16x4 __attribute__((address_space(3))) * lds_p;
+  const char __attribute__((address_space(3)))* p =
+      (const char __attribute__((address_space(3)))*)base + byte_off;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)p);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p + 64));
+  const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+constexpr int pad_plane(int n) {   // smallest m >= n with m % 16 in {4, 12}
+  for (int m = n;; ++m)
+    if (m % 16 == 4 || m % 16 == 12) return m;
+}
+
+template <int KS, int TWL, bool Q>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_x3_k(WgradX3Args a) {
+  constexpr int TAPS = KS * KS, PAD = KS / 2;
+  constexpr int NPX = Q ? 64 : 128;
+  constexpr int TW = 1 << TWL, TH = NPX >> TWL;
+  constexpr int PITCH = TW + 2 * PAD, ROWS = TH + 2 * PAD;
+  constexpr int PE = PITCH * ROWS;
+  constexpr int NCG = Q ? 8 : 4;                      // 8-channel groups per image
+  constexpr int BLK = NCG * 8;                        // channels per workgroup block (co and ci)
+  constexpr int XP = pad_plane(PE), YP = pad_plane(NPX);
+  constexpr int XS_U4 = 3 * NCG * XP, YS_U4 = 3 * NCG * YP;
+  constexpr int RED_U4 = Q ? 0 : 4 * 1024 / 4;        // !Q: [4 waves][32][32] floats
+  constexpr int SM_U4 = (XS_U4 + YS_U4) > RED_U4 ? (XS_U4 + YS_U4) : RED_U4;
+  __shared__ u32x4v smem[SM_U4];
+  u32x4v* Xs = smem;
+  u32x4v* Ys = smem + XS_U4;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // one k-slice per XCD (see conv_wgrad_k): its workgroups read the same tiles
+  int bx = blockIdx.x, ky = blockIdx.y;
+  if ((gridDim.y & 7) == 0) {
+    const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const int k = lin >> 3;
+    ky = (lin & 7) + 8 * (k / (int)gridDim.x);
+    bx = k % (int)gridDim.x;
+  }
+  const int cin0 = (bx % a.nci) * BLK, cout0 = (bx / a.nci) * BLK;
+  const int HW = a.H * a.W;
+  const int wco = Q ? (wave >> 1) : 0, wci = Q ? (wave & 1) : 0;
+  const bool any_pro = a.pro0 != nullptr || a.pro1 != nullptr || a.pro_relu != 0;
+
+  // transposed-read lane geometry: group g = lane >> 4 (k half h = g >> 1, channel half g & 1), q = row of the 4-pixel block,
+  // p = which 4 of the group's 16 channels this lane addresses
+  const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3, h = g >> 1;
+  const int cgl = 2 * (g & 1) + (p >> 1);              // 8-channel group within the wave's 32 channels
+  const int a_base = (((wco * 4 + cgl) * YP) + 8 * h + q) * 16 + 8 * (p & 1);
+  const int b_base = (((wci * 4 + cgl) * XP) + 8 * h + q) * 16 + 8 * (p & 1);
+
+  f32x16 acc[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // loader items: 64-position blocks [group][block], dealt to the waves round-robin (a wave's group is uniform)
+  constexpr int PBX = (PE + 63) / 64, NITX = (NCG * PBX + 3) / 4;
+  constexpr int PBY = NPX / 64, NITY = NCG * PBY / 4;
+  const int tiles_per_img = a.tiles_x * a.tiles_y;
+
+  for (int tile = ky; tile < a.ntiles; tile += gridDim.y) {
+    const int b = tile / tiles_per_img;
+    const int trem = tile - b * tiles_per_img;
+    const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
+    const __amdgpu_buffer_rsrc_t rsy = make_rsrc(a.dy + (size_t)b * a.Cout * HW, (unsigned)a.Cout * HW * 4u);
+    const __amdgpu_buffer_rsrc_t rsx0 = make_rsrc(a.x0 + (size_t)b * a.C0 * HW, (unsigned)a.C0 * HW * 4u);
+    const __amdgpu_buffer_rsrc_t rsx1 = a.x1 ? make_rsrc(a.x1 + (size_t)b * a.C1 * HW, (unsigned)a.C1 * HW * 4u) : rsx0;
+    __syncthreads();   // the previous tile's MFMAs are done with the images
+    // ---- X halo tile: (position, 8-channel group) items, two at a time (16 loads in flight per lane; the scheduling
+    // barriers keep the compiler from hoisting every item's loads to the top, which spills beside 144 accumulators)
+    auto x_item = [&](int i, float (&v)[8], int& cg, int& pos, bool& in, bool& first, int& cb, int& cn) {
+      const int blk = __builtin_amdgcn_readfirstlane(i * 4 + wave);
+      cg = blk / PBX;
+      pos = (blk - cg * PBX) * 64 + lane;
+      const int r = pos / PITCH, x = pos - r * PITCH;
+      const int gy = ty * TH + r - PAD, gx = tx * TW + x - PAD;
+      in = blk < NCG * PBX && pos < PE && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      if (blk >= NCG * PBX) pos = PE;                    // a padding block of the last round: nothing to store
+      const unsigned vo = in ? (unsigned)(gy * a.W + gx) * 4u : BUF_OOB;
+      const int c = cin0 + min(cg, NCG - 1) * 8;         // first channel of the group; C0 % 8 == 0: never straddles
+      first = c < a.C0 || a.x1 == nullptr;
+      const __amdgpu_buffer_rsrc_t rs = first ? rsx0 : rsx1;
+      cb = first ? c : c - a.C0;
+      cn = first ? a.C0 : a.C1;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = buf_load(rs, vo, (unsigned)min(cb + j, cn) * (unsigned)HW * 4u);
+    };
+    auto x_finish = [&](float (&v)[8], int cg, int pos, bool in, bool first, int cb, int cn) {
+      if (any_pro) {
+        const bool relu = first ? (a.pro_relu & 1) : (a.pro_relu & 2);
+        const float* pro = first ? a.pro0 : a.pro1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int cgi = min(cb + j, cn - 1);
+          const float sc = pro ? pro[2 * cgi] : 1.f, sh = pro ? pro[2 * cgi + 1] : 0.f;
+          float w = fmaf(v[j], sc, sh);
+          if (relu) w = fmaxf(w, 0.f);
+          v[j] = in ? w : 0.f;
+        }
+      }
+      if (pos < PE) {
+        u32x4v t0, t1, t2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          unsigned q0, q1, q2;
+          split3_pair(v[2 * j], v[2 * j + 1], q0, q1, q2);
+          t0[j] = q0; t1[j] = q1; t2[j] = q2;
+        }
+        Xs[(0 * NCG + cg) * XP + pos] = t0;
+        Xs[(1 * NCG + cg) * XP + pos] = t1;
+        Xs[(2 * NCG + cg) * XP + pos] = t2;
+      }
+    };
+#pragma unroll
+    for (int i = 0; i < NITX; i += 2) {
+      float v0[8], v1[8];
+      int cg0, pos0, cb0, cn0, cg1 = 0, pos1 = PE, cb1 = 0, cn1 = 1;
+      bool in0, f0, in1 = false, f1 = true;
+      x_item(i, v0, cg0, pos0, in0, f0, cb0, cn0);
+      if (i + 1 < NITX) x_item(i + 1, v1, cg1, pos1, in1, f1, cb1, cn1);
+      x_finish(v0, cg0, pos0, in0, f0, cb0, cn0);
+      if (i + 1 < NITX) x_finish(v1, cg1, pos1, in1, f1, cb1, cn1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- dY tile: (pixel, 8-channel group) items
+#pragma unroll
+    for (int i = 0; i < NITY; ++i) {
+      const int blk = __builtin_amdgcn_readfirstlane(i * 4 + wave);
+      const int cg = blk / PBY;
+      const int px = (blk - cg * PBY) * 64 + lane;
+      const int gy = ty * TH + (px >> TWL), gx = tx * TW + (px & (TW - 1));
+      const unsigned vo = (gy < a.H && gx < a.W) ? (unsigned)(gy * a.W + gx) * 4u : BUF_OOB;
+      const int c = cout0 + cg * 8;
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = buf_load(rsy, vo, (unsigned)min(c + j, a.Cout) * (unsigned)HW * 4u);
+      u32x4v t0, t1, t2;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        unsigned q0, q1, q2;
+        split3_pair(v[2 * j], v[2 * j + 1], q0, q1, q2);
+        t0[j] = q0; t1[j] = q1; t2[j] = q2;
+      }
+      Ys[(0 * NCG + cg) * YP + px] = t0;
+      Ys[(1 * NCG + cg) * YP + px] = t1;
+      Ys[(2 * NCG + cg) * YP + px] = t2;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    // ---- MFMAs: k-steps of 16 consecutive pixels of one tile row
+    constexpr int NSTEP = Q ? NPX / 16 : NPX / 64;
+    // software pipeline over (k-step, tap): the 6 transposed reads of the next tap's B fragments (and, at a step's last
+    // tap, of the next step's A fragments) are issued before the 6 MFMAs of the current tap; the scheduling barriers keep
+    // the compiler from hoisting reads further ahead (it did, and spilled the fragments beside the 144 accumulators)
+    auto step_p0 = [&](int s) { return (Q ? s : wave * NSTEP + s) * 16; };
+    auto load_a = [&](int s, bf16x8 (&af)[3]) {
+      const int p0 = step_p0(s);
+#pragma unroll
+      for (int t = 0; t < 3; ++t) af[t] = lds_tr8(Ys, a_base + (t * NCG * YP + p0) * 16);
+    };
+    auto load_b = [&](int s, int tap, bf16x8 (&bfr)[3]) {
+      const int p0 = step_p0(s);
+      const int toff = ((p0 >> TWL) + tap / KS) * PITCH + (p0 & (TW - 1)) + tap % KS;
+#pragma unroll
+      for (int t = 0; t < 3; ++t) bfr[t] = lds_tr8(Xs, b_base + (t * NCG * XP + toff) * 16);
+    };
+    bf16x8 af[2][3], bfr[2][3];
+    load_a(0, af[0]);
+    load_b(0, 0, bfr[0]);
+#pragma unroll
+    for (int idx = 0; idx < NSTEP * TAPS; ++idx) {
+      const int s = idx / TAPS, tap = idx % TAPS;
+      const int cur = idx & 1, acur = s & 1;
+      if (idx + 1 < NSTEP * TAPS) {
+        load_b((idx + 1) / TAPS, (idx + 1) % TAPS, bfr[cur ^ 1]);
+        if (tap == TAPS - 1) load_a(s + 1, af[acur ^ 1]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      f32x16 c = acc[tap];
+      c = mfma_bf16(af[acur][0], bfr[cur][2], c);
+      c = mfma_bf16(af[acur][1], bfr[cur][1], c);
+      c = mfma_bf16(af[acur][2], bfr[cur][0], c);
+      c = mfma_bf16(af[acur][0], bfr[cur][1], c);
+      c = mfma_bf16(af[acur][1], bfr[cur][0], c);
+      c = mfma_bf16(af[acur][0], bfr[cur][0], c);
+      acc[tap] = c;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // ---- slab[ky][co][ci][t]
+  float* slab = a.slab + (size_t)ky * a.Cout * a.Cin * TAPS;
+  if constexpr (Q) {
+    const int ci = cin0 + wci * 32 + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = cout0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (co < a.Cout && ci < a.Cin) {
+        float* dst = slab + ((size_t)co * a.Cin + ci) * TAPS;
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) dst[t] = acc[t][r];
+      }
+    }
+  } else {
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        red[(wave * 32 + co) * 32 + (lane & 31)] = acc[t][r];
+      }
+      __syncthreads();
+      for (int e = tid; e < 1024; e += 256) {
+        const int co = e >> 5, ci = e & 31;
+        const float v = red[e] + red[1024 + e] + red[2048 + e] + red[3072 + e];
+        if (cout0 + co < a.Cout && cin0 + ci < a.Cin) slab[((size_t)(cout0 + co) * a.Cin + cin0 + ci) * TAPS + t] = v;
+      }
+    }
+  }
+}
+
+static bool wgrad_x3_quadrants(int Cin, int Cout) { return Cin % 64 == 0 && Cout % 64 == 0; }
+
+extern "C" int wtpse_wgrad_x3_supported(int Cin, int Cout, int ksize, int C0) {
+  return ksize == 3 && Cin >= 32 && Cout >= 32 && Cin % 32 == 0 && Cout % 32 == 0 && C0 % 8 == 0;
+}
+
+extern "C" int wtpse_wgrad_x3_ksplit(int B, int H, int W, int Cin, int Cout) {
+  const bool q = wgrad_x3_quadrants(Cin, Cout);
+  const int TW = W <= 16 ? 16 : 32, TH = (q ? 64 : 128) / TW;
+  const int ntiles = B * ceil_div(W, TW) * ceil_div(H, TH);
+  const int blk = q ? 64 : 32;
+  const int nx = (Cout / blk) * (Cin / blk);
+  int ks = 512 / nx;   // two workgroups per CU
+  if (ks < 1) ks = 1;
+  if (ks > ntiles) ks = ntiles;
+  return ks;
+}
+
+extern "C" void wtpse_wgrad_reduce_launch(const float* slab, int ksplit, int n, float* dw, int accumulate, void* stream);
+
+// Same contract as wtpse_conv_wgrad (include/wtpse_hip.h) without the bias gradient; requires wtpse_wgrad_x3_supported().
+extern "C" int wtpse_conv_wgrad_x3(const float* dy, const float* x0, int C0, const float* x1, int C1, const float* pro0,
+                                   const float* pro1, int pro_relu, float* slab, int ksplit, float* dw, int accumulate, int B,
+                                   int H, int W, int Cout, int ksize, void* stream) {
+  WTPSE_REQUIRE(dy && x0 && slab && dw && B > 0 && H > 0 && W > 0 && C0 > 0 && C1 >= 0 && Cout > 0 && ksplit > 0);
+  WTPSE_REQUIRE((C1 == 0) == (x1 == nullptr));
+  const int Cin = C0 + C1;
+  WTPSE_REQUIRE(wtpse_wgrad_x3_supported(Cin, Cout, ksize, C1 ? C0 : 8));
+  const bool q = wgrad_x3_quadrants(Cin, Cout);
+  WgradX3Args a;
+  a.dy = dy; a.x0 = x0; a.x1 = x1; a.pro0 = pro0; a.pro1 = pro1; a.slab = slab;
+  a.B = B; a.H = H; a.W = W; a.C0 = C0; a.C1 = C1; a.Cin = Cin; a.Cout = Cout; a.pro_relu = pro_relu;
+  const bool narrow = W <= 16;
+  const int TW = narrow ? 16 : 32, TH = (q ? 64 : 128) / TW;
+  a.tiles_x = ceil_div(W, TW);
+  a.tiles_y = ceil_div(H, TH);
+  a.ntiles = B * a.tiles_x * a.tiles_y;
+  WTPSE_REQUIRE(ksplit <= a.ntiles);
+  const int blk = q ? 64 : 32;
+  a.nci = Cin / blk;
+  dim3 grid((unsigned)((Cout / blk) * a.nci), (unsigned)ksplit);
+  hipStream_t st = (hipStream_t)stream;
+  if (q) {
+    if (narrow) hipLaunchKernelGGL((conv_wgrad_x3_k<3, 4, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv_wgrad_x3_k<3, 5, true>), grid, dim3(256), 0, st, a);
+  } else {
+    if (narrow) hipLaunchKernelGGL((conv_wgrad_x3_k<3, 4, false>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv_wgrad_x3_k<3, 5, false>), grid, dim3(256), 0, st, a);
+  }
+  int rc = wtpse_status();
+  if (rc) return rc;
+  wtpse_wgrad_reduce_launch(slab, ksplit, Cout * Cin * 9, dw, accumulate, stream);
+  return wtpse_status();
+}

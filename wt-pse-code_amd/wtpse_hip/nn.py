@@ -406,6 +406,7 @@ def _relu_bits(a0, a1):
 # kernel on these layers); the 16-output-channel layers, the 1-/3-channel input layers and the small 1x1 convs stay on the
 # fp32-input MFMA (csrc/conv.hip).  WTPSE_X3=0 routes everything to the fp32-input MFMA.
 X3 = os.environ.get("WTPSE_X3", "1") != "0"
+X3_WGRAD = os.environ.get("WTPSE_X3_WGRAD", "1") != "0"
 
 
 def x3_eligible(k_dim, rows, ksize):
@@ -503,6 +504,11 @@ def _wgrad(layer, dy, a0, a1=None, with_bias=True):
     a1 = as_act(a1) if a1 is not None else None
     dw = root.gview(layer.weight)
     db = root.gview(layer.bias) if with_bias else None
+    if (X3 and X3_WGRAD and db is None and
+            ops.wgrad_x3_supported(layer.cin, layer.cout, layer.k, a0.t.shape[1] if a1 is not None else 8)):
+        ops.conv_wgrad_x3(dy, a0.t, a1.t if a1 is not None else None, layer.k, dw, a0.pro, _relu_bits(a0, a1), False,
+                          a1.pro if a1 is not None else None)
+        return
     ops.conv_wgrad(dy, a0.t, a1.t if a1 is not None else None, layer.k, dw, db, a0.pro, _relu_bits(a0, a1), False,
                    a1.pro if a1 is not None else None)
 

@@ -110,6 +110,24 @@ def conv_wgrad(dy, x0, x1, ksize, dw, dbias, pro0=None, pro_relu=0, accumulate=F
            ptr(dw), ptr(dbias), int(accumulate), B, H, W, cout, ksize, stream_ptr())
 
 
+def wgrad_x3_supported(cin, cout, ksize, c0):
+    return bool(lib().query("wtpse_wgrad_x3_supported", int(cin), int(cout), int(ksize), int(c0)))
+
+
+def conv_wgrad_x3(dy, x0, x1, ksize, dw, pro0=None, pro_relu=0, accumulate=False, pro1=None):
+    """conv_wgrad in the x3 arithmetic (csrc/conv_x3.hip); no bias gradient."""
+    _chk(dy, "dy"); _chk(x0, "x0"); _chk(x1, "x1")
+    B, cout, H, W = dy.shape
+    C0 = x0.shape[1]
+    C1 = 0 if x1 is None else x1.shape[1]
+    cin = C0 + C1
+    L = lib()
+    ks = L.query("wtpse_wgrad_x3_ksplit", B, H, W, cin, cout)
+    slab = workspace("wgrad_slab", ks * cout * cin * ksize * ksize, dy.device)
+    L.call("wtpse_conv_wgrad_x3", ptr(dy), ptr(x0), C0, ptr(x1), C1, ptr(pro0), ptr(pro1), int(pro_relu), ptr(slab), ks, ptr(dw),
+           int(accumulate), B, H, W, cout, ksize, stream_ptr())
+
+
 # ----------------------------------------------------------------------------------------------- batch norm
 def bn_finalize(stats, count, gamma, beta, rmean, rvar, nbt, momentum=0.1, eps=1e-5):
     nblk, C, _ = stats.shape
