@@ -44,9 +44,10 @@ def parse():
     ap.add_argument("--workload", choices=["full", "seg"], default="full",
                     help="full = configs[2] (seg + shape nets + WT loss); seg = configs[1] (seg-net only)")
     ap.add_argument("--bn-sync", type=int, default=0, help="1: BatchNorm statistics over the global batch (parity mode)")
-    ap.add_argument("--graph", type=int, default=0,
-                    help="1: replay the step from HIP graphs (TrainStep(graph=True)); 0 (default): eager launches — measured on "
-                         "ROCm 7.0's runtime a replay costs the host 40-60 ms per step and serialises the streams (88 vs 80 ms/step)")
+    ap.add_argument("--launch", choices=["plan", "eager", "graph"], default="plan",
+                    help="plan (default): the step is recorded once and replayed from native code (csrc/plan.hip; exact "
+                         "data-parallel mode always runs eagerly); eager: one ctypes call per launch; graph: hipGraph replay "
+                         "(slower than eager on this runtime, profiles/r02_hipgraph_vs_eager.txt)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-full", action="store_true",
                     help="SURVEY.md 8d protocol in full: 3 warm-up + 10 timed iterations at B=6 and B=30 (minutes of CPU time)")
@@ -287,7 +288,7 @@ def main():
     B, H = args.batch, args.size
     pb = B // 3                                  # per-domain rows on this rank; the MMD sees 3*pb*world rows
     nets = build_nets(hp, pb, dev)
-    ts = TrainStep(*nets, hp, dp=dp, graph=bool(args.graph))
+    ts = TrainStep(*nets, hp, dp=dp, graph={"plan": "plan", "graph": True, "eager": False}[args.launch])
     image, target_od, target_oc = make_batch(B, H, H, dev, seed=1 + rank)
 
     def barrier():
@@ -299,10 +300,12 @@ def main():
     def timed(nsteps):
         """barrier + sync, nsteps steps, barrier + sync; -> (seconds = max over ranks, host enqueue seconds, last losses)"""
         barrier()
+        c0 = time.process_time()
         t0 = time.perf_counter()
         for _ in range(nsteps):
             res = ts.step(image, target_od, target_oc)
-        t_host = time.perf_counter() - t0        # host time to enqueue the steps (no GPU wait inside a step)
+        t_host = time.perf_counter() - t0        # host wall time to enqueue the steps: includes the time the runtime holds the
+        timed.cpu = time.process_time() - c0     # thread back when the launch queues are full; .cpu = CPU time actually spent
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -365,9 +368,10 @@ def main():
                                     "BASELINE.json configs[1]: seg-net only") + ", 3x%dx%d, batch %d per GPU" % (H, H, B),
                        "global_batch": B * world, "image": [3, H, H], "parallelism": "dp%d" % world,
                        "bn_sync": bool(args.bn_sync), "step": "calls A-D + 4 backward + 4 Adam (Trainer.py:766-914)",
-                       "launch": "hipGraph replay" if ts.graph else "eager",
+                       "launch": ("native launch plan" if ts.plan else "hipGraph replay") if ts.graph else "eager",
                        "roi": "od_pred covers %.3f of the pixels after %d untimed set-up steps" % (frac, presteps)},
             "host_enqueue_ms_per_step": 1e3 * t_host / args.steps,
+            "host_cpu_ms_per_step": 1e3 * timed.cpu / args.steps,
             "conv_tflops_end_to_end": ips * GFLOP_PER_IMAGE * (H * H / 65536.0) / 1e3 if full else None,
             "losses": losses,
         }

@@ -217,6 +217,19 @@ int wtpse_axpy(float* dst, const float* src, float alpha, long long n, void* str
 int wtpse_reduce_rows(const float* partial, int rows, int cols, float* out, int accumulate, float scale, void* stream);
 int wtpse_zero(void* p, long long nbytes, void* stream);
 
+/* ---- launch plans (csrc/plan.hip): a recorded sequence of the calls above, replayed with one host call ------------------
+ * wtpse_plan_add_call: `fn` indexes the entry points that take a stream (wtpse_plan_fn_name(fn), 0 <= fn < wtpse_plan_fn_count());
+ * `args`: its arguments without the trailing stream, one 8-byte slot each (pointer / long long / unsigned long long / double).
+ * wtpse_plan_add_wait: stream `waiter` waits for everything issued so far on stream `waited`. */
+int wtpse_plan_fn_count(void);
+const char* wtpse_plan_fn_name(int id);
+void* wtpse_plan_create(void);
+int wtpse_plan_destroy(void* plan);
+int wtpse_plan_size(void* plan);
+int wtpse_plan_add_call(void* plan, int fn, const void* args, int nargs, void* stream);
+int wtpse_plan_add_wait(void* plan, void* waiter, void* waited);
+int wtpse_plan_replay(void* plan);
+
 /* Fingerprint (hex) of the sources and of this header the library was compiled from; the binding refuses a library
  * whose fingerprint differs from the tree's (a stale .so after a signature change would otherwise go unnoticed). */
 const char* wtpse_source_hash(void);

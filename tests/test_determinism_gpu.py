@@ -41,12 +41,14 @@ def test_two_runs_bitwise_identical():
 
 
 @pytest.mark.gpu
-def test_captured_step_equals_eager_step():
-    """The step replayed from HIP graphs (TrainStep(graph=True)) against the same step launched eagerly: same kernels, same
-    order of every reduction, the Adam step number and the Philox position read from device memory in both — the
-    parameters of all four networks, their BatchNorm buffers and the losses must agree bit for bit after 4 steps on
-    changing batches (fresh sampling noise and bias corrections on every replay)."""
+@pytest.mark.parametrize("mode", ["plan", True])
+def test_captured_step_equals_eager_step(mode):
+    """The step replayed from native launch plans (TrainStep(graph="plan")) or from HIP graphs (graph=True) against the same
+    step launched eagerly: same kernels, same order of every reduction, the Adam step number and the Philox position read
+    from device memory in both — the parameters of all four networks, their BatchNorm buffers and the losses must agree
+    bit for bit after 4 steps on changing batches (fresh sampling noise and bias corrections on every replay)."""
     import bench
+    from wtpse_hip import ops
     from wtpse_hip.step import TrainStep
     from wtpse_hip.synth import make_batch, default_hparams
     dev = torch.device("cuda:0")
@@ -65,12 +67,14 @@ def test_captured_step_equals_eager_step():
             res = ts.step(image, od, oc)
             losses.append({k2: float(v) for k2, v in res.items()})
         torch.cuda.synchronize()
-        assert (ts._graphs is not None) == graph
+        assert (ts._graphs is not None) == bool(graph)
+        if graph == "plan":
+            assert sum(ops.lib().raw("wtpse_plan_size")(p) for _, _, p in ts._graphs) > 1000
         bufs = [torch.cat([b.detach().reshape(-1).double() for b in n.buffers()]) for n in nets]
         return [n.flat_params().clone() for n in nets], bufs, losses, [o.t for o in ts.opt.values()]
 
     pe, be, le, te = run(False)
-    pg, bg, lg, tg = run(True)
+    pg, bg, lg, tg = run(mode)
     assert te == tg == [4, 4, 4, 4]
     assert all(v == v for d in lg for v in d.values()), lg
     assert le == lg, (le, lg)

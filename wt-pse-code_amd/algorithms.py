@@ -212,14 +212,14 @@ class WT_PSE(E.HipNet, E.UNetBody):
         second = None if (self._dp is not None and self._dp.exact) else E.second_stream(inputs.device)
         if second is not None:
             main = torch.cuda.current_stream()
-            second.wait_stream(main)
+            E.stream_wait(second, main)
             with torch.cuda.stream(second):
                 w, th, eps, z_post, st1, st2, scal = prior_chain()
         emb = self._embedding(inputs, training, t if want_tape else None)
         if second is None:
             w, th, eps, z_post, st1, st2, scal = prior_chain()
         else:
-            main.wait_stream(second)
+            E.stream_wait(main, second)
             z_post.record_stream(main)
             scal.record_stream(main)
         att, _, att_mask, fuse = ops.attn_fuse_fwd(z_post, self.attention_layer.layer1.weight.data_ptr(), emb, coef,
@@ -273,7 +273,7 @@ class WT_PSE(E.HipNet, E.UNetBody):
             second = None if (self._dp is not None and self._dp.exact) else E.second_stream(dz_post.device)
             if second is not None:
                 main = torch.cuda.current_stream()
-                second.wait_stream(main)
+                E.stream_wait(second, main)
                 with torch.cuda.stream(second):
                     prior_chain_bwd()
                 for g in (dz_post, gi, gd):

@@ -127,7 +127,7 @@ class ShapeVariationalDist_x(E.HipNet, E.UNetBody):
         side = None if synced else E.second_stream(x.device)
         if side is not None:
             main = torch.cuda.current_stream()
-            side.wait_stream(main)
+            E.stream_wait(side, main)
             with torch.cuda.stream(side):
                 mu_t = teacher()
         else:
@@ -136,7 +136,7 @@ class ShapeVariationalDist_x(E.HipNet, E.UNetBody):
         w2 = E.deepwt_fwd(self.wt_model, x, want_tape)
         mu_s = self._student_mu(E.Act(w2.z2, None, True), training, t if want_tape else None)
         if side is not None:
-            main.wait_stream(side)
+            E.stream_wait(main, side)
             mu_t.record_stream(main)
         scal = torch.empty((5,), dtype=torch.float32, device=x.device)   # (kd, ins_total, ins_off, ins_diag, dom)
         ops.mse_fwd(mu_t, mu_s, out=scal[0:1])

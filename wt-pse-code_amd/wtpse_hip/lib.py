@@ -24,6 +24,15 @@ class WtpseError(RuntimeError):
     pass
 
 
+class PlanArg(ctypes.Union):
+    """One argument slot of a recorded call (csrc/plan.hip)."""
+    _fields_ = [("p", ctypes.c_void_p), ("i", ctypes.c_longlong), ("u", ctypes.c_ulonglong), ("d", ctypes.c_double)]
+
+
+_SLOT = {ctypes.c_void_p: "p", ctypes.c_int: "i", ctypes.c_longlong: "i", ctypes.c_ulonglong: "u", ctypes.c_float: "d",
+         ctypes.c_double: "d"}
+
+
 def parse_header(path=HEADER_PATH):
     """-> {name: [ctypes arg types]} for every `int wtpse_*(...)` declaration."""
     text = open(path).read()
@@ -78,11 +87,56 @@ class _Lib:
             fn.argtypes = argtypes
             fn.restype = ctypes.c_int
             setattr(self, "_raw_" + name, fn)
+        # launch plans: entry points that can be recorded, by name
+        self._dll.wtpse_plan_create.restype = ctypes.c_void_p
+        self._dll.wtpse_plan_fn_name.restype = ctypes.c_char_p
+        self._plan_fn = {self._dll.wtpse_plan_fn_name(i).decode(): i for i in range(self._dll.wtpse_plan_fn_count())}
+        self._rec = None                         # the plan being recorded (a c_void_p value) or None
+
+    # ---- launch plans (csrc/plan.hip) ----------------------------------------------------------------------------
+    def plan_begin(self):
+        """Start recording every call() into a new plan (the calls are still issued: under stream capture they only enter
+        the capture).  -> opaque plan handle."""
+        assert self._rec is None, "a plan is already being recorded"
+        self._rec = self._dll.wtpse_plan_create()
+        return self._rec
+
+    def plan_end(self):
+        plan, self._rec = self._rec, None
+        return plan
+
+    def plan_wait(self, waiter, waited):
+        """Record: stream `waiter` waits for stream `waited` (raw hipStream_t values).  No-op when not recording."""
+        if self._rec is not None and waiter != waited:
+            rc = self._raw_wtpse_plan_add_wait(self._rec, waiter, waited)
+            if rc:
+                raise WtpseError("wtpse_plan_add_wait failed with status %d" % rc)
+
+    def plan_replay(self, plan):
+        rc = self._raw_wtpse_plan_replay(plan)
+        if rc:
+            raise WtpseError("wtpse_plan_replay failed with status %d" % rc)
+
+    def plan_destroy(self, plan):
+        self._raw_wtpse_plan_destroy(plan)
+
+    def _record(self, name, args):
+        types = self.protos[name]
+        n = len(types) - 1                       # the trailing stream is stored separately
+        arr = (PlanArg * max(n, 1))()
+        for k in range(n):
+            v = args[k]
+            setattr(arr[k], _SLOT[types[k]], 0 if v is None else v)
+        rc = self._raw_wtpse_plan_add_call(self._rec, self._plan_fn[name], arr, n, args[n])
+        if rc:
+            raise WtpseError("cannot record %s (status %d)" % (name, rc))
 
     def raw(self, name):
         return getattr(self, "_raw_" + name)
 
     def call(self, name, *args):
+        if self._rec is not None and name in self._plan_fn:
+            self._record(name, args)
         rc = getattr(self, "_raw_" + name)(*args)
         if rc != 0:
             raise WtpseError("%s failed with status %d%s" % (name, rc, " (invalid argument)" if rc == -1 else " (hipError_t)"))

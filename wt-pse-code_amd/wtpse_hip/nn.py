@@ -325,7 +325,7 @@ class HipNet(nn.Module):
         if joins:                                   # helper streams this backward put work on (weight gradients, prior chain)
             cur = torch.cuda.current_stream()
             for st in joins:
-                cur.wait_stream(st)
+                stream_wait(cur, st)
             joins.clear()
         if self._dp is not None and not self.__dict__.get("_defer_allreduce"):     # the step harness issues it itself
             self._dp.allreduce_grads(self, self._gtarget)
@@ -470,6 +470,12 @@ def second_stream(device):
     return st
 
 
+def stream_wait(waiter, waited):
+    """waiter.wait_stream(waited), also entered into the launch plan being recorded (wtpse_hip/lib.py), if any."""
+    waiter.wait_stream(waited)
+    ops.lib().plan_wait(waiter.cuda_stream, waited.cuda_stream)
+
+
 def note_join(root, stream):
     """end_backward() of `root` must wait for `stream`."""
     j = root.__dict__.get("_join")
@@ -488,7 +494,7 @@ def _wgrad_side(layer, dy, a0, a1=None):
         return _wgrad(layer, dy, a0, a1, with_bias=False)
     main = torch.cuda.current_stream()
     side = _side_stream(dy.device)
-    side.wait_stream(main)
+    stream_wait(side, main)
     with torch.cuda.stream(side):
         _wgrad(layer, dy, a0, a1, with_bias=False)
     a0 = as_act(a0)

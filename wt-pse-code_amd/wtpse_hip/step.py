@@ -13,12 +13,18 @@ Differences from the reference loop that cannot change a result: no per-iteratio
 tensorboard scalars (losses stay on the device), fused Adam over the flat parameter buffer instead of ~390
 per-tensor updates, and the dead work listed in shape_networks.py's header is skipped.
 
-hipGraph: a step is ~1 900 kernel launches from one Python thread (tens of milliseconds of host time, about as long
-as the GPU needs for them).  `TrainStep(..., graph=True)` captures the step once into HIP graphs and replays them:
-the C ABI allocates nothing, never synchronises and takes nothing that changes from step to step by value (Adam's step
-number and the Philox stream position live in device memory), so every launch is capture-legal.  With data-parallel
-training the gradient all-reduces stay outside the graphs (RCCL runs them eagerly between the replayed segments):
-a step is then five graphs with four collectives between them.
+Replaying a recorded step: a step is ~1 900 kernel launches from one Python thread (tens of milliseconds of host time,
+about as long as the GPU needs for them).  The C ABI allocates nothing, never synchronises and takes nothing that changes
+from step to step by value (Adam's step number and the Philox stream position live in device memory), so a step can be
+recorded once and replayed:
+  * `TrainStep(..., graph="plan")`: the step is recorded under stream capture — which pins every device address: the
+    allocator serves the capture from a private pool and defers cross-stream frees — into native launch plans
+    (csrc/plan.hip: entry point + argument values + stream of every call, plus the cross-stream waits) and replayed with one
+    host call per plan; the captured HIP graph itself is only kept alive as the owner of the memory pool.
+  * `TrainStep(..., graph=True)`: the captured HIP graphs themselves are replayed (hipGraphLaunch).  Measured slower than
+    eager launches on this runtime (profiles/r02_hipgraph_vs_eager.txt); kept for comparison.
+With data-parallel training the gradient all-reduces stay outside (RCCL runs them eagerly between the replayed stretches):
+a step is then five plans / graphs with four collectives between them.
 """
 import torch
 
@@ -76,6 +82,7 @@ class TrainStep:
         self.last_od_pred = None
         # exact data-parallel mode runs ~100 small collectives inside every forward: it stays eager
         self.graph = bool(graph) and not (dp is not None and dp.exact)
+        self.plan = self.graph and graph == "plan"
         self._graphs = None
         self._static = None
 
@@ -143,26 +150,46 @@ class TrainStep:
 
     # ------------------------------------------------------------------------------------------------ hipGraph
     def _capture(self, image, target_od, target_oc):
-        """Record the step into HIP graphs (one per stretch between gradient exchanges).  Nothing executes while a stretch
-        is recorded; the eager collectives between two stretches run on stale buffers and are harmless."""
+        """Record the step into HIP graphs / launch plans (one per stretch between gradient exchanges).  Nothing executes
+        while a stretch is recorded; the eager collectives between two stretches run on stale buffers and are harmless."""
         self._static = tuple(t.clone() for t in (image, target_od, target_oc))
         pool = torch.cuda.graph_pool_handle()
-        cap_stream = torch.cuda.Stream(device=image.device)
+        self._cap_stream = torch.cuda.Stream(device=image.device)
         gen = self._schedule(*self._static, {})
         graphs, res = [], None
+        L = ops.lib()
         done = False
         while not done:
             g = torch.cuda.CUDAGraph()
-            net = None
-            with torch.cuda.graph(g, pool=pool, stream=cap_stream):
-                try:
-                    net = next(gen)
-                except StopIteration as stop:
-                    res, done = stop.value, True
-            graphs.append((g, net))
+            net = plan = None
+            if self.plan:
+                L.plan_begin()
+            try:
+                with torch.cuda.graph(g, pool=pool, stream=self._cap_stream):
+                    try:
+                        net = next(gen)
+                    except StopIteration as stop:
+                        res, done = stop.value, True
+            finally:
+                if self.plan:
+                    plan = L.plan_end()
+            graphs.append((g, net, plan))
             if net is not None:
                 self._exchange(net)
         self._graphs, self._result = graphs, res
+
+    def _replay(self):
+        L = ops.lib()
+        for g, net, plan in self._graphs:
+            if plan is not None:
+                cur = torch.cuda.current_stream()
+                self._cap_stream.wait_stream(cur)       # the plan's streams start behind the caller's stream ...
+                L.plan_replay(plan)
+                cur.wait_stream(self._cap_stream)       # ... and the caller's stream continues behind the plan
+            else:
+                g.replay()
+            if net is not None:
+                self._exchange(net)
 
     def step(self, image, target_od, target_oc, noise=None):
         """image [B,3,H,W] in [-1,1], targets [B,1,H,W] in {0,1}; all device fp32, rows domain-major.
@@ -176,10 +203,7 @@ class TrainStep:
             for dst, src in zip(self._static, (image, target_od, target_oc)):
                 if dst.data_ptr() != src.data_ptr():
                     dst.copy_(src)
-            for g, net in self._graphs:
-                g.replay()
-                if net is not None:
-                    self._exchange(net)
+            self._replay()
             return self._result
         gen = self._schedule(image, target_od, target_oc, noise or {})
         try:
