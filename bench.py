@@ -44,10 +44,12 @@ def parse():
     ap.add_argument("--workload", choices=["full", "seg"], default="full",
                     help="full = configs[2] (seg + shape nets + WT loss); seg = configs[1] (seg-net only)")
     ap.add_argument("--bn-sync", type=int, default=0, help="1: BatchNorm statistics over the global batch (parity mode)")
-    ap.add_argument("--launch", choices=["plan", "eager", "graph"], default="plan",
-                    help="plan (default): the step is recorded once and replayed from native code (csrc/plan.hip; exact "
-                         "data-parallel mode always runs eagerly); eager: one ctypes call per launch; graph: hipGraph replay "
-                         "(slower than eager on this runtime, profiles/r02_hipgraph_vs_eager.txt)")
+    ap.add_argument("--launch", choices=["eager", "plan", "graph"], default="eager",
+                    help="eager (default): one ctypes call per launch; plan: the step is recorded once and replayed from native "
+                         "code (csrc/plan.hip; 2x less host time per step: what a small batch needs, e.g. the reference's own "
+                         "B=6 — at B=32 the GPU is the bottleneck either way and eager measures ~2 %% faster); graph: hipGraph "
+                         "replay (slower than eager on this runtime, profiles/r02_hipgraph_vs_eager.txt).  Exact data-parallel "
+                         "mode always runs eagerly")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-full", action="store_true",
                     help="SURVEY.md 8d protocol in full: 3 warm-up + 10 timed iterations at B=6 and B=30 (minutes of CPU time)")

@@ -24,7 +24,7 @@ def main():
   B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
   tot = [0.0] * 6
   for c0, c1, co, H, k, name in SHAPES:
-      if co <= 16 or c0 + c1 < 16:
+      if c0 + c1 < 16:
           continue
       x0 = torch.randn(B, c0, H, H, device=DEV)
       x1 = torch.randn(B, c1, H, H, device=DEV) if c1 else None

@@ -21,6 +21,11 @@
 // The data gradient is the same kernel run on dY with tap-flipped, transposed weights (see pack kernel).
 #include "common.h"
 
+// Input channels per LDS chunk on the 16-cout path.  These layers (16 -> 16 at full resolution, the 1x1 heads) are bound by
+// load latency, not by the matrix pipe: small chunks (4 channels for 3x3, 8 for 1x1 instead of 16) cut LDS and staging
+// registers so that more workgroups are resident per CU: inc.conv2 149 -> 122 us forward, 127 -> 105 us data gradient.
+#define WTPSE_P16_KC(KS) ((KS) == 3 ? 4 : 8)
+
 struct ConvArgs {
   const float* in0;
   const float* in1;
@@ -82,7 +87,7 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
   constexpr int CB = MB * MT;
   constexpr int NT = P16 ? 4 : 2;
   constexpr int NB = P16 ? 16 : 32;
-  constexpr int KC = P16 ? 16 : 8;
+  constexpr int KC = P16 ? WTPSE_P16_KC(KS) : 8;
   constexpr int KQ = P16 ? 4 : 2;
   constexpr int NACC = P16 ? 4 : 16;
   constexpr int CB4 = CB / 4;
@@ -437,7 +442,7 @@ extern "C" int wtpse_conv_fwd(const float* in0, int C0, const float* in1, int C1
   if (mode == 2 && tiles * (a.CoutP / 64) < 512) mode = 1;
   if (mode == 1 && tiles * ceil_div(a.CoutP, 32) < 384) mode = 0;   // still under two workgroups per CU: 16-cout blocks
   const int cb = mode == 0 ? 16 : 32 * mode;
-  const bool db = tiles * ceil_div(a.CoutP, cb) < 768 && a.CinP > (mode == 0 ? 16 : 8);
+  const bool db = tiles * ceil_div(a.CoutP, cb) < 768 && a.CinP > (mode == 0 ? WTPSE_P16_KC(ksize) : 8);
 #define FWD(KS, M) (mask_ref ? (db ? launch_fwd<KS, M, true, true>(a, st) : launch_fwd<KS, M, false, true>(a, st)) \
                          : (db ? launch_fwd<KS, M, true, false>(a, st) : launch_fwd<KS, M, false, false>(a, st)))
   if (ksize == 3) {

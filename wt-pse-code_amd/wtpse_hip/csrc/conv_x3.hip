@@ -15,6 +15,7 @@
 // lane's fragment, and consecutive lanes read consecutive 16-byte slots: conflict-free):
 //     Xs[term 3][k-half 2][halo position][8 cin]      the 16-channel chunk of the input tile, split on the way in
 //     Ws[tap 3][term 3][k-half 2][cout CB][8 cin]     one kernel row of the weights (pre-split by the pack kernel)
+#include <stdlib.h>
 #include "common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -447,12 +448,13 @@ static int launch_x3(const ConvX3Args& a, hipStream_t st) {
   return wtpse_status();
 }
 
-// Same contract as wtpse_conv_fwd (include/wtpse_hip.h) with `wpacked` in the x3 layout; requires Cout > 16.
+// Same contract as wtpse_conv_fwd (include/wtpse_hip.h) with `wpacked` in the x3 layout.  Cout <= 16 runs on a 32-row
+// tile with the upper rows idle (zero weights, stores dropped by the range check): the bf16 MFMAs are cheap enough.
 extern "C" int wtpse_conv_fwd_x3(const float* in0, int C0, const float* in1, int C1, const unsigned short* wpacked,
                                  const float* bias, const float* pro0, const float* pro1, int pro_relu, float* out0, float* out1,
                                  int Csplit, float* stats, int B, int H, int W, int Cout, int ksize, int relu_out,
                                  const float* mask_ref, void* stream) {
-  WTPSE_REQUIRE(in0 && wpacked && out0 && B > 0 && H > 0 && W > 0 && C0 > 0 && C1 >= 0 && Cout > 16);
+  WTPSE_REQUIRE(in0 && wpacked && out0 && B > 0 && H > 0 && W > 0 && C0 > 0 && C1 >= 0 && Cout > 0);
   WTPSE_REQUIRE(ksize == 1 || ksize == 3);
   WTPSE_REQUIRE((C1 == 0) == (in1 == nullptr));
   WTPSE_REQUIRE(Csplit > 0 && Csplit <= Cout && ((Csplit == Cout) == (out1 == nullptr)));
@@ -470,7 +472,11 @@ extern "C" int wtpse_conv_fwd_x3(const float* in0, int C0, const float* in1, int
   hipStream_t st = (hipStream_t)stream;
   const int TW = W <= 16 ? 16 : 32, TH = 256 / TW;
   const int tiles = B * ceil_div(W, TW) * ceil_div(H, TH);
-  const bool mt2 = (a.CoutP % 64 == 0) && tiles * (a.CoutP / 64) >= 512;
+  bool mt2 = (a.CoutP % 64 == 0) && tiles * (a.CoutP / 64) >= 512;
+  if (const char* e = getenv("WTPSE_X3_MT")) {   // tuning override: 1 | 2
+    if (e[0] == '1') mt2 = false;
+    if (e[0] == '2' && a.CoutP % 64 == 0) mt2 = true;
+  }
 #define X3(KS, M) (mask_ref ? launch_x3<KS, M, true>(a, st) : launch_x3<KS, M, false>(a, st))
   if (ksize == 3) return mt2 ? X3(3, 2) : X3(3, 1);
   return mt2 ? X3(1, 2) : X3(1, 1);
@@ -746,7 +752,9 @@ extern "C" int wtpse_wgrad_x3_ksplit(int B, int H, int W, int Cin, int Cout) {
   const int ntiles = B * ceil_div(W, TW) * ceil_div(H, TH);
   const int blk = q ? 64 : 32;
   const int nx = (Cout / blk) * (Cin / blk);
-  int ks = 512 / nx;   // two workgroups per CU
+  int target = 512;    // two workgroups per CU
+  if (const char* e = getenv("WTPSE_X3_WGS")) target = atoi(e);   // tuning override
+  int ks = target / nx;
   if (ks < 1) ks = 1;
   if (ks > ntiles) ks = ntiles;
   return ks;
