@@ -31,6 +31,9 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3     # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak
+# the x3 kernels form one fp32 product from 6 bf16 MFMA products: their bound is the dense bf16 MFMA peak (16x the fp32-input
+# rate, MI355X_MICROARCH.md "Matrix cores": ~2.5 PFLOP/s) / 6
+MFMA_X3_PEAK_TF = 16.0 * 157.3 / 6.0
 GFLOP_PER_IMAGE = 224.5      # SURVEY.md §8d / BASELINE.md §5: necessary conv FLOPs of one full iteration at 256x256
 
 
@@ -102,30 +105,55 @@ def dominant_kernel_share():
 
 
 def kernel_rooflines(B, H, dev):
-    """Live HIP-event timings of the kernels BASELINE.json names a roofline for, at the benchmark's own shapes.
-    * `wgrad`: the step's dominant kernel, conv_wgrad_k<3,true,5,9> (weight gradient of the 3x3 layers with >= 32 input
-      and output channels on maps wider than 16; 22 % of the summed kernel time in profiles/r01_bench_b32_kernel_stats.csv)
-      on its four FLOP-heaviest launches — conv3 of up1..up4, 1208 MFLOP/img each — launched as
-      the training step launches them: two inputs (the virtual concat) each with its BatchNorm-apply + ReLU prologue,
-      the k-split slabs and their fp64 fold (wgrad_reduce_k) included in the timed call.
-    * `conv`: the forward / data-gradient kernel conv_fwd_k<3,2,5> on up3.conv3 (bias + BatchNorm partials in the epilogue).
-    * the WT-loss Gram kernels (compute_whitening_loss forward / backward, 16*H*W*4 bytes/img/pass) against HBM."""
+    """Live HIP-event timings of the kernels BASELINE.json names a roofline for, at the benchmark's own shapes, launched
+    through the same dispatch the training step uses (wtpse_hip/nn.py: layers with > 16 output channels run the split-bf16
+    "x3" kernels of csrc/conv_x3.hip).
+    * `x3_conv`: conv_x3_k<3,2,5> — forward (BatchNorm+ReLU prologue on both inputs of the virtual concat, bias, BatchNorm
+      partials in the epilogue) and data gradient (split output) of conv3 of up1..up4, 1208 MFLOP/img each (SURVEY.md
+      Appendix B): the FLOP-heaviest launches of the kernel that leads the in-step profile.
+    * `x3_wgrad`: conv_wgrad_x3_k + the slab fold on the same four layers.
+    * `conv`: the fp32-input-MFMA kernel conv_fwd_k<3,2,5> of round 1 on up3.conv3 (kept for comparison; WTPSE_X3=0 path).
+    * the WT-loss Gram kernels (compute_whitening_loss forward / backward, 16*H*W*4 bytes/img/pass) against HBM.
+    FLOPs are the convolution's 2*Cin*Cout*9*H*W*B throughout (one fp32 multiply-add = 2 FLOP), whatever the kernel
+    issues to form them."""
     from wtpse_hip import ops
+    from wtpse_hip import nn as E
     out = {}
-    wg = []
+    wg, fw, dg = [], [], []
     for name, C, Hc in (("up1.conv3", 256, H // 8), ("up2.conv3", 128, H // 4), ("up3.conv3", 64, H // 2), ("up4.conv3", 32, H)):
+        class Holder(E.HipNet):
+            def __init__(self):
+                super().__init__()
+                self.conv = E.ConvP(C, C, 3)
+                self._finish_init()
+        net = Holder().to(dev)
+        net.ensure_ready(repack=True)
+        layer = net.conv
         x0, x1 = torch.randn(B, C // 2, Hc, Hc, device=dev), torch.randn(B, C // 2, Hc, Hc, device=dev)
         p0, p1 = torch.rand(C // 2, 2, device=dev) + 0.5, torch.rand(C // 2, 2, device=dev) + 0.5
         dy = torch.randn(B, C, Hc, Hc, device=dev)
-        dw = torch.empty(C, C, 3, 3, device=dev)
-        ms = time_kernel(lambda: ops.conv_wgrad(dy, x0, x1, 3, dw, None, p0, 3, False, p1))
+        a0, a1 = E.Act(x0, p0, True), E.Act(x1, p1, True)
         fl = 2.0 * C * C * 9 * Hc * Hc * B
-        wg.append({"layer": "%s %d+%d->%d @%dx%d" % (name, C // 2, C // 2, C, Hc, Hc), "ms": ms, "tflops": fl / ms / 1e9, "flop": fl})
-        del x0, x1, dy, dw
-    tot_ms, tot_fl = sum(w["ms"] for w in wg), sum(w["flop"] for w in wg)
-    out["wgrad"] = {"kernel": "conv_wgrad_k<3,true,5,9> + wgrad_reduce_k: conv3 of up1..up4 (3x3, C/2+C/2->C, C=256..32 @%d..%d), B=%d, "
-                              "BatchNorm+ReLU prologue on both inputs" % (H // 8, H, B),
-                    "ms": tot_ms / len(wg), "tflops": tot_fl / tot_ms / 1e9, "flop_per_launch": tot_fl / len(wg), "launches": wg}
+        tag = "%s %d+%d->%d @%dx%d" % (name, C // 2, C // 2, C, Hc, Hc)
+        ms = time_kernel(lambda: E._conv(layer, a0, a1, False, True))
+        fw.append({"layer": tag, "ms": ms, "tflops": fl / ms / 1e9, "flop": fl})
+        ms = time_kernel(lambda: E._dgrad(layer, dy, C // 2))
+        dg.append({"layer": tag, "ms": ms, "tflops": fl / ms / 1e9, "flop": fl})
+        net.begin_backward()
+        ms = time_kernel(lambda: E._wgrad(layer, dy, a0, a1, with_bias=False))
+        wg.append({"layer": tag, "ms": ms, "tflops": fl / ms / 1e9, "flop": fl})
+        del x0, x1, dy, net
+    x3 = "x3 (3 bf16 terms per fp32 operand, 6 bf16 MFMAs per product, fp32 accumulate)" if E.X3 else "fp32-input MFMA (WTPSE_X3=0)"
+
+    def agg(rows, kernel):
+        tot_ms, tot_fl = sum(r["ms"] for r in rows), sum(r["flop"] for r in rows)
+        return {"kernel": kernel, "ms": tot_ms / len(rows), "tflops": tot_fl / tot_ms / 1e9, "flop_per_launch": tot_fl / len(rows),
+                "launches": rows}
+    shape = "conv3 of up1..up4 (3x3, C/2+C/2->C, C=256..32 @%d..%d), B=%d" % (H // 8, H, B)
+    out["x3_fwd"] = agg(fw, "conv_x3_k forward, %s: %s, BatchNorm+ReLU prologue on both inputs, bias + BatchNorm partials" % (x3, shape))
+    out["x3_dgrad"] = agg(dg, "conv_x3_k data gradient, %s: %s, split output" % (x3, shape))
+    out["x3_conv"] = agg(fw + dg, "conv_x3_k forward + data gradient, %s: %s" % (x3, shape))
+    out["x3_wgrad"] = agg(wg, "conv_wgrad_x3_k + slab fold, %s: %s, BatchNorm+ReLU prologue on both inputs" % (x3, shape))
     C, Hc = 64, H // 2
     x = torch.randn(B, C, Hc, Hc, device=dev)
     w = torch.randn(C, C, 3, 3, device=dev) * 0.05
@@ -136,12 +164,12 @@ def kernel_rooflines(B, H, dev):
     bias = torch.zeros(C, device=dev)
     stats = torch.empty(ops.lib().query("wtpse_conv_stats_blocks", B, Hc, Hc) * C * 2, device=dev)
 
-    def conv():   # as the training step launches it: bias + BatchNorm (sum, sum^2) partials in the epilogue
+    def conv():   # the fp32-input-MFMA kernel, as round 1 launched it: bias + BatchNorm (sum, sum^2) partials in the epilogue
         ops.lib().call("wtpse_conv_fwd", x.data_ptr(), C, 0, 0, packed.data_ptr(), bias.data_ptr(), 0, 0, 0, y.data_ptr(), 0, C,
                        stats.data_ptr(), B, Hc, Hc, C, 3, 0, 0, ops.stream_ptr())
     ms = time_kernel(conv)
     flops = 2.0 * C * C * 9 * Hc * Hc * B
-    out["conv"] = {"kernel": "conv_fwd_k<3,2,5> 64->64 3x3 @%dx%d B=%d (+bias, BN partials)" % (Hc, Hc, B), "ms": ms,
+    out["conv"] = {"kernel": "conv_fwd_k<3,2,5> (fp32-input MFMA) 64->64 3x3 @%dx%d B=%d (+bias, BN partials)" % (Hc, Hc, B), "ms": ms,
                    "tflops": flops / ms / 1e9, "flop_per_launch": flops}
     z = torch.randn(B, 16, H, H, device=dev)
     L = ops.lib()
@@ -231,6 +259,11 @@ def cpu_baseline(H, full, full_protocol=False):
             "b30": {"value": r30, "unit": "images/s", "sample": "median of %d iteration(s), B=30 (%.1f s each)" % (len(t30), t30[len(t30) // 2])},
             "wt_loss_fwd": {"value": wt_gbs, "unit": "GB/s", "sample": "compute_whitening_loss forward on [32,16,%d,%d], median of 10 "
                             "after 3 warm-up (%.1f ms)" % (H, H, 1e3 * tw[len(tw) // 2])}}
+
+
+def _x3_on():
+    from wtpse_hip import nn as E
+    return bool(E.X3)
 
 
 def log(msg):
@@ -364,7 +397,8 @@ def main():
             "metric": ("training images/sec (%dx%d fundus) — " % (H, H)) + ("full WT-PSE iteration" if full else "seg-net only"),
             "value": ips, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32 (layers with > 16 output channels: fp32 operands as 3 bf16 terms, 6 bf16 MFMA products, fp32 accumulation; "
+                     "the rest fp32-input MFMA)" if _x3_on() else "f32", "data": "synthetic",
             "config": {"workload": (("BASELINE.json configs[2]: full WT-PSE (seg+shape nets + WT loss)" if H == 256 else
                                      "BASELINE.json configs[4] per-GPU share: full WT-PSE at high resolution") if full else
                                     "BASELINE.json configs[1]: seg-net only") + ", 3x%dx%d, batch %d per GPU" % (H, H, B),
@@ -383,14 +417,23 @@ def main():
             log("kernel rooflines")
             kr = kernel_rooflines(B, H, dev)
             tr = measured_traffic() if (B, H) == (32, 256) else {}
-            wg, c = kr["wgrad"], kr["conv"]
-            line["roofline"] = {"bound": "mfma", "kernel": wg["kernel"], "achieved": wg["tflops"], "peak": MFMA_F32_PEAK_TF,
-                                "unit": "TFLOP/s", "frac": wg["tflops"] / MFMA_F32_PEAK_TF, "traffic": tr.get("wgrad"),
-                                "ms_per_launch": wg["ms"], "flop_per_launch": wg["flop_per_launch"],
-                                "launches": wg["launches"], "dominant_in_profile": dominant_kernel_share()}
-            line["roofline_conv_fwd"] = {"bound": "mfma", "kernel": c["kernel"], "achieved": c["tflops"], "peak": MFMA_F32_PEAK_TF,
-                                         "unit": "TFLOP/s", "frac": c["tflops"] / MFMA_F32_PEAK_TF, "traffic": tr.get("conv"),
-                                         "ms_per_launch": c["ms"], "flop_per_launch": c["flop_per_launch"]}
+            dom = dominant_kernel_share()
+            lead = "x3_wgrad" if (dom and "wgrad" in dom["kernel"]) else "x3_conv"
+
+            def mfma_line(k, traffic_key):
+                r = kr[k]
+                return {"bound": "mfma", "kernel": r["kernel"], "achieved": r["tflops"], "peak": MFMA_X3_PEAK_TF,
+                        "unit": "TFLOP/s", "frac": r["tflops"] / MFMA_X3_PEAK_TF, "traffic": tr.get(traffic_key),
+                        "frac_of_fp32_mfma_peak": r["tflops"] / MFMA_F32_PEAK_TF,
+                        "peak_note": "bf16 dense MFMA peak (16 x 157.3) / 6 products per fp32 multiply; fp32-input MFMA peak 157.3",
+                        "ms_per_launch": r["ms"], "flop_per_launch": r["flop_per_launch"], "launches": r.get("launches")}
+            line["roofline"] = dict(mfma_line(lead, lead), dominant_in_profile=dom)
+            for k in ("x3_fwd", "x3_dgrad", "x3_wgrad"):
+                line["roofline_" + k] = mfma_line(k, "x3_wgrad" if k == "x3_wgrad" else "x3_conv")
+            c = kr["conv"]
+            line["roofline_conv_fwd_fp32"] = {"bound": "mfma", "kernel": c["kernel"], "achieved": c["tflops"], "peak": MFMA_F32_PEAK_TF,
+                                              "unit": "TFLOP/s", "frac": c["tflops"] / MFMA_F32_PEAK_TF, "traffic": tr.get("conv"),
+                                              "ms_per_launch": c["ms"], "flop_per_launch": c["flop_per_launch"]}
             for k in ("wt_fwd", "wt_bwd"):
                 w = kr[k]
                 line["roofline_" + k] = {"bound": "hbm", "kernel": w["kernel"], "achieved": w["gbs"], "peak": HBM_PEAK_GBS,

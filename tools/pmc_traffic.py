@@ -16,27 +16,27 @@ import sys
 # kernel -> (name pattern, FETCH_SIZE factor): x2 is calibrated for 16-B-per-lane streams (the WT kernels: the corrected
 # value reproduces their algorithmic bytes to 0.5 %); the conv loader issues 4-B-per-lane loads, for which the guide
 # gives no calibration — the raw value (x1) is reported (halo-tile estimate: 1.33 x input), x2 would be an upper bound
-KERNELS = {"conv": ("conv_fwd_k<3, 2, 5", 1.0), "wt_fwd": ("gram_partial_k", 2.0), "wt_bwd": ("gram_bwd_k", 2.0)}
+# The x3 kernels run on four layer shapes each in `bench.py --kernels-only` (conv3 of up1..up4, forward and data gradient
+# share one kernel name): their entry is the mean over all those launches, to be compared with the mean algorithmic bytes.
+KERNELS = {"x3_conv": ("conv_x3_k<3", 1.0), "x3_wgrad": ("conv_wgrad_x3_k<3", 1.0), "conv": ("conv_fwd_k<3, 2, 5", 1.0),
+           "wt_fwd": ("gram_partial_k", 2.0), "wt_bwd": ("gram_bwd_k", 2.0)}
 
 
-def per_launch(path, counter):
-    agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] == counter:
-            agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
-    return {k: sum(v) / len(v) for k, v in agg.items()}
+def per_launch(path, counter, pattern):
+    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
+            if r["Counter_Name"] == counter and pattern in r["Kernel_Name"]]
+    return (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
 
 
 def main():
-    fetch = per_launch(sys.argv[1], "FETCH_SIZE")
-    write = per_launch(sys.argv[2], "WRITE_SIZE")
     out = {}
     for key, (pat, fac) in KERNELS.items():
-        f = [v for k, v in fetch.items() if pat in k]
-        w = [v for k, v in write.items() if pat in k]
-        if f and w:
-            out[key] = {"hbm_read_bytes": fac * f[0] * 1024.0, "hbm_write_bytes": w[0] * 1024.0,
-                        "hbm_bytes": fac * f[0] * 1024.0 + w[0] * 1024.0, "fetch_size_kib_raw": f[0], "write_size_kib_raw": w[0],
+        f, nf = per_launch(sys.argv[1], "FETCH_SIZE", pat)
+        w, nw = per_launch(sys.argv[2], "WRITE_SIZE", pat)
+        if f is not None and w is not None:
+            out[key] = {"hbm_read_bytes": fac * f * 1024.0, "hbm_write_bytes": w * 1024.0,
+                        "hbm_bytes": fac * f * 1024.0 + w * 1024.0, "fetch_size_kib_raw": f, "write_size_kib_raw": w,
+                        "launches_averaged": nf,
                         "note": "rocprofv3 --pmc, separate passes; FETCH_SIZE KiB x%g, WRITE_SIZE KiB x1 (MI355X_MICROARCH.md HBM)" % fac}
     dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
     json.dump(out, open(dst, "w"), indent=1)
