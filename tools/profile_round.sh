@@ -1,0 +1,22 @@
+#!/bin/bash
+# One gpurun call's worth of profiling for a round (run from the repo root on the GPU box):
+#   bash tools/profile_round.sh gpurun_out/r02prof
+# in-step and kernels-only rocprofv3 kernel statistics, HBM-traffic and MFMA-busy PMC passes (each in its own run, as the
+# MI355X guide prescribes), the per-layer microbenchmarks.  Copy what should be judged into profiles/.
+set -o pipefail
+OUT=${1:-gpurun_out/prof}
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+B="python3 bench.py"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/step" -o step -- $B --steps 7 --warmup 2 --no-cpu-baseline --no-kernel-roofline > "$OUT/step.log" 2>&1 &&
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/ko" -o ko -- $B --kernels-only > "$OUT/ko.log" 2>&1 &&
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_f" -o f -- $B --kernels-only > "$OUT/pmc_f.log" 2>&1 &&
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_w" -o w -- $B --kernels-only > "$OUT/pmc_w.log" 2>&1 &&
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OUT/pmc_a" -o a -- $B --kernels-only > "$OUT/pmc_a.log" 2>&1 &&
+python3 tools/pmc_traffic.py "$OUT/pmc_f/f_counter_collection.csv" "$OUT/pmc_w/w_counter_collection.csv" > "$OUT/pmc_traffic.log" 2>&1 &&
+python3 tools/microbench_x3.py > "$OUT/microbench_x3.log" 2>&1 &&
+python3 tools/microbench.py --only wt > "$OUT/microbench_rest.log" 2>&1 &&
+python3 tools/microbench.py --only head >> "$OUT/microbench_rest.log" 2>&1 &&
+python3 tools/microbench.py --only bn >> "$OUT/microbench_rest.log" 2>&1 &&
+python3 tools/microbench.py --only pw >> "$OUT/microbench_rest.log" 2>&1
+echo "profile_round rc $?"
