@@ -200,6 +200,14 @@ def kernel_rooflines(B, H, dev):
     return out
 
 
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench %.1fs] %s" % (time.time() - T0, msg), file=sys.stderr, flush=True)
+
+
+T0 = time.time()
+
+
 def cpu_baseline(H, full, full_protocol=False):
     """The CPU restatement (oracle/, bit-checked against the reference in the build container) timed on this box's host
     cores: full A-D iterations (4 forward + 4 backward + 4 Adam) at B = 6 — what `--batch-size 8` yields
@@ -236,6 +244,7 @@ def cpu_baseline(H, full, full_protocol=False):
         for i in range(warm + timed):
             t0 = time.time()
             O.train_iteration(nets, hp, img, od, oc, nz, pb)
+            log("cpu baseline: B=%d iteration %d/%d took %.1f s" % (B, i + 1, warm + timed, time.time() - t0))
             if i >= warm:
                 ts.append(time.time() - t0)
         ts.sort()
@@ -264,14 +273,6 @@ def cpu_baseline(H, full, full_protocol=False):
 def _x3_on():
     from wtpse_hip import nn as E
     return bool(E.X3)
-
-
-def log(msg):
-    if int(os.environ.get("RANK", "0")) == 0:
-        print("[bench %.1fs] %s" % (time.time() - T0, msg), file=sys.stderr, flush=True)
-
-
-T0 = time.time()
 
 
 def measured_traffic():
