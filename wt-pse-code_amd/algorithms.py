@@ -8,7 +8,8 @@ There is no CPU path: modules must live on a HIP device.
 
 Only the reachable configuration space of the reference is supported: ``shape_prior`` and ``whitening`` both on
 (the WT-PSE method) or both off (plain segmentation U-Net, BASELINE.json configs[1]); the mixed settings crash in
-the reference itself.
+the reference itself, and so does ``shape_attention=False`` (see ``__init__``).  The one reachable
+non-default branch that is not built is ``cat_shape=True``.
 """
 import torch
 import torch.nn as nn
@@ -95,8 +96,13 @@ class WT_PSE(E.HipNet, E.UNetBody):
         if bool(hparams['shape_prior']) != bool(hparams['whitening']):
             raise NotImplementedError("shape_prior and whitening must be switched together (the mixed settings fail in "
                                       "the reference: algorithms.py:994,1022-1023,1235)")
-        if self.cat_shape or not hparams['shape_attention']:
-            raise NotImplementedError("only the reference defaults cat_shape=False, shape_attention=True are built")
+        if not hparams['shape_attention']:
+            raise NotImplementedError("shape_attention=False fails in the reference itself: update() returns "
+                                      "z_posterior_attention_mask and predict() no_sigmoid_embeddings, which only the "
+                                      "attention branch assigns (algorithms.py:1241-1272, 1340-1352: UnboundLocalError)")
+        if self.cat_shape:
+            raise NotImplementedError("cat_shape=True (outc over cat(fuse, z_posterior), algorithms.py:1192,1253,1348) is not "
+                                      "built: only the reference default cat_shape=False")
         n = 16
         # registration order == reference state_dict order (algorithms.py:1161-1204)
         if self.whitening:
