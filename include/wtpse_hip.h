@@ -217,6 +217,15 @@ int wtpse_axpy(float* dst, const float* src, float alpha, long long n, void* str
 int wtpse_reduce_rows(const float* partial, int rows, int cols, float* out, int accumulate, float scale, void* stream);
 int wtpse_zero(void* p, long long nbytes, void* stream);
 
+/* ---- standalone 2-D discrete wavelet transform (csrc/dwt.hip) — NOT part of WT-PSE ---------------------------------------
+ * The reference has no wavelet transform (its "WT" is the whitening transform); these two entry points exist only as the
+ * HBM-bandwidth micro-benchmark BASELINE.json's wording names and are never called by the training path.
+ * Specification (self-defined, parity unpinned): oracle/dwt_cpu.py — separable, orthonormal, periodic extension, lifting,
+ * Mallat layout.  x / coef: [planes][H][W] fp32, distinct buffers; wavelet 0 = Haar, 1 = Daubechies 4-tap ("db2");
+ * H, W divisible by 2^levels; tmp: 2 * planes * (H/2) * (W/2) floats. */
+int wtpse_dwt2_fwd(const float* x, float* coef, float* tmp, int planes, int H, int W, int wavelet, int levels, void* stream);
+int wtpse_dwt2_inv(const float* coef, float* x, float* tmp, int planes, int H, int W, int wavelet, int levels, void* stream);
+
 /* ---- launch plans (csrc/plan.hip): a recorded sequence of the calls above, replayed with one host call ------------------
  * wtpse_plan_add_call: `fn` indexes the entry points that take a stream (wtpse_plan_fn_name(fn), 0 <= fn < wtpse_plan_fn_count());
  * `args`: its arguments without the trailing stream, one 8-byte slot each (pointer / long long / unsigned long long / double).
