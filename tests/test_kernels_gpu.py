@@ -439,3 +439,28 @@ def test_rejects_bad_arguments():
         o.lib().call("wtpse_conv_fwd", 0, 16, 0, 0, 0, 0, 0, 0, 0, 0, 0, 16, 0, 1, 8, 8, 16, 3, 0, 0, 0)
     with pytest.raises(ValueError):
         o.conv_fwd(torch.zeros(1, 16, 8, 8), None, 0, None, 16, 3)     # host tensor: no CPU fallback
+
+
+def test_public_whitening_loss_is_differentiable():
+    """WT_PSE.compute_whitening_loss / ShapeVariationalDist_x.compute_whitening_loss as public helpers: values and the
+    gradient through autograd against the oracle's (reference algorithms.py:1277-1309, shape_networks.py:561-594)."""
+    import algorithms
+    import shape_networks
+    from oracle import wtpse_cpu as O
+    hp = dict(O.DEFAULT_HPARAMS)
+    m = algorithms.WT_PSE(3, 1, hp, DEV, False, per_domain_batch=2, source_domain_num=3).to(DEV)
+    sn = shape_networks.ShapeVariationalDist_x(hp, DEV, 1, 3, 2).to(DEV)
+    z = rnd(6, 16, 24, 40, seed=91, scale=0.7)
+    zr = z.clone().requires_grad_(True)
+    off, dg, dom = O.whitening_loss(zr, 3, 2, 0.0)
+    (off + dg + 2.0 * dom).backward()
+    zd = z.to(DEV).requires_grad_(True)
+    ins, d = m.compute_whitening_loss(zd)
+    (ins + 2.0 * d).backward()
+    close(ins, (off + dg).detach(), rtol=1e-5, atol=1e-7, what="ins")
+    close(d, dom.detach(), rtol=1e-3, atol=1e-7, what="dom")
+    close(zd.grad, zr.grad, rtol=1e-4, atol=1e-9, what="dz")
+    zd2 = z.to(DEV).requires_grad_(True)
+    o2, g2, d2 = sn.compute_whitening_loss(zd2)
+    (o2 + g2 + 2.0 * d2).backward()
+    close(zd2.grad, zr.grad, rtol=1e-4, atol=1e-9, what="dz (shape net)")

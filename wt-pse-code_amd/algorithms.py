@@ -48,6 +48,27 @@ class compute_MMD(object):
         return out[0]
 
 
+class _WtLossFn(torch.autograd.Function):
+    """compute_whitening_loss as an autograd node: forward = fused Gram + masked L1 + MMD kernels, backward = gram_bwd_k with
+    the three upstream scalars read on the device (no host sync).  -> (ins_offdiag, ins_diag, domain)."""
+
+    @staticmethod
+    def forward(ctx, z, domain_num, per_domain, margin, eps):
+        zc = z.detach().to(torch.float32).contiguous()
+        st = ops.wt_loss_fwd(zc, domain_num, per_domain, margin, eps)
+        ctx.st = st
+        return st.losses[0].clone(), st.losses[1].clone(), st.losses[2].clone()
+
+    @staticmethod
+    def backward(ctx, g_off, g_diag, g_dom):
+        st = ctx.st
+        dz = torch.empty_like(st.z)
+        c = lambda g: None if g is None else g.detach().to(torch.float32).contiguous()
+        ops.wt_loss_bwd(st, dz, False, c(g_off), c(g_diag), c(g_dom), w_off=0.0 if g_off is None else 1.0,
+                        w_diag=0.0 if g_diag is None else 1.0, w_dom=0.0 if g_dom is None else 1.0)
+        return dz, None, None, None, None
+
+
 class _UpdateFn(torch.autograd.Function):
     """One autograd node per WT_PSE.update(): forward runs the fused schedule and keeps a tape, backward replays it."""
 
@@ -160,10 +181,10 @@ class WT_PSE(E.HipNet, E.UNetBody):
         return self.predict(x)
 
     def compute_whitening_loss(self, z):
-        """Reference algorithms.py:1277-1309 -> (instance_loss, domain_loss); forward values only."""
-        st = ops.wt_loss_fwd(z.contiguous(), self.number_source_domain, self.per_domain_batch, self.margin, self.eps)
-        comb = ops.wt_combine(st.losses.view(1, 3), 1.0, 0)
-        return comb[0], comb[3]
+        """Reference algorithms.py:1277-1309 -> (instance_loss, domain_loss), connected to autograd through `z`
+        (gradients flow as in the reference when a caller differentiates the returned scalars)."""
+        ins_off, ins_diag, dom = _WtLossFn.apply(z, self.number_source_domain, self.per_domain_batch, float(self.margin), self.eps)
+        return ins_off + ins_diag, dom
 
     # ------------------------------------------------------------------------------------------------ schedules
     def _as_input(self, t):

@@ -84,9 +84,9 @@ class ShapeVariationalDist_x(E.HipNet, E.UNetBody):
         return ops.reparam_student(mu, logvar, eps, self._flag), mu
 
     def compute_whitening_loss(self, z):
-        """Reference shape_networks.py:561-594 -> (ins_offdiag, ins_diag, domain); forward values only."""
-        st = ops.wt_loss_fwd(z.contiguous(), 3, self.batch_size, self.margin, self.eps)
-        return st.losses[0], st.losses[1], st.losses[2]
+        """Reference shape_networks.py:561-594 -> (ins_offdiag, ins_diag, domain), connected to autograd through `z`."""
+        from algorithms import _WtLossFn
+        return _WtLossFn.apply(z, 3, self.batch_size, float(self.margin), self.eps)
 
     # ------------------------------------------------------------------------------------------------ schedules
     def _as_input(self, t):
