@@ -187,6 +187,23 @@ def kernel_rooflines(B, H, dev):
     nbytes = B * 16 * H * H * 4.0
     out["wt_fwd"] = {"kernel": "wtpse_wt_loss_fwd (gram_partial_k + 3 small) [%d,16,%d,%d]" % (B, H, H), "ms": ms,
                      "gbs": nbytes / ms / 1e6, "bytes_per_launch": nbytes}
+    # in a training step the Gram partials come from the epilogue of the DeepWT conv that writes z (wtpse_conv_fwd_gram):
+    # the loss then costs the extra epilogue time plus the tail on the partials, and never reads z
+    h = torch.randn(B, 16, H, H, device=dev)
+    w16 = torch.randn(16, 16, 3, 3, device=dev) * 0.1
+    pk = torch.empty(16 * 9 * 16 * 2, device=dev)
+    d16 = torch.tensor([0, 16, 16, 9, 0, 16 * 9 * 16, 0, 0], dtype=torch.int32, device=dev)
+    L.call("wtpse_pack_conv_weights", w16.data_ptr(), d16.data_ptr(), 1, pk.data_ptr(), ops.stream_ptr())
+    b16 = torch.zeros(16, device=dev)
+    t_plain = time_kernel(lambda: ops.conv_fwd(h, None, pk.data_ptr(), b16, 16, 3))
+    t_gram = time_kernel(lambda: ops.conv_fwd_gram(h, pk.data_ptr(), b16))
+    zz, gp = ops.conv_fwd_gram(h, pk.data_ptr(), b16)
+    t_tail = time_kernel(lambda: ops.wt_loss_fwd(zz, 3, pb, 0.0, gram_partial=gp))
+    out["wt_fwd"]["fused_in_step"] = {
+        "what": "Gram partials in the epilogue of the conv that writes z (conv_fwd_k 16->16 3x3) + wtpse_wt_loss_fwd_partials",
+        "conv_ms": t_plain, "conv_with_gram_epilogue_ms": t_gram, "tail_on_partials_ms": t_tail,
+        "loss_cost_ms": (t_gram - t_plain) + t_tail, "hbm_bytes_avoided_per_call": nbytes,
+        "equivalent_gbs": nbytes / ((t_gram - t_plain) + t_tail) / 1e6}
     dz = torch.empty_like(z)
     M = torch.randn(B * 256, device=dev) * 1e-3
     bpi = (H * H + 1023) // 1024
@@ -440,6 +457,8 @@ def main():
                 line["roofline_" + k] = {"bound": "hbm", "kernel": w["kernel"], "achieved": w["gbs"], "peak": HBM_PEAK_GBS,
                                          "unit": "GB/s", "frac": w["gbs"] / HBM_PEAK_GBS, "traffic": tr.get(k),
                                          "ms_per_launch": w["ms"], "bytes_per_launch": w["bytes_per_launch"]}
+                if "fused_in_step" in w:
+                    line["roofline_" + k]["fused_in_step"] = w["fused_in_step"]
         if world == 1 and not args.no_cpu_baseline:
             log("cpu baseline")
             line["cpu_baseline"] = cpu_baseline(H, full, args.cpu_baseline_full)

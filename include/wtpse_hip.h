@@ -40,6 +40,11 @@ int wtpse_conv_fwd(const float* in0, int C0, const float* in1, int C1, const flo
                    const float* pro0, const float* pro1, int pro_relu, float* out0, float* out1, int Csplit, float* stats,
                    int B, int H, int W, int Cout, int ksize, int relu_out, const float* mask_ref, void* stream);
 int wtpse_conv_stats_blocks(int B, int H, int W);
+/* 3x3 convolution with exactly 16 output channels (DeepWT, algorithms.py:1091-1117) that also emits the per-tile partial
+ * Grams of its output in the epilogue: gram_partial [wtpse_conv_stats_blocks(B,H,W)][256] = the WT loss's `partial` layout
+ * with S = tiles per image (wtpse_wt_loss_fwd_partials), so that compute_whitening_loss never re-reads z from HBM. */
+int wtpse_conv_fwd_gram(const float* in0, int C0, const float* wpacked, const float* bias, const float* pro0, int pro_relu,
+                        float* out0, float* gram_partial, int B, int H, int W, int Cout, int relu_out, void* stream);
 
 /* The same convolution on the BF16 matrix cores at fp32 accuracy (csrc/conv_x3.hip): every fp32 operand is split into three
  * bf16 terms and the product formed from the six leading cross terms with fp32 accumulation (6 bf16 MFMAs instead of 8 fp32
@@ -101,6 +106,10 @@ int wtpse_wt_loss_fwd(const float* z, int B, int C, int HW, float eps, float mar
                       float* partial, float* gram, float* v, float* offdiag, float* diag, double* rowval,
                       float* dmmd_dv, float* losses, void* stream);
 int wtpse_wt_split(int B, int HW, int* chunk_out);
+/* The same loss from partial Grams [B][S][256] that a conv epilogue already produced (wtpse_conv_fwd_gram): z is not read. */
+int wtpse_wt_loss_fwd_partials(const float* partial, int S, int B, int HW, float eps, float margin, int domain_num,
+                               int per_domain, float* gram, float* v, float* offdiag, float* diag, double* rowval,
+                               float* dmmd_dv, float* losses, void* stream);
 /* The two halves of wtpse_wt_loss_fwd (data parallel: all-gather of v and wtpse_mmd_fwd on the global rows in between).
  * wtpse_wt_final: losses[0..1] = this rank's share of the instance means (divided by Bnorm), losses[2] = sum(rowval). */
 int wtpse_wt_gram_fwd(const float* z, int B, int C, int HW, float eps, float* partial, float* gram, float* v, float* offdiag,

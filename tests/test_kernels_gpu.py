@@ -464,3 +464,35 @@ def test_public_whitening_loss_is_differentiable():
     o2, g2, d2 = sn.compute_whitening_loss(zd2)
     (o2 + g2 + 2.0 * d2).backward()
     close(zd2.grad, zr.grad, rtol=1e-4, atol=1e-9, what="dz (shape net)")
+
+
+@pytest.mark.parametrize("shape", [(3, 16, 32, 64), (3, 16, 20, 40), (6, 3, 64, 64)])
+def test_conv_gram_epilogue_and_wt_loss_from_partials(shape):
+    """The DeepWT convs emit the per-tile partial Grams of their output (wtpse_conv_fwd_gram); compute_whitening_loss from
+    those partials (wtpse_wt_loss_fwd_partials) must equal the loss computed from z itself and the oracle's."""
+    from oracle import wtpse_cpu as O
+    o = ops()
+    B, Cin, H, W = shape
+    x = rnd(B, Cin, H, W, seed=31)
+    w = rnd(16, Cin, 3, 3, seed=32, scale=0.3)
+    b = rnd(16, seed=33)
+    packed, wf, _ = pack(w)
+    z, (partial, S) = o.conv_fwd_gram(x.to(DEV), packed.data_ptr() + 4 * wf, b.to(DEV))
+    ref = F.conv2d(x, w, b, padding=1)
+    close(z, ref, what="conv (gram variant)")
+    g_ref = torch.einsum("bip,bjp->bij", ref.reshape(B, 16, -1).double(), ref.reshape(B, 16, -1).double())
+    g = partial.view(B, S, 16, 16).double().sum(1).cpu()
+    close(g, g_ref, rtol=1e-5, atol=1e-5 * float(g_ref.abs().max()), what="partial Grams")
+    pb = B // 3
+    st_f = o.wt_loss_fwd(z, 3, pb, 0.0, gram_partial=(partial, S))
+    st_d = o.wt_loss_fwd(z, 3, pb, 0.0)
+    off, dg, dom = O.whitening_loss(ref, 3, pb, 0.0)
+    for st in (st_f, st_d):
+        close(st.losses[0], off, rtol=1e-4, atol=1e-7, what="off")
+        close(st.losses[1], dg, rtol=1e-4, atol=1e-7, what="diag")
+        close(st.losses[2], dom, rtol=2e-3, atol=1e-6, what="dom")
+    close(st_f.gram, st_d.gram, rtol=1e-5, atol=1e-6, what="gram fused vs stand-alone")
+    dz_f, dz_d = torch.empty_like(z), torch.empty_like(z)
+    o.wt_loss_bwd(st_f, dz_f, False)
+    o.wt_loss_bwd(st_d, dz_d, False)
+    close(dz_f, dz_d, rtol=1e-4, atol=1e-7 * float(dz_d.abs().max()) + 1e-12, what="dL/dz fused vs stand-alone")

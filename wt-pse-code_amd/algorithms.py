@@ -224,13 +224,13 @@ class WT_PSE(E.HipNet, E.UNetBody):
         def prior_chain():
             """DeepWT -> teacher -> posterior sample, and the WT loss on the first two maps divided by
             len([z1, z2, relu(z2)]) = 3 (algorithms.py:1259-1267).  Shares only the inputs with the embedding above."""
-            w = E.deepwt_fwd(self.wt_model, wt_in, want_tape)
+            w = E.deepwt_fwd(self.wt_model, wt_in, want_tape, want_gram=not (self._dp is not None and self._dp.exact))
             th = E.teacher_fwd(self.prior_dist, E.Act(w.z2, None, True), mask, training, True, want_tape)
             eps = self.next_noise(th.mu.shape)
             z_post = ops.reparam_fwd(th.mu, th.logvar, eps)
             losses = torch.empty((2, 3), dtype=torch.float32, device=inputs.device)
-            st1 = self._wt_loss(w.z1, D, n, losses[0])
-            st2 = self._wt_loss(w.z2, D, n, losses[1])
+            st1 = self._wt_loss(w.z1, D, n, losses[0], w.g1)
+            st2 = self._wt_loss(w.z2, D, n, losses[1], w.g2)
             return w, th, eps, z_post, st1, st2, ops.wt_combine(losses, 3.0, 0)
 
         # The prior chain runs on the second stream beside the segmentation U-Net (small-grid layers of the two networks
@@ -256,10 +256,10 @@ class WT_PSE(E.HipNet, E.UNetBody):
             t.w, t.th, t.eps, t.z_post, t.att, t.emb, t.fuse, t.st1, t.st2, t.coef = w, th, eps, z_post, att, emb, fuse, st1, st2, coef
         return (out, att_mask, scal), t
 
-    def _wt_loss(self, z, D, n, losses_out):
-        if self._dp is not None:
+    def _wt_loss(self, z, D, n, losses_out, gram=None):
+        if self._dp is not None and self._dp.exact:
             return self._dp.wt_loss_fwd(z, D, n, float(self.margin), self.eps, losses_out)
-        return ops.wt_loss_fwd(z, D, n, float(self.margin), self.eps, losses_out)
+        return ops.wt_loss_fwd(z, D, n, float(self.margin), self.eps, losses_out, gram)
 
     def _wt_loss_bwd(self, st, dz, **kw):
         if self._dp is not None:

@@ -133,7 +133,7 @@ class ShapeVariationalDist_x(E.HipNet, E.UNetBody):
         else:
             mu_t = teacher()
         # student side
-        w2 = E.deepwt_fwd(self.wt_model, x, want_tape)
+        w2 = E.deepwt_fwd(self.wt_model, x, want_tape, want_gram=not (self._dp is not None and self._dp.exact))
         mu_s = self._student_mu(E.Act(w2.z2, None, True), training, t if want_tape else None)
         if side is not None:
             E.stream_wait(main, side)
@@ -142,17 +142,17 @@ class ShapeVariationalDist_x(E.HipNet, E.UNetBody):
         ops.mse_fwd(mu_t, mu_s, out=scal[0:1])
         losses = torch.empty((2, 3), dtype=torch.float32, device=x.device)
         n = self.batch_size
-        st1 = self._wt_loss(w2.z1, 3, n, losses[0])
-        st2 = self._wt_loss(w2.z2, 3, n, losses[1])
+        st1 = self._wt_loss(w2.z1, 3, n, losses[0], w2.g1)
+        st2 = self._wt_loss(w2.z2, 3, n, losses[1], w2.g2)
         ops.wt_combine(losses, 3.0, 1, out=scal[1:5])
         if want_tape:
             t.w2, t.mu_t, t.mu_s, t.st1, t.st2 = w2, mu_t, mu_s, st1, st2
         return scal, t
 
-    def _wt_loss(self, z, D, n, losses_out):
-        if self._dp is not None:
+    def _wt_loss(self, z, D, n, losses_out, gram=None):
+        if self._dp is not None and self._dp.exact:
             return self._dp.wt_loss_fwd(z, D, n, float(self.margin), self.eps, losses_out)
-        return ops.wt_loss_fwd(z, D, n, float(self.margin), self.eps, losses_out)
+        return ops.wt_loss_fwd(z, D, n, float(self.margin), self.eps, losses_out, gram)
 
     def _wt_loss_bwd(self, st, dz, **kw):
         if self._dp is not None:

@@ -37,6 +37,7 @@ struct ConvArgs {
   float* out1;
   float* stats;        // [gridDim.x][Cout][2] or null
   const float* mask;   // [B][Cout][H][W] or null: out = mask > 0 ? value : 0 (ReLU backward fused into a data gradient)
+  float* gram;         // [gridDim.x][16][16] or null (16-cout path): the tile's partial Gram  sum_px out[i][px] * out[j][px]
   int B, H, W;
   int C0, C1, Cin, CinP;
   int Cout, CoutP, Csplit;
@@ -93,7 +94,8 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
   constexpr int CB4 = CB / 4;
   constexpr int NW = (KC * TAPS * CB4 + 255) / 256;   // 16-byte weight loads per thread and chunk
   constexpr int XS_SZ = KC * S, WS_SZ = NW * 1024;     // weight slab [KC*TAPS][CB], padded to whole load rounds
-  constexpr int RED_SZ = 4 * CB * 2;
+  constexpr int GRAM_SZ = (P16 && KS == 3) ? 4 * 16 * 65 + 4 * 256 : 0;   // wave-private [16 ch][64 px (+1)] tiles + 4 partial Grams
+  constexpr int RED_SZ = 4 * CB * 2 > GRAM_SZ ? 4 * CB * 2 : GRAM_SZ;
   constexpr int MAIN_SZ = (XS_SZ + WS_SZ) > RED_SZ ? (XS_SZ + WS_SZ) : RED_SZ;
   __shared__ __attribute__((aligned(16))) float smem[MAIN_SZ + CB];
   float* bias_s = smem + MAIN_SZ;   // this block's biases (written here, visible after the first barrier of the chunk loop)
@@ -302,6 +304,35 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt][r] = (cvalid && poff[nt] >= 0) ? acc[mt][nt][r] : 0.f;
       }
   }
+  if constexpr (P16 && KS == 3) {
+    // Gram of the output tile in the epilogue (the WT loss's G = z z^T, reference algorithms.py:1283): the DeepWT convs that
+    // produce z1 / z2 hand the loss their per-tile partial Grams, so that compute_whitening_loss never reads z from HBM
+    // again (134 MB per map at B=32, 256x256).  The accumulators hold [channel in registers][pixel on lanes]; the 16x16x4
+    // MFMA wants [channel on lanes][4 pixels across lane groups] — one trip through a wave-private LDS tile — and then takes
+    // the same register as A and as B (as gram_partial_k does).
+    if (a.gram) {
+      __syncthreads();   // every wave is done with Xs / Ws
+      float* zs = smem + wave * (16 * 65);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < NACC; ++r) zs[((lane >> 4) * 4 + r) * 65 + nt * 16 + (lane & 15)] = acc[0][nt][r];
+      __builtin_amdgcn_wave_barrier();
+      f32x4 g = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int st = 0; st < 16; ++st) {
+        const float v = zs[(lane & 15) * 65 + 4 * st + (lane >> 4)];
+        g = mfma16(v, v, g);
+      }
+      float* gs = smem + 4 * 16 * 65 + wave * 256;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) gs[((lane >> 4) * 4 + r) * 16 + (lane & 15)] = g[r];
+      __syncthreads();
+      const float* g0 = smem + 4 * 16 * 65;
+      a.gram[(size_t)blockIdx.x * 256 + tid] = g0[tid] + g0[256 + tid] + g0[512 + tid] + g0[768 + tid];
+      __syncthreads();   // before the statistics (if any) reuse smem
+    }
+  }
   const unsigned hw4 = (unsigned)HW * 4u;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
@@ -415,11 +446,10 @@ extern "C" int wtpse_conv_stats_blocks(int B, int H, int W) {
   return B * ceil_div(W, TW) * ceil_div(H, TH);
 }
 
-// See include/wtpse_hip.h for the contract.
-extern "C" int wtpse_conv_fwd(const float* in0, int C0, const float* in1, int C1, const float* wpacked,
-                              const float* bias, const float* pro0, const float* pro1, int pro_relu, float* out0, float* out1,
-                              int Csplit, float* stats, int B, int H, int W, int Cout, int ksize, int relu_out,
-                              const float* mask_ref, void* stream) {
+static int conv_fwd_impl(const float* in0, int C0, const float* in1, int C1, const float* wpacked, const float* bias,
+                         const float* pro0, const float* pro1, int pro_relu, float* out0, float* out1, int Csplit, float* stats,
+                         int B, int H, int W, int Cout, int ksize, int relu_out, const float* mask_ref, float* gram,
+                         void* stream) {
   WTPSE_REQUIRE(in0 && wpacked && out0 && B > 0 && H > 0 && W > 0 && C0 > 0 && C1 >= 0 && Cout > 0);
   WTPSE_REQUIRE(ksize == 1 || ksize == 3);
   WTPSE_REQUIRE((C1 == 0) == (in1 == nullptr));
@@ -430,7 +460,7 @@ extern "C" int wtpse_conv_fwd(const float* in0, int C0, const float* in1, int C1
   WTPSE_REQUIRE(!(mask_ref && out1));
   WTPSE_REQUIRE(C1 == 0 || C0 % 16 == 0);   // a channel chunk must not straddle the two inputs
   ConvArgs a;
-  a.in0 = in0; a.in1 = in1; a.wp = wpacked; a.bias = bias; a.pro0 = pro0; a.pro1 = pro1; a.out0 = out0; a.out1 = out1; a.stats = stats; a.mask = mask_ref;
+  a.in0 = in0; a.in1 = in1; a.wp = wpacked; a.bias = bias; a.pro0 = pro0; a.pro1 = pro1; a.out0 = out0; a.out1 = out1; a.stats = stats; a.mask = mask_ref; a.gram = gram;
   a.B = B; a.H = H; a.W = W; a.C0 = C0; a.C1 = C1; a.Cin = C0 + C1; a.CinP = (a.Cin + 3) & ~3;
   a.Cout = Cout; a.CoutP = (Cout + 15) & ~15; a.Csplit = Csplit; a.pro_relu = pro_relu; a.relu_out = relu_out;
   a.tiles_x = a.tiles_y = 0;
@@ -454,6 +484,26 @@ extern "C" int wtpse_conv_fwd(const float* in0, int C0, const float* in1, int C1
   if (mode == 1) return FWD(1, 1);
   return FWD(1, 2);
 #undef FWD
+}
+
+// See include/wtpse_hip.h for the contract.
+extern "C" int wtpse_conv_fwd(const float* in0, int C0, const float* in1, int C1, const float* wpacked,
+                              const float* bias, const float* pro0, const float* pro1, int pro_relu, float* out0, float* out1,
+                              int Csplit, float* stats, int B, int H, int W, int Cout, int ksize, int relu_out,
+                              const float* mask_ref, void* stream) {
+  return conv_fwd_impl(in0, C0, in1, C1, wpacked, bias, pro0, pro1, pro_relu, out0, out1, Csplit, stats, B, H, W, Cout, ksize,
+                       relu_out, mask_ref, nullptr, stream);
+}
+
+// 3x3 convolution with exactly 16 output channels that also emits the per-tile partial Grams of its output
+// (gram_partial: [wtpse_conv_stats_blocks(B,H,W)][256], tile-major per image = the `partial` layout of the WT loss with
+// S = tiles per image; see wtpse_wt_loss_fwd_partials).
+extern "C" int wtpse_conv_fwd_gram(const float* in0, int C0, const float* wpacked, const float* bias, const float* pro0,
+                                   int pro_relu, float* out0, float* gram_partial, int B, int H, int W, int Cout, int relu_out,
+                                   void* stream) {
+  WTPSE_REQUIRE(gram_partial && Cout == 16);
+  return conv_fwd_impl(in0, C0, nullptr, 0, wpacked, bias, pro0, nullptr, pro_relu, out0, nullptr, Cout, nullptr, B, H, W, Cout, 3,
+                       relu_out, nullptr, gram_partial, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

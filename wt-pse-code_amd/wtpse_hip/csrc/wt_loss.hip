@@ -79,7 +79,20 @@ __global__ __launch_bounds__(256) void gram_finalize_k(const float* __restrict__
   const int b = blockIdx.x, t = threadIdx.x;
   const int i = t >> 4, j = t & 15;
   float s = 0.f;
-  for (int k = 0; k < S; ++k) s += partial[((size_t)b * S + k) * 256 + t];
+  if (S >= 64) {   // per-tile partials from a conv epilogue (wtpse_conv_fwd_gram): four independent chains, loads in flight
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 3 < S; k += 4) {
+      s0 += partial[((size_t)b * S + k) * 256 + t];
+      s1 += partial[((size_t)b * S + k + 1) * 256 + t];
+      s2 += partial[((size_t)b * S + k + 2) * 256 + t];
+      s3 += partial[((size_t)b * S + k + 3) * 256 + t];
+    }
+    for (; k < S; ++k) s0 += partial[((size_t)b * S + k) * 256 + t];
+    s = (s0 + s1) + (s2 + s3);
+  } else {
+    for (int k = 0; k < S; ++k) s += partial[((size_t)b * S + k) * 256 + t];
+  }
   float g = s / (float)(HW - 1) + (i == j ? eps : 0.f);
   gram[(size_t)b * 256 + t] = g;
   if (i < j) v[(size_t)b * WT_NV + triu_index(i, j)] = g;
@@ -294,6 +307,22 @@ extern "C" int wtpse_wt_loss_fwd(const float* z, int B, int C, int HW, float eps
     hipLaunchKernelGGL(gram_partial_k<true>, dim3(B * S), dim3(256), 0, st, z, HW, S, chunk, partial);
   else
     hipLaunchKernelGGL(gram_partial_k<false>, dim3(B * S), dim3(256), 0, st, z, HW, S, chunk, partial);
+  hipLaunchKernelGGL(gram_finalize_k, dim3(B), dim3(256), 0, st, partial, S, HW, eps, gram, v, offdiag, diag);
+  hipLaunchKernelGGL(mmd_rows_k, dim3(R), dim3(128), R * sizeof(double), st, v, domain_num, per_domain, rowval, dmmd_dv);
+  hipLaunchKernelGGL(wt_final_k, dim3(1), dim3(256), 0, st, offdiag, diag, B, B, margin, rowval, R, losses);
+  return wtpse_status();
+}
+
+// The same loss from per-tile partial Grams produced elsewhere (the epilogue of the conv that wrote z:
+// wtpse_conv_fwd_gram): partial [B][S][256].  z itself is not read: 16*HW*4 bytes per image stay in HBM untouched.
+extern "C" int wtpse_wt_loss_fwd_partials(const float* partial, int S, int B, int HW, float eps, float margin, int domain_num,
+                                          int per_domain, float* gram, float* v, float* offdiag, float* diag, double* rowval,
+                                          float* dmmd_dv, float* losses, void* stream) {
+  WTPSE_REQUIRE(partial && gram && v && offdiag && diag && rowval && dmmd_dv && losses);
+  WTPSE_REQUIRE(S >= 1 && B > 0 && HW > 1 && domain_num >= 1 && per_domain >= 1);
+  const int R = domain_num * per_domain;
+  WTPSE_REQUIRE(R <= B);
+  hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(gram_finalize_k, dim3(B), dim3(256), 0, st, partial, S, HW, eps, gram, v, offdiag, diag);
   hipLaunchKernelGGL(mmd_rows_k, dim3(R), dim3(128), R * sizeof(double), st, v, domain_num, per_domain, rowval, dmmd_dv);
   hipLaunchKernelGGL(wt_final_k, dim3(1), dim3(256), 0, st, offdiag, diag, B, B, margin, rowval, R, losses);

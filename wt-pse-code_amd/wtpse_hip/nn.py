@@ -751,14 +751,34 @@ def head_bwd(seq, t, d, idxs):
 
 
 # ---- DeepWT (algorithms.py:1091-1117) -----------------------------------------------------------------------------
-def deepwt_fwd(wt, x, want_tape=True):
+# Gram partials of z1 / z2 in the epilogue of the convs that write them: the WT loss then never reads the maps from HBM
+# (134 MB per map at B=32, 256x256).  WTPSE_WT_FUSED_GRAM=0: the stand-alone gram_partial_k pass.
+WT_FUSED_GRAM = os.environ.get("WTPSE_WT_FUSED_GRAM", "1") != "0"
+
+
+def _conv_gram(layer, a0):
+    """3x3, 16 output channels, no BatchNorm: -> (z, (partial Grams, S))."""
+    a0 = as_act(a0)
+    return ops.conv_fwd_gram(a0.t, layer._root.packed_ptr(layer.wf_off), layer.bias, a0.pro, _relu_bits(a0, None), False)
+
+
+def deepwt_fwd(wt, x, want_tape=True, want_gram=False):
+    """want_gram: the caller computes the WT loss on z1 / z2 (training updates): t.g1 / t.g2 = their partial Grams."""
     t = Tape()
     a, b = wt.DoubleConv.double_conv, wt.DoubleConv2.double_conv
     t.x = x
+    t.g1 = t.g2 = None
+    fused = want_gram and WT_FUSED_GRAM and a[2].cout == 16 and a[2].k == 3 and b[2].cout == 16
     t.h1, _ = _conv(a[0], x, None, True)
-    t.z1, _ = _conv(a[2], t.h1)
+    if fused:
+        t.z1, t.g1 = _conv_gram(a[2], t.h1)
+    else:
+        t.z1, _ = _conv(a[2], t.h1)
     t.h2, _ = _conv(b[0], Act(t.z1, None, True), None, True)     # ReLU(z1) on load
-    t.z2, _ = _conv(b[2], t.h2)
+    if fused:
+        t.z2, t.g2 = _conv_gram(b[2], t.h2)
+    else:
+        t.z2, _ = _conv(b[2], t.h2)
     return t
 
 

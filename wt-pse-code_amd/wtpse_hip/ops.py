@@ -66,6 +66,20 @@ def conv_fwd(in0, in1, wpacked_ptr, bias, cout, ksize, pro0=None, pro_relu=0, re
     return out0, out1, stats
 
 
+def conv_fwd_gram(in0, wpacked_ptr, bias, pro0=None, pro_relu=0, relu_out=False):
+    """3x3 conv with 16 output channels that also returns the per-tile partial Grams of its output.
+    -> (out, (partial [B*S,256], S)) with S = tiles per image: what wt_loss_fwd(..., gram_partial=) takes."""
+    _chk(in0, "in0"); _chk(pro0, "pro0")
+    B, C0, H, W = in0.shape
+    L = lib()
+    out = torch.empty((B, 16, H, W), dtype=torch.float32, device=in0.device)
+    nblk = L.query("wtpse_conv_stats_blocks", B, H, W)
+    partial = torch.empty((nblk, 256), dtype=torch.float32, device=in0.device)
+    L.call("wtpse_conv_fwd_gram", ptr(in0), C0, wpacked_ptr, ptr(bias), ptr(pro0), int(pro_relu), ptr(out), ptr(partial), B, H, W,
+           16, int(relu_out), stream_ptr())
+    return out, (partial, nblk // B)
+
+
 def x3_packed_size(rows, k, taps):
     """unsigned shorts of one direction of one conv in the x3 layout (include/wtpse_hip.h)."""
     return ((k + 15) & ~15) * ((rows + 31) & ~31) * taps * 3
@@ -173,8 +187,9 @@ class WtLossState:
     __slots__ = ("z", "gram", "offdiag", "diag", "dmmd_dv", "losses", "v", "B", "HW", "D", "n", "margin")
 
 
-def wt_loss_fwd(z, domain_num, per_domain, margin=0.0, eps=1e-5, losses_out=None):
-    """-> WtLossState; st.losses = device [3] = (ins_offdiag, ins_diag, domain)."""
+def wt_loss_fwd(z, domain_num, per_domain, margin=0.0, eps=1e-5, losses_out=None, gram_partial=None):
+    """-> WtLossState; st.losses = device [3] = (ins_offdiag, ins_diag, domain).
+    gram_partial: (partial, S) from conv_fwd_gram — the producer of z already formed the per-tile Grams: z is not read."""
     _chk(z, "z")
     B, C, H, W = z.shape
     HW = H * W
@@ -183,7 +198,7 @@ def wt_loss_fwd(z, domain_num, per_domain, margin=0.0, eps=1e-5, losses_out=None
     S = L.query("wtpse_wt_split", B, HW, 0)
     R = domain_num * per_domain
     st = WtLossState()
-    partial = workspace("wt_partial", B * S * 256, dev)
+    partial = workspace("wt_partial", B * S * 256, dev) if gram_partial is None else None
     st.gram = torch.empty((B, 256), dtype=torch.float32, device=dev)
     st.v = torch.empty((B, 120), dtype=torch.float32, device=dev)
     st.offdiag = torch.empty((B,), dtype=torch.float32, device=dev)
@@ -191,9 +206,15 @@ def wt_loss_fwd(z, domain_num, per_domain, margin=0.0, eps=1e-5, losses_out=None
     rowval = torch.empty((max(R, 1),), dtype=torch.float64, device=dev)
     st.dmmd_dv = torch.empty((max(R, 1), 120), dtype=torch.float32, device=dev)
     st.losses = losses_out if losses_out is not None else torch.empty((3,), dtype=torch.float32, device=dev)
-    L.call("wtpse_wt_loss_fwd", ptr(z), B, C, HW, float(eps), float(margin), int(domain_num), int(per_domain),
-           ptr(partial), ptr(st.gram), ptr(st.v), ptr(st.offdiag), ptr(st.diag), ptr(rowval), ptr(st.dmmd_dv),
-           ptr(st.losses), stream_ptr())
+    if gram_partial is not None:
+        gp, gs = gram_partial
+        assert C == 16 and gp.shape[0] == B * gs
+        L.call("wtpse_wt_loss_fwd_partials", ptr(gp), int(gs), B, HW, float(eps), float(margin), int(domain_num), int(per_domain),
+               ptr(st.gram), ptr(st.v), ptr(st.offdiag), ptr(st.diag), ptr(rowval), ptr(st.dmmd_dv), ptr(st.losses), stream_ptr())
+    else:
+        L.call("wtpse_wt_loss_fwd", ptr(z), B, C, HW, float(eps), float(margin), int(domain_num), int(per_domain),
+               ptr(partial), ptr(st.gram), ptr(st.v), ptr(st.offdiag), ptr(st.diag), ptr(rowval), ptr(st.dmmd_dv),
+               ptr(st.losses), stream_ptr())
     st.z, st.B, st.HW, st.D, st.n, st.margin = z, B, HW, domain_num, per_domain, float(margin)
     return st
 
