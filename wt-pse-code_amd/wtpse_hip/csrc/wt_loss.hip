@@ -79,17 +79,23 @@ __global__ __launch_bounds__(256) void gram_finalize_k(const float* __restrict__
   const int b = blockIdx.x, t = threadIdx.x;
   const int i = t >> 4, j = t & 15;
   float s = 0.f;
-  if (S >= 64) {   // per-tile partials from a conv epilogue (wtpse_conv_fwd_gram): four independent chains, loads in flight
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int k = 0;
-    for (; k + 3 < S; k += 4) {
-      s0 += partial[((size_t)b * S + k) * 256 + t];
-      s1 += partial[((size_t)b * S + k + 1) * 256 + t];
-      s2 += partial[((size_t)b * S + k + 2) * 256 + t];
-      s3 += partial[((size_t)b * S + k + 3) * 256 + t];
+  if (S >= 64) {
+    // per-tile partials from a conv epilogue (wtpse_conv_fwd_gram), hundreds per image: the four waves take every fourth
+    // partial with one 16-byte load per lane (a 1 KB row per wave and load, two rows in flight), then meet in LDS
+    __shared__ float fold[4][256];
+    const int q = t >> 6, l = t & 63;
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+    int k = q;
+    for (; k + 4 < S; k += 8) {
+      a0 += *reinterpret_cast<const f32x4*>(partial + ((size_t)b * S + k) * 256 + 4 * l);
+      a1 += *reinterpret_cast<const f32x4*>(partial + ((size_t)b * S + k + 4) * 256 + 4 * l);
     }
-    for (; k < S; ++k) s0 += partial[((size_t)b * S + k) * 256 + t];
-    s = (s0 + s1) + (s2 + s3);
+    for (; k < S; k += 4) a0 += *reinterpret_cast<const f32x4*>(partial + ((size_t)b * S + k) * 256 + 4 * l);
+    a0 += a1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) fold[q][4 * l + e] = a0[e];
+    __syncthreads();
+    s = (fold[0][t] + fold[1][t]) + (fold[2][t] + fold[3][t]);
   } else {
     for (int k = 0; k < S; ++k) s += partial[((size_t)b * S + k) * 256 + t];
   }
