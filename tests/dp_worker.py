@@ -145,6 +145,19 @@ def nccl_rccl(rank, world, port, out_dir, B_g, pb_g, H):
         tag = "exact" if mode else "ddp"
         res["losses_" + tag] = {k: float(v) for k, v in lo.items()}
         res["params_" + tag] = [n.flat_params().detach().cpu().clone() for n in nets]
+    # the same throughput-mode step replayed from launch plans: the gradient all-reduces run between the recorded stretches
+    nets_e, nets_p = build_nets(n_l), build_nets(n_l)
+    for nn_ in nets_e + nets_p:
+        nn_.seed_noise(77)
+    ts_e = TrainStep(*nets_e, HP, dp=DataParallel(world, rank, dev, bn_sync=False))
+    ts_p = TrainStep(*nets_p, HP, dp=DataParallel(world, rank, dev, bn_sync=False), graph="plan")
+    for _ in range(2):
+        ts_e.step(img[rows].to(dev), od[rows].to(dev), oc[rows].to(dev))
+        lp = ts_p.step(img[rows].to(dev), od[rows].to(dev), oc[rows].to(dev))
+    torch.cuda.synchronize()
+    res["plan_equals_eager"] = all(bool(torch.equal(a.flat_params(), b.flat_params())) for a, b in zip(nets_e, nets_p))
+    res["plan_segments"] = len(ts_p._graphs)
+    res["losses_plan"] = {k: float(v) for k, v in lp.items()}
     torch.save(res, os.path.join(out_dir, "r%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()

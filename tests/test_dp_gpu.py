@@ -118,8 +118,9 @@ def test_exact_mode_matches_single_device(tmp_path):
 def _check_steps(res):
     for rk in res:
         assert rk["mean"] and rk["sum"] and rk["bcast"], {k: rk[k] for k in ("mean", "sum", "bcast")}
-        for tag in ("exact", "ddp"):
+        for tag in ("exact", "ddp", "plan"):
             assert all(np.isfinite(v) for v in rk["losses_" + tag].values()), rk["losses_" + tag]
+        assert rk["plan_equals_eager"] and rk["plan_segments"] == 5, (rk["plan_equals_eager"], rk["plan_segments"])
     for rk in res[1:]:
         for tag in ("exact", "ddp"):          # same averaged gradient + same Adam -> identical parameters on every rank
             for a, b in zip(res[0]["params_" + tag], rk["params_" + tag]):
