@@ -52,6 +52,7 @@ int wtpse_conv_fwd_gram(const float* in0, int C0, const float* wpacked, const fl
  * wtpse_pack_conv_weights_x3 — desc as for wtpse_pack_conv_weights with offsets {xf_off, xd_off} in unsigned shorts; per
  * conv and direction ceil16(K) * ceil32(rows) * taps * 3 unsigned shorts (forward: rows = Cout, K = Cin; data gradient:
  * rows = Cin, K = Cout), layout [K chunk 16][row block 32][tap][term 3][k half 2][row 32][8 k]. */
+int wtpse_conv_x3_stats_blocks(int B, int H, int W, int Cout);   /* rows of `stats` for wtpse_conv_fwd_x3 */
 int wtpse_pack_conv_weights_x3(const float* params, const int* desc, int n_desc, unsigned short* packed, void* stream);
 int wtpse_conv_fwd_x3(const float* in0, int C0, const float* in1, int C1, const unsigned short* wpacked, const float* bias,
                       const float* pro0, const float* pro1, int pro_relu, float* out0, float* out1, int Csplit, float* stats,

@@ -63,15 +63,17 @@ __device__ __forceinline__ void split3_pair(float a, float b, unsigned& p0, unsi
   p2 = pack_rne(sa, sb);
 }
 
-template <int KS, int MT, int TWL, bool MASK>
+// NT = 32-pixel column tiles per wave: 2 (256-pixel workgroup tile) or 1 (128 pixels: twice the workgroups for the 16x16
+// maps, whose 256-pixel tiles would leave one workgroup per CU with nothing to overlap its loader phases with)
+template <int KS, int MT, int TWL, bool MASK, int NT = 2>
 __global__ __launch_bounds__(256, 2) void conv_x3_k(ConvX3Args a) {
   constexpr int TAPS = KS * KS, PAD = KS / 2;
-  constexpr int TW = 1 << TWL, TH = 256 / TW;
+  constexpr int TW = 1 << TWL, TH = (128 * NT) / TW;
   constexpr int PITCH = TW + 2 * PAD, ROWS = TH + 2 * PAD;
   constexpr int PE = PITCH * ROWS;
   constexpr int PEP = (PE + 7) & ~7;
   constexpr int CB = 32 * MT;
-  constexpr int NT = 2, NACC = 16;
+  constexpr int NACC = 16;
   constexpr int KC = 16;
   constexpr int XS_U4 = 6 * PEP;                   // 16-byte slots
   constexpr int WS_U4 = KS * 6 * CB;               // one kernel row (KS taps)
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_k(ConvX3Args a) {
   int off[NT];                                    // halo position of this lane's pixel (tap 0,0 corner)
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    const int p = wave * 64 + nt * 32 + r32;
+    const int p = wave * (32 * NT) + nt * 32 + r32;
     off[nt] = (p >> TWL) * PITCH + (p & (TW - 1));
   }
   // Loader work items: (halo position, k-half) = 8 channels of one position.  The two halves are laid out as
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_k(ConvX3Args a) {
   int poff[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    const int p = wave * 64 + nt * 32 + r32;
+    const int p = wave * (32 * NT) + nt * 32 + r32;
     const int gy = ty * TH + (p >> TWL), gx = tx * TW + (p & (TW - 1));
     poff[nt] = (gy < a.H && gx < a.W) ? gy * a.W + gx : -1;
   }
@@ -433,19 +435,47 @@ extern "C" int wtpse_pack_conv_weights_x3(const float* params, const int* desc, 
   return wtpse_status();
 }
 
+// 128-pixel tiles: only where the 256-pixel tiling gives under two workgroups per CU on a 16-wide map (the deepest level)
+static bool x3_small_tiles(int B, int H, int W, int CoutP, bool mt2) {
+  if (W > 16 || mt2) return false;
+  return B * ceil_div(H, 16) * ceil_div(W, 16) * (CoutP / 32) < 512;
+}
+
 template <int KS, int MT, bool MASK>
 static int launch_x3(const ConvX3Args& a, hipStream_t st) {
   ConvX3Args args = a;
   const bool narrow = a.W <= 16;
-  const int TW = narrow ? 16 : 32, TH = 256 / TW;
+  const bool small = MT == 1 && x3_small_tiles(a.B, a.H, a.W, a.CoutP, false);
+  const int TW = narrow ? 16 : 32, TH = (small ? 128 : 256) / TW;
   args.tiles_x = ceil_div(a.W, TW);
   args.tiles_y = ceil_div(a.H, TH);
   dim3 grid((unsigned)(a.B * args.tiles_x * args.tiles_y), (unsigned)ceil_div(a.CoutP, 32 * MT));
-  if (narrow)
+  if (small) {
+    if constexpr (MT == 1) hipLaunchKernelGGL((conv_x3_k<KS, 1, 4, MASK, 1>), grid, dim3(256), 0, st, args);
+  } else if (narrow)
     hipLaunchKernelGGL((conv_x3_k<KS, MT, 4, MASK>), grid, dim3(256), 0, st, args);
   else
     hipLaunchKernelGGL((conv_x3_k<KS, MT, 5, MASK>), grid, dim3(256), 0, st, args);
   return wtpse_status();
+}
+
+static bool x3_mt2(int B, int H, int W, int CoutP) {
+  const int TW = W <= 16 ? 16 : 32, TH = 256 / TW;
+  const int tiles = B * ceil_div(W, TW) * ceil_div(H, TH);
+  bool mt2 = (CoutP % 64 == 0) && tiles * (CoutP / 64) >= 512;
+  if (const char* e = getenv("WTPSE_X3_MT")) {   // tuning override: 1 | 2
+    if (e[0] == '1') mt2 = false;
+    if (e[0] == '2' && CoutP % 64 == 0) mt2 = true;
+  }
+  return mt2;
+}
+
+// workgroups along x of a wtpse_conv_fwd_x3 launch = rows of its `stats` partials
+extern "C" int wtpse_conv_x3_stats_blocks(int B, int H, int W, int Cout) {
+  const int CoutP = (Cout + 31) & ~31;
+  const bool small = x3_small_tiles(B, H, W, CoutP, x3_mt2(B, H, W, CoutP));
+  const int TW = W <= 16 ? 16 : 32, TH = (small ? 128 : 256) / TW;
+  return B * ceil_div(W, TW) * ceil_div(H, TH);
 }
 
 // Same contract as wtpse_conv_fwd (include/wtpse_hip.h) with `wpacked` in the x3 layout.  Cout <= 16 runs on a 32-row
@@ -470,13 +500,7 @@ extern "C" int wtpse_conv_fwd_x3(const float* in0, int C0, const float* in1, int
   a.Cout = Cout; a.CoutP = (Cout + 31) & ~31; a.Csplit = Csplit; a.pro_relu = pro_relu; a.relu_out = relu_out;
   a.tiles_x = a.tiles_y = 0;
   hipStream_t st = (hipStream_t)stream;
-  const int TW = W <= 16 ? 16 : 32, TH = 256 / TW;
-  const int tiles = B * ceil_div(W, TW) * ceil_div(H, TH);
-  bool mt2 = (a.CoutP % 64 == 0) && tiles * (a.CoutP / 64) >= 512;
-  if (const char* e = getenv("WTPSE_X3_MT")) {   // tuning override: 1 | 2
-    if (e[0] == '1') mt2 = false;
-    if (e[0] == '2' && a.CoutP % 64 == 0) mt2 = true;
-  }
+  const bool mt2 = x3_mt2(B, H, W, a.CoutP);
 #define X3(KS, M) (mask_ref ? launch_x3<KS, M, true>(a, st) : launch_x3<KS, M, false>(a, st))
   if (ksize == 3) return mt2 ? X3(3, 2) : X3(3, 1);
   return mt2 ? X3(1, 2) : X3(1, 1);

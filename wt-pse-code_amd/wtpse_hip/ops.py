@@ -102,7 +102,7 @@ def conv_fwd_x3(in0, in1, wpacked_ptr, bias, cout, ksize, pro0=None, pro_relu=0,
         out1 = torch.empty((B, cout - csplit, H, W), dtype=torch.float32, device=in0.device)
     stats = None
     if want_stats:
-        nblk = L.query("wtpse_conv_stats_blocks", B, H, W)
+        nblk = L.query("wtpse_conv_x3_stats_blocks", B, H, W, cout)
         stats = torch.empty((nblk, cout, 2), dtype=torch.float32, device=in0.device)
     L.call("wtpse_conv_fwd_x3", ptr(in0), C0, ptr(in1), C1, wpacked_ptr, ptr(bias), ptr(pro0), ptr(pro1), int(pro_relu), ptr(out0),
            ptr(out1), csplit, ptr(stats), B, H, W, cout, ksize, int(relu_out), ptr(mask_ref), stream_ptr())
