@@ -67,59 +67,6 @@ def test_conv_x3_forward(case):
     assert e3 <= 2.0 * e32 + 2e-8, (e3, e32)
 
 
-PP_CASES = [
-    # B, C0, C1, Cout, H, W     (3x3; WTPSE_X3_MT=2 forces the 64-cout tiling the ping-pong kernel serves)
-    (4, 32, 0, 64, 32, 64),        # even tile count, two chunks
-    (1, 16, 0, 64, 24, 32),        # 3 tiles: the last workgroup's group B carries a padding tile
-    (3, 64, 64, 128, 16, 32),      # concat input, two cout blocks, 8 chunks
-    (2, 64, 0, 64, 16, 16),        # 16-wide map: stays on the two-workgroup kernel
-    (2, 48, 0, 64, 20, 40),        # ragged tiles and a ragged chunk (48 channels)
-    (1, 16, 0, 64, 8, 8),          # a single tile
-]
-
-
-@pytest.mark.parametrize("case", PP_CASES)
-def test_conv_x3_pingpong_bit_identical(case, monkeypatch):
-    """The ping-pong kernel (one 512-thread workgroup, two tiles, alternating multiply / data phases) performs the arithmetic
-    of the two-workgroups-per-CU kernel in the same order: outputs, statistics partials, masked and split results are equal
-    bit for bit, and both match the host convolution."""
-    o = ops()
-    B, C0, C1, Co, H, W = case
-    monkeypatch.setenv("WTPSE_X3_MT", "2")
-    x0 = rnd(B, C0, H, W, seed=21)
-    x1 = rnd(B, C1, H, W, seed=22) if C1 else None
-    w = rnd(Co, C0 + C1, 3, 3, seed=23, scale=0.2)
-    bias = rnd(Co, seed=24)
-    pro = torch.stack([rnd(C0 + C1, seed=25) * 0.5 + 1.0, rnd(C0 + C1, seed=26)], 1).contiguous()
-    dy = rnd(B, Co, H, W, seed=27)
-    mref = rnd(B, C0 + C1, H, W, seed=28)
-    packed, xf, xd = pack_x3(w)
-    dev = lambda t: None if t is None else t.to(DEV)
-
-    def run():
-        r = []
-        y, _, st = o.conv_fwd_x3(dev(x0), dev(x1), packed.data_ptr() + 2 * xf, dev(bias), Co, 3, want_stats=True)
-        r += [y, st]
-        r.append(o.conv_fwd_x3(dev(x0), dev(x1), packed.data_ptr() + 2 * xf, None, Co, 3, relu_out=True,
-                               pro0=dev(pro[:C0].contiguous()), pro1=(dev(pro[C0:].contiguous()) if C1 else None), pro_relu=1)[0])
-        if (C0 + C1) % 64 == 0:          # the data gradient runs the same kernel with Cout = C0 + C1
-            d0, d1, _ = o.conv_fwd_x3(dev(dy), None, packed.data_ptr() + 2 * xd, None, C0 + C1, 3, split=(C0 if C1 else None))
-            r += [d0] + ([d1] if C1 else [])
-            r.append(o.conv_fwd_x3(dev(dy), None, packed.data_ptr() + 2 * xd, None, C0 + C1, 3, mask_ref=dev(mref))[0])
-        torch.cuda.synchronize()
-        return r
-
-    monkeypatch.setenv("WTPSE_X3_PP", "1")
-    got = run()
-    monkeypatch.setenv("WTPSE_X3_PP", "0")
-    want = run()
-    assert len(got) == len(want)
-    for i, (g_, w_) in enumerate(zip(got, want)):
-        assert g_.shape == w_.shape and torch.equal(g_, w_), (i, float((g_ - w_).abs().max()))
-    xin = torch.cat([x0, x1], 1) if C1 else x0
-    close(got[0], F.conv2d(xin, w, bias, padding=1), what="ping-pong conv x3")
-
-
 @pytest.mark.parametrize("case", [(2, 16, 16, 32, 16, 32, 3), (1, 32, 32, 64, 8, 16, 1), (20, 32, 32, 64, 32, 64, 3)])
 def test_conv_x3_prologue(case):
     o = ops()

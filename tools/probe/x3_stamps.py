@@ -43,8 +43,9 @@ def main():
     vp = ctypes.c_void_p
     dev = torch.device("cuda:0")
     from wtpse_hip import ops
-    x = torch.randn(B, cin, hw, hw, device=dev)
-    w = torch.randn(cout, cin, 3, 3, device=dev) * 0.05
+    zeros = os.environ.get("ZEROS", "0") != "0"          # all-zero operands: the clock the chip holds without data toggling
+    x = torch.zeros(B, cin, hw, hw, device=dev) if zeros else torch.randn(B, cin, hw, hw, device=dev)
+    w = torch.zeros(cout, cin, 3, 3, device=dev) if zeros else torch.randn(cout, cin, 3, 3, device=dev) * 0.05
     xf = ops.x3_packed_size(cout, cin, 9)
     packed = torch.zeros(xf, dtype=torch.int16, device=dev)
     desc = torch.tensor([0, cout, cin, 9, 0, -1, 0, 0], dtype=torch.int32, device=dev)
@@ -53,7 +54,7 @@ def main():
     tiles = B * ((hw + 31) // 32) * ((hw + 7) // 8)
     mt = 2 if (cout % 64 == 0 and tiles * (cout // 64) >= 512) else 1
     nwg = tiles * ((cout + 32 * mt - 1) // (32 * mt))
-    stamps = torch.zeros(nwg * 128, dtype=torch.int64, device=dev)
+    stamps = torch.zeros(nwg * 64, dtype=torch.int64, device=dev)
 
     def run():
         return dll.wtpse_conv_fwd_x3(vp(x.data_ptr()), cin, None, 0, vp(packed.data_ptr()), None, None, None, 0, vp(y.data_ptr()),
@@ -63,26 +64,33 @@ def main():
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(20):
+    nrep = int(os.environ.get("REPS", "200"))            # long enough for the clock to settle under the load
+    for _ in range(nrep):
         run()
     e1.record()
     torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / 20
-    print("unstamped: %.1f us, %.1f TFLOP/s (fp32-equivalent)  [%s]" % (us, 2.0 * B * hw * hw * cin * cout * 9 / us * 1e-6, os.environ.get("PROBE_DEFS", "")))
+    us = e0.elapsed_time(e1) * 1e3 / nrep
+    print("%s operands, %d back-to-back launches: %.1f us, %.1f TFLOP/s fp32-equivalent = %.0f TFLOP/s of bf16 MFMA  [%s]" % (
+        "zero" if zeros else "random", nrep, us, 2.0 * B * hw * hw * cin * cout * 9 / us * 1e-6,
+        12.0 * B * hw * hw * cin * cout * 9 / us * 1e-6, os.environ.get("PROBE_DEFS", "")))
     if not STAMPS:
         return
     assert dll.wtpse_probe_set_stamps_x3(vp(stamps.data_ptr())) == 0
     assert run() == 0
     torch.cuda.synchronize()
-    if mt == 2 and os.environ.get("WTPSE_X3_PP", "1") != "0":
-        return pingpong_report(stamps.cpu().numpy().reshape(-1, 2, 64), cin, cout, hw, B)
-    st = stamps[:nwg * 64].cpu().numpy().reshape(nwg, 64)
+    st = stamps.cpu().numpy().reshape(nwg, 64)
     st = st[st[:, 0] != 0]
     nch = int(st[0, 62])
     hw_id = st[:, 1] & 0xFFFFFFFF
     xcc = (st[:, 1] >> 32) & 0xF
     key = ((xcc * 8 + ((hw_id >> 13) & 0x7)) * 2 + ((hw_id >> 12) & 0x1)) * 16 + ((hw_id >> 8) & 0xF)
     print("x3 forward %d->%d @%d B=%d: workgroups %d, chunks %d, MT %d, distinct CUs %d" % (cin, cout, hw, B, len(st), nch, mt, len(np.unique(key))))
+    clk = (st[:, 61] - st[:, 0]) / np.maximum(st[:, 59] - st[:, 58], 1) * 0.1
+    print("in-kernel clock (s_memtime / s_memrealtime over each workgroup): median %.2f GHz, p10 %.2f, p90 %.2f" % (
+        np.median(clk), *np.percentile(clk, [10, 90])))
+    mf_cycles = nch * 3 * (36 * mt) * 32                  # matrix-pipe cycles of one wave (one wave of a workgroup per SIMD)
+    busy = [np.sum(key == k) * mf_cycles / (st[key == k][:, 61].max() - st[key == k][:, 0].min()) for k in np.unique(key)]
+    print("matrix pipe busy per CU (MFMA cycles of its workgroups / its span): median %.0f %%" % (100 * np.median(busy)))
     n = min(nch, 7)
     ph = {"prologue": st[:, 2] - st[:, 0], "epilogue": st[:, 61] - st[:, 60], "workgroup": st[:, 61] - st[:, 0]}
     rows, gaps, xst = [], [], []
@@ -112,48 +120,6 @@ def main():
             segs.append("c%d M%d g%d M%d g%d M%d x%d" % (c, q[b] - (q[2] if c == 0 else q[3 + 7 * (c - 1) + 5]), q[b + 1] - q[b], q[b + 2] - q[b + 1],
                                                         q[b + 3] - q[b + 2], q[b + 4] - q[b + 3], (q[b + 6] - q[b + 4]) if c + 1 < nch else 0))
         print("  start %7d end %7d | pro %d | %s | epi %d" % (q[0] - t0, q[61] - t0, q[2] - q[0], " ; ".join(segs), q[61] - q[60]))
-
-
-def pingpong_report(st, cin, cout, hw, B):
-    """conv_x3_pp_k: slots per group: 0 start, 2 prologue done, phase p = 2j, 2j+1: 3+2p work done, 4+2p past the barrier,
-    60/61 epilogue; group A multiplies in even phases, B in odd ones."""
-    st = st[st[:, 0, 0] != 0]
-    nrows = int(st[0, 0, 62])
-    nph = min(2 * nrows, 28)
-    print("x3 ping-pong %d->%d @%d B=%d: workgroups %d, rows %d (stamped phases %d)" % (cin, cout, hw, B, len(st), nrows, nph))
-    A, Bg = st[:, 0], st[:, 1]
-    start = np.minimum(A[:, 0], Bg[:, 0])
-    ph = {"prologue (A)": A[:, 2] - A[:, 0], "epilogue (A)": A[:, 61] - A[:, 60], "epilogue (B)": Bg[:, 61] - Bg[:, 60],
-          "workgroup": np.maximum(A[:, 61], Bg[:, 61]) - start}
-    mf, da, dx, wait_m, wait_d, plen = [], [], [], [], [], []
-    for p in range(nph):
-        m, d = (A, Bg) if p % 2 == 0 else (Bg, A)           # multiplying / data group of this phase
-        t_in = m[:, 2 + 2 * p]                               # previous barrier passed (slot 2 for p = 0)
-        mf.append(m[:, 3 + 2 * p] - t_in)
-        jd = (p - 1) // 2 if p % 2 else p // 2 - 1           # row the data group finished last
-        (dx if (jd + 3) % 3 == 2 else da).append(d[:, 3 + 2 * p] - d[:, 2 + 2 * p])
-        wait_m.append(m[:, 4 + 2 * p] - m[:, 3 + 2 * p])
-        wait_d.append(d[:, 4 + 2 * p] - d[:, 3 + 2 * p])
-        plen.append(m[:, 4 + 2 * p] - t_in)
-    ph["phase length"] = np.concatenate(plen)
-    ph["multiply work (72 MFMAs)"] = np.concatenate(mf)
-    ph["data work, weights only"] = np.concatenate(da)
-    ph["data work, with input chunk"] = np.concatenate(dx)
-    ph["multiplier waits at barrier"] = np.concatenate(wait_m)
-    ph["data group waits at barrier"] = np.concatenate(wait_d)
-    for k, v in ph.items():
-        print("%-30s mean %7.0f  p10 %7.0f  p50 %7.0f  p90 %7.0f cycles" % (k, v.mean(), *np.percentile(v, [10, 50, 90])))
-    for gi in range(2):
-        v = st[:, gi]
-        print("  chunk-1 input stash, group %s (median cycles): weights stored %d, item 0 split %d, item 0 stored %d, rest %d" % (
-            "AB"[gi], np.median(v[:, 53] - v[:, 52]), np.median(v[:, 55] - v[:, 53]), np.median(v[:, 56] - v[:, 55]),
-            np.median(v[:, 54] - v[:, 56])))
-    q = st[len(st) // 2]
-    t0 = min(q[0, 0], q[1, 0])
-    for gi in range(2):
-        print("  group %s: start %d pro %d | " % ("AB"[gi], q[gi, 0] - t0, q[gi, 2] - q[gi, 0]) +
-              " ".join("%s%d+%d" % ("M" if p % 2 == gi else "d", q[gi, 3 + 2 * p] - q[gi, 2 + 2 * p], q[gi, 4 + 2 * p] - q[gi, 3 + 2 * p])
-                       for p in range(nph)) + " | epi %d end %d" % (q[gi, 61] - q[gi, 60], q[gi, 61] - t0))
 
 
 if __name__ == "__main__":

@@ -29,19 +29,9 @@ __device__ unsigned long long* g_stamps_x3 = nullptr;
 extern "C" int wtpse_probe_set_stamps_x3(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps_x3), &p, sizeof(p)); }
 #define XSTAMP(i) do { if (g_stamps_x3 && threadIdx.x == 0) g_stamps_x3[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 64 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #define XSTAMPV(i, v) do { if (g_stamps_x3 && threadIdx.x == 0) g_stamps_x3[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 64 + (i)] = (v); } while (0)
-// (ping-pong kernel: lane 0 of each group's first wave keeps its stamps in LDS — a global store per stamp would sit in vmcnt in
-// front of the prefetched loads — and the workgroup dumps them at the end)
-#define PSTAMP_DECL __shared__ unsigned long long stamp_s[128];
-#define PSTAMP(i) do { if (g_stamps_x3 && (threadIdx.x & 255) == 0 && (i) < 64) stamp_s[(threadIdx.x >> 8) * 64 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-#define PSTAMPV(i, v) do { if (g_stamps_x3 && (threadIdx.x & 255) == 0) stamp_s[(threadIdx.x >> 8) * 64 + (i)] = (v); } while (0)
-#define PSTAMP_DUMP do { __syncthreads(); if (g_stamps_x3 && threadIdx.x < 128) g_stamps_x3[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 128 + threadIdx.x] = stamp_s[threadIdx.x]; } while (0)
 #else
 #define XSTAMP(i)
 #define XSTAMPV(i, v)
-#define PSTAMP_DECL
-#define PSTAMP(i)
-#define PSTAMPV(i, v)
-#define PSTAMP_DUMP
 #endif
 
 struct ConvX3Args {
@@ -367,6 +357,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_k(ConvX3Args a) {
 
   const int nchunks = a.CinP / KC;
   XSTAMP(0);
+  XSTAMPV(58, __builtin_amdgcn_s_memrealtime());   // 100 MHz: with slots 0/61 gives the clock the workgroup ran at
   XSTAMPV(1, (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32));
   issue_x(0);
   issue_w(0, 0);
@@ -385,35 +376,53 @@ __global__ __launch_bounds__(256, 2) void conv_x3_k(ConvX3Args a) {
       // keep the loads in front of the MFMAs (left alone, the scheduler sinks them to their first use behind the row,
       // where their latency is exposed)
       __builtin_amdgcn_sched_barrier(0);
-      // ---- MFMAs of this kernel row
+      // ---- MFMAs of this kernel row.  The six cross terms of a tap run as six groups of MT*NT independent MFMAs (one per
+      // accumulator), smallest terms first; a fragment is re-read for tap tl+1 right behind the group that used it last, so
+      // every ds_read has MFMA groups to land behind (left to the scheduler, a tap's 12 reads sit in front of its MFMAs
+      // with their latency exposed three times per row).  The weight terms 0 and 1, needed by the first two groups of the
+      // next tap and used until the last two of this one, alternate between two register sets.
       const u32x4v* Wb = Ws + buf * WS_U4;
+      {
+        bf16x8 a01[2][MT][2], a2[MT], bfr[NT][3];
+        auto rd_a = [&](int tl, int t) {
 #pragma unroll
-      for (int tl = 0; tl < KS; ++tl) {
-        const int toff = ky * PITCH + tl;
-        bf16x8 af[MT][3], bfr[NT][3];
+          for (int mt = 0; mt < MT; ++mt) {
+            const bf16x8 v = __builtin_bit_cast(bf16x8, Wb[((tl * 6) + t * 2 + h) * CB + mt * 32 + r32]);
+            if (t == 2) a2[mt] = v; else a01[tl & 1][mt][t] = v;
+          }
+        };
+        auto rd_b = [&](int tl, int t) {
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
+          for (int nt = 0; nt < NT; ++nt) bfr[nt][t] = __builtin_bit_cast(bf16x8, Xs[(t * 2 + h) * PEP + off[nt] + ky * PITCH + tl]);
+        };
+        auto mm = [&](int tl, int ta, int tb) {
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
-            af[mt][t] = __builtin_bit_cast(bf16x8, Wb[((tl * 6) + t * 2 + h) * CB + mt * 32 + r32]);
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            bfr[nt][t] = __builtin_bit_cast(bf16x8, Xs[(t * 2 + h) * PEP + off[nt] + toff]);
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma_bf16(ta == 2 ? a2[mt] : a01[tl & 1][mt][ta], bfr[nt][tb], acc[mt][nt]);
+        };
+        rd_a(0, 0); rd_b(0, 2); rd_a(0, 1); rd_b(0, 1); rd_a(0, 2); rd_b(0, 0);
+#pragma unroll
+        for (int tl = 0; tl < KS; ++tl) {
+          const bool nx = tl + 1 < KS;
+          __builtin_amdgcn_sched_barrier(0);
+          mm(tl, 0, 2);
+          if (nx) { rd_b(tl + 1, 2); rd_a(tl + 1, 0); }
+          __builtin_amdgcn_sched_barrier(0);
+          mm(tl, 1, 1);
+          if (nx) rd_a(tl + 1, 1);
+          __builtin_amdgcn_sched_barrier(0);
+          mm(tl, 2, 0);
+          if (nx) rd_a(tl + 1, 2);
+          __builtin_amdgcn_sched_barrier(0);
+          mm(tl, 0, 1);
+          if (nx) rd_b(tl + 1, 1);
+          __builtin_amdgcn_sched_barrier(0);
+          mm(tl, 1, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          mm(tl, 0, 0);
+          if (nx) rd_b(tl + 1, 0);
         }
-        // smallest cross terms first
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            f32x16 c = acc[mt][nt];
-            c = mfma_bf16(af[mt][0], bfr[nt][2], c);
-            c = mfma_bf16(af[mt][1], bfr[nt][1], c);
-            c = mfma_bf16(af[mt][2], bfr[nt][0], c);
-            c = mfma_bf16(af[mt][0], bfr[nt][1], c);
-            c = mfma_bf16(af[mt][1], bfr[nt][0], c);
-            c = mfma_bf16(af[mt][0], bfr[nt][0], c);
-            acc[mt][nt] = c;
-          }
       }
       __builtin_amdgcn_sched_barrier(0);
       if (chunk < 7) XSTAMP(3 + 7 * chunk + 2 * ky);        // this row's MFMAs issued
@@ -433,318 +442,8 @@ __global__ __launch_bounds__(256, 2) void conv_x3_k(ConvX3Args a) {
   XSTAMP(60);
   x3_epilogue<MT, NT, TWL, MASK, true>(a, acc, b, ty, tx, cout0, tid, reinterpret_cast<float*>(smem), bias_s, (int)blockIdx.x, true);
   XSTAMP(61);
+  XSTAMPV(59, __builtin_amdgcn_s_memrealtime());
   XSTAMPV(62, (unsigned long long)nchunks);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Ping-pong form of the 3x3 kernel (64 couts x 256 pixels per tile): one 512-thread workgroup per CU carries TWO pixel
-// tiles, one per group of 4 waves (a SIMD holds one wave of each group), and the groups alternate roles row by row
-// (row = one kernel row of one 16-channel chunk = 72 MFMAs per wave):
-//      phase 2j   : group A multiplies row j            | group B moves data
-//      phase 2j+1 : group A moves data                  | group B multiplies row j
-// with one workgroup barrier per phase.  "Moves data" = store its half of the next weight row (both tiles use the same 64
-// couts, so the double-buffered weight slab is shared), split + store its own next input chunk when it has just left a chunk,
-// and issue the global loads the next such phase will store.  Two independent workgroups per CU (conv_x3_k) drift into
-// lockstep — both multiply, then both sit in their loader phases with the matrix cores idle (tools/probe/x3_stamps.py:
-// MFMA busy 58 %) — here the matrix pipe of a SIMD always has exactly one wave feeding it.  Arithmetic and summation order
-// are those of conv_x3_k: results are bit-identical.
-#ifdef EXP_NOBAR
-#define PP_SYNC() do {} while (0)
-#else
-#define PP_SYNC() __syncthreads()
-#endif
-template <int TWL, bool MASK>
-__global__ __launch_bounds__(512, 1) void conv_x3_pp_k(ConvX3Args a) {
-  constexpr int KS = 3, TAPS = 9, PAD = 1, MT = 2, NT = 2;
-  constexpr int TW = 1 << TWL, TH = 256 / TW;
-  constexpr int PITCH = TW + 2 * PAD, ROWS = TH + 2 * PAD;
-  constexpr int PE = PITCH * ROWS;
-  constexpr int PEP = (PE + 7) & ~7;
-  constexpr int CB = 32 * MT;
-  constexpr int KC = 16;
-  constexpr int XS_U4 = 6 * PEP;                   // 16-byte slots, one tile
-  constexpr int WS_U4 = KS * 6 * CB;               // one kernel row
-  constexpr int WH_U4 = WS_U4 / 2;                 // a group's half of it
-  constexpr int NW = (WH_U4 + 255) / 256;
-  constexpr int RED_U4 = (4 * CB * 2) / 4;
-  __shared__ u32x4v smem[2 * XS_U4 + 2 * WS_U4 + 2 * RED_U4 + CB / 4];
-  PSTAMP_DECL
-  const int g = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);     // 0: group A, 1: group B
-  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
-  u32x4v* Xs = smem + g * XS_U4;
-  u32x4v* Ws = smem + 2 * XS_U4;
-  float* red = reinterpret_cast<float*>(smem + 2 * XS_U4 + 2 * WS_U4 + g * RED_U4);
-  float* bias_s = reinterpret_cast<float*>(smem + 2 * XS_U4 + 2 * WS_U4 + 2 * RED_U4);
-
-  const int r32 = lane & 31, h = lane >> 5;
-  const int ntiles = a.B * a.tiles_x * a.tiles_y;
-  int tile = 2 * (int)blockIdx.x + g;
-  const bool live = tile < ntiles;                 // an odd tile count leaves the last group B a padding tile
-  tile = live ? tile : ntiles - 1;
-  int bx = tile;
-  const int tx = bx % a.tiles_x;
-  bx /= a.tiles_x;
-  const int ty = bx % a.tiles_y;
-  const int b = bx / a.tiles_y;
-  const int cout0 = blockIdx.y * CB;
-  const int HW = a.H * a.W;
-  if (threadIdx.x < CB) bias_s[threadIdx.x] = (a.bias && cout0 + (int)threadIdx.x < a.Cout) ? a.bias[cout0 + threadIdx.x] : 0.f;
-
-  int off[NT];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int p = wave * (32 * NT) + nt * 32 + r32;
-    off[nt] = (p >> TWL) * PITCH + (p & (TW - 1));
-  }
-  constexpr int PB = (PE + 63) / 64;
-  constexpr int NIT = (2 * PB + 3) / 4;
-  int ipos[NIT], ihalf[NIT];
-  unsigned voff[NIT];
-  bool iin[NIT];
-#pragma unroll
-  for (int i = 0; i < NIT; ++i) {
-    const int blk = __builtin_amdgcn_readfirstlane(i * 4 + wave);
-    ihalf[i] = blk >= PB ? 1 : 0;
-    const int p = (blk - ihalf[i] * PB) * 64 + lane;
-    ipos[i] = (blk < 2 * PB && p < PE) ? p : -1;
-    const int r = p / PITCH, x = p - r * PITCH;
-    const int gy = ty * TH + r - PAD, gx = tx * TW + x - PAD;
-    iin[i] = ipos[i] >= 0 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-    voff[i] = iin[i] ? (unsigned)(gy * a.W + gx) * 4u + (unsigned)ihalf[i] * 8u * (unsigned)HW * 4u : BUF_OOB;
-  }
-
-  f32x16 acc[MT][NT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
-
-  const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(a.in0 + (size_t)b * a.C0 * HW, (unsigned)a.C0 * HW * 4u);
-  const __amdgpu_buffer_rsrc_t rs1 = a.in1 ? make_rsrc(a.in1 + (size_t)b * a.C1 * HW, (unsigned)a.C1 * HW * 4u) : rs0;
-  const int ncb32 = a.CoutP / 32;
-  const __amdgpu_buffer_rsrc_t rsw = make_rsrc(a.wx, (unsigned)(a.CinP / 16) * ncb32 * TAPS * 6u * 32u * 16u);
-  const bool any_pro = a.pro0 != nullptr || a.pro1 != nullptr || a.pro_relu != 0;
-
-  float xv[NIT][8];
-  u32x4v wv[NW];
-  auto issue_x = [&](int c0) {
-    const bool first = c0 < a.C0;
-    const __amdgpu_buffer_rsrc_t rs = first ? rs0 : rs1;
-    const int cbase = first ? c0 : c0 - a.C0;
-    const int cn = first ? a.C0 : a.C1;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const unsigned soff = (unsigned)min(cbase + j, cn) * (unsigned)HW * 4u;
-#pragma unroll
-      for (int i = 0; i < NIT; ++i) xv[i][j] = buf_load(rs, voff[i], soff);
-    }
-  };
-  // the next input chunk: loads issued in the data phase after the chunk's first kernel row, landed two multiply phases
-  // later, when the group has left the chunk: fused affine / ReLU, bf16 split, LDS stores
-  auto stash_x = [&](int c0) {
-    if (any_pro) {
-      const bool first = c0 < a.C0;
-      const int cbase = first ? c0 : c0 - a.C0;
-      const int cmax = (first ? a.C0 : a.C1) - 1;
-      const bool relu = first ? (a.pro_relu & 1) : (a.pro_relu & 2);
-      const float* pro = first ? a.pro0 : a.pro1;
-#pragma unroll
-      for (int i = 0; i < NIT; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int cg = min(cbase + ihalf[i] * 8 + j, cmax);
-          const float sc = pro ? pro[2 * cg] : 1.f, sh = pro ? pro[2 * cg + 1] : 0.f;
-          float v = fmaf(xv[i][j], sc, sh);
-          if (relu) v = fmaxf(v, 0.f);
-          xv[i][j] = iin[i] ? v : 0.f;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-      if (ipos[i] >= 0) {
-        u32x4v t0, t1, t2;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          unsigned q0, q1, q2;
-#ifdef EXP_NOSPLIT
-          q0 = __builtin_bit_cast(unsigned, xv[i][2 * j]); q1 = __builtin_bit_cast(unsigned, xv[i][2 * j + 1]); q2 = q0 ^ q1;
-#else
-          split3_pair(xv[i][2 * j], xv[i][2 * j + 1], q0, q1, q2);
-#endif
-          t0[j] = q0;
-          t1[j] = q1;
-          t2[j] = q2;
-        }
-        if (c0 == KC && i == 0) PSTAMP(55);
-#ifdef EXP_NOXSTORE
-        asm volatile("" :: "v"(t0), "v"(t1), "v"(t2));
-#else
-        Xs[(0 * 2 + ihalf[i]) * PEP + ipos[i]] = t0;
-        Xs[(1 * 2 + ihalf[i]) * PEP + ipos[i]] = t1;
-        Xs[(2 * 2 + ihalf[i]) * PEP + ipos[i]] = t2;
-#endif
-        if (c0 == KC && i == 0) PSTAMP(56);
-      }
-    }
-  };
-  // this group's half of a weight row: LDS slots g*WH_U4 + tid + 256*it
-  unsigned wslot[NW];
-#pragma unroll
-  for (int it = 0; it < NW; ++it) {
-    const int sl = tid + 256 * it;
-    const int s = g * WH_U4 + sl;
-    const int co = s % CB, q6 = (s / CB) % 6, tl = s / (CB * 6);
-    const bool ok = sl < WH_U4 && cout0 + co < a.CoutP;
-    wslot[it] = ok ? (unsigned)(((co >> 5) * (TAPS * 6 * 32) + (tl * 6 + q6) * 32 + (co & 31)) * 16) : BUF_OOB;
-  }
-  const int nchunks = a.CinP / KC;
-  const int nrows = nchunks * KS;
-  auto issue_w = [&](int row) {                    // row = chunk*3 + ky
-    const int chunk = row / KS, ky = row - chunk * KS;
-    const unsigned base = ((unsigned)(chunk * ncb32 + cout0 / 32) * (unsigned)(TAPS * 6 * 32) + (unsigned)(ky * KS * 6 * 32)) * 16u;
-#pragma unroll
-    for (int it = 0; it < NW; ++it) wv[it] = __builtin_bit_cast(u32x4v, buf_load4(rsw, wslot[it], base));
-  };
-  auto stash_w = [&](int buf) {
-#pragma unroll
-    for (int it = 0; it < NW; ++it)
-      if (NW * 256 == WH_U4 || tid + 256 * it < WH_U4) Ws[buf * WS_U4 + g * WH_U4 + tid + 256 * it] = wv[it];
-  };
-  // one kernel row.  The six cross terms of a tap run as six groups of four independent MFMAs (one per accumulator) in
-  // conv_x3_k's order (smallest terms first); a fragment is re-read for tap tl+1 right behind the group that used it last, so
-  // every ds_read has MFMA groups (128 cycles each) to land behind.  The weight terms 0 and 1, needed by the first two groups of
-  // the next tap and used until the last two of this one, alternate between two register sets.
-  auto mfma_row = [&](int ky, int buf) {
-    const u32x4v* Wb = Ws + buf * WS_U4;
-    bf16x8 a01[2][MT][2], a2[MT], bfr[NT][3];
-    auto rd_a = [&](int tl, int t) {
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const bf16x8 v = __builtin_bit_cast(bf16x8, Wb[((tl * 6) + t * 2 + h) * CB + mt * 32 + r32]);
-        if (t == 2) a2[mt] = v; else a01[tl & 1][mt][t] = v;
-      }
-    };
-    auto rd_b = [&](int tl, int t) {
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) bfr[nt][t] = __builtin_bit_cast(bf16x8, Xs[(t * 2 + h) * PEP + off[nt] + ky * PITCH + tl]);
-    };
-    auto mm = [&](int tl, int ta, int tb) {
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma_bf16(ta == 2 ? a2[mt] : a01[tl & 1][mt][ta], bfr[nt][tb], acc[mt][nt]);
-    };
-#ifdef EXP_NOMFMA
-    return;
-#endif
-    rd_a(0, 0); rd_b(0, 2); rd_a(0, 1); rd_b(0, 1); rd_a(0, 2); rd_b(0, 0);
-#pragma unroll
-    for (int tl = 0; tl < KS; ++tl) {
-      const bool nx = tl + 1 < KS;
-      __builtin_amdgcn_sched_barrier(0);
-      mm(tl, 0, 2);
-      if (nx) { rd_b(tl + 1, 2); rd_a(tl + 1, 0); }
-      __builtin_amdgcn_sched_barrier(0);
-      mm(tl, 1, 1);
-      if (nx) rd_a(tl + 1, 1);
-      __builtin_amdgcn_sched_barrier(0);
-      mm(tl, 2, 0);
-      if (nx) rd_a(tl + 1, 2);
-      __builtin_amdgcn_sched_barrier(0);
-      mm(tl, 0, 1);
-      if (nx) rd_b(tl + 1, 1);
-      __builtin_amdgcn_sched_barrier(0);
-      mm(tl, 1, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      mm(tl, 0, 0);
-      if (nx) rd_b(tl + 1, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-  // data phase of a group that has finished row jd (jd = -1: nothing yet): the other group is multiplying.
-  //   A (phase 2jd+1) stores its half of row jd+1 and loads its half of row jd+2;
-  //   B (phase 2jd+2) stores its half of row jd+2 and loads its half of row jd+3.
-  auto data_phase = [&](int jd, int buf_next) {
-#ifdef EXP_NODATA
-    return;
-#endif
-    __builtin_amdgcn_s_setprio(3);                 // its few VALU / LDS / VMEM instructions go ahead of the other group's MFMA stream
-    const int wrow = jd + 1 + g;                   // the weight row whose half is in wv
-    if (jd == 2) PSTAMP(52);
-    if (wrow < nrows) stash_w(buf_next);
-    if (jd == 2) PSTAMP(53);
-    const int kyd = (jd + KS) % KS;                // kernel row just finished (jd = -1 -> 2: "left chunk -1")
-    const int cnext = (jd + 1) / KS;               // chunk of row jd+1
-    if (kyd == KS - 1 && cnext < nchunks) stash_x(cnext * KC);
-    __builtin_amdgcn_sched_barrier(0);
-    if (jd == 2) PSTAMP(54);
-    if (wrow + 1 < nrows) issue_w(wrow + 1);
-#ifndef EXP_NOXLOAD
-    if (kyd == 0 && cnext + 1 < nchunks) issue_x((cnext + 1) * KC);
-#endif
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(0);
-  };
-
-  // prologue: both halves of weight row 0, group A's first input chunk (group B stores its own in phase 0)
-  PSTAMP(0);
-  PSTAMPV(1, (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32));
-  issue_w(0);
-  issue_x(0);
-  stash_w(0);
-  issue_w(1);                                      // stored by the group's first data phase (A: phase 1, B: phase 0)
-  if (g == 0) stash_x(0);                          // B: in phase 0
-  __syncthreads();
-  PSTAMP(2);
-
-  // Each group runs its own loop (the role is wave-uniform; every wave of the workgroup meets the same number of barriers):
-  // sharing one loop body between the roles makes the register allocator merge the two roles' live ranges — copies and
-  // vmcnt(0) waits on the prefetched loads at every phase boundary.
-  int buf = 0;
-  if (g == 0) {
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-#pragma unroll
-      for (int ky = 0; ky < KS; ++ky) {
-        const int j = chunk * KS + ky;
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_row(ky, buf);                 // phase 2j
-        __builtin_amdgcn_sched_barrier(0);
-        PSTAMP(3 + 4 * j);
-        PP_SYNC();
-        PSTAMP(4 + 4 * j);
-        data_phase(j, buf ^ 1);            // phase 2j+1
-        PSTAMP(5 + 4 * j);
-        PP_SYNC();
-        PSTAMP(6 + 4 * j);
-        buf ^= 1;
-      }
-    }
-  } else {
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-#pragma unroll
-      for (int ky = 0; ky < KS; ++ky) {
-        const int j = chunk * KS + ky;
-        data_phase(j - 1, buf ^ 1);        // phase 2j
-        PSTAMP(3 + 4 * j);
-        PP_SYNC();
-        PSTAMP(4 + 4 * j);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_row(ky, buf);                 // phase 2j+1
-        __builtin_amdgcn_sched_barrier(0);
-        PSTAMP(5 + 4 * j);
-        PP_SYNC();
-        PSTAMP(6 + 4 * j);
-        buf ^= 1;
-      }
-    }
-  }
-  PSTAMP(60);
-  x3_epilogue<MT, NT, TWL, MASK, false>(a, acc, b, ty, tx, cout0, tid, red, bias_s, tile, live);
-  PSTAMP(61);
-  PSTAMPV(62, (unsigned long long)nrows);
-  PSTAMP_DUMP;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -796,24 +495,10 @@ static bool x3_small_tiles(int B, int H, int W, int CoutP, bool mt2) {
   return B * ceil_div(H, 16) * ceil_div(W, 16) * (CoutP / 32) < 512;
 }
 
-static bool x3_pingpong() {                      // WTPSE_X3_PP=0: the two-workgroups-per-CU kernel everywhere (comparison runs)
-  const char* e = getenv("WTPSE_X3_PP");
-  return !(e && e[0] == '0');
-}
-
 template <int KS, int MT, bool MASK>
 static int launch_x3(const ConvX3Args& a, hipStream_t st) {
   ConvX3Args args = a;
   const bool narrow = a.W <= 16;
-  if constexpr (KS == 3 && MT == 2) {
-    if (!narrow && x3_pingpong()) {                // (16-wide maps reach the 64-cout tiling only at batch sizes >= 128)
-      args.tiles_x = ceil_div(a.W, 32);
-      args.tiles_y = ceil_div(a.H, 8);
-      dim3 grid((unsigned)ceil_div(a.B * args.tiles_x * args.tiles_y, 2), (unsigned)(a.CoutP / 64));
-      hipLaunchKernelGGL((conv_x3_pp_k<5, MASK>), grid, dim3(512), 0, st, args);
-      return wtpse_status();
-    }
-  }
   const bool small = MT == 1 && x3_small_tiles(a.B, a.H, a.W, a.CoutP, false);
   const int TW = narrow ? 16 : 32, TH = (small ? 128 : 256) / TW;
   args.tiles_x = ceil_div(a.W, TW);
