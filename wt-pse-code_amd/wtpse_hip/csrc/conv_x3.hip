@@ -606,6 +606,17 @@ constexpr int pad_plane(int n) {   // smallest m >= n with m % 16 in {4, 12}
     if (m % 16 == 4 || m % 16 == 12) return m;
 }
 
+// (ablation hooks of tools/probe/wgrad_abl.py: defined in probe builds only)
+#ifdef EXP_W_NOSPLIT
+#define WSPLIT(a, b, q0, q1, q2) do { q0 = __builtin_bit_cast(unsigned, a); q1 = __builtin_bit_cast(unsigned, b); q2 = q0 ^ q1; } while (0)
+#else
+#define WSPLIT(a, b, q0, q1, q2) split3_pair(a, b, q0, q1, q2)
+#endif
+#ifdef EXP_W_NOSTORE
+#define WSTORE(dst, v) asm volatile("" :: "v"(v))
+#else
+#define WSTORE(dst, v) dst = v
+#endif
 template <int KS, int TWL, bool Q>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_k(WgradX3Args a) {
   constexpr int TAPS = KS * KS, PAD = KS / 2;
@@ -679,8 +690,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_k(WgradX3Args a) {
       const __amdgpu_buffer_rsrc_t rs = first ? rsx0 : rsx1;
       cb = first ? c : c - a.C0;
       cn = first ? a.C0 : a.C1;
+#ifdef EXP_W_NOXLOAD
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = __builtin_bit_cast(float, vo + j);
+#else
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = buf_load(rs, vo, (unsigned)min(cb + j, cn) * (unsigned)HW * 4u);
+#endif
     };
     auto x_finish = [&](float (&v)[8], int cg, int pos, bool in, bool first, int cb, int cn) {
       if (any_pro) {
@@ -700,12 +716,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_k(WgradX3Args a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           unsigned q0, q1, q2;
-          split3_pair(v[2 * j], v[2 * j + 1], q0, q1, q2);
+          WSPLIT(v[2 * j], v[2 * j + 1], q0, q1, q2);
           t0[j] = q0; t1[j] = q1; t2[j] = q2;
         }
-        Xs[(0 * NCG + cg) * XP + pos] = t0;
-        Xs[(1 * NCG + cg) * XP + pos] = t1;
-        Xs[(2 * NCG + cg) * XP + pos] = t2;
+        WSTORE(Xs[(0 * NCG + cg) * XP + pos], t0);
+        WSTORE(Xs[(1 * NCG + cg) * XP + pos], t1);
+        WSTORE(Xs[(2 * NCG + cg) * XP + pos], t2);
       }
     };
 #pragma unroll
@@ -729,18 +745,23 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_k(WgradX3Args a) {
       const unsigned vo = (gy < a.H && gx < a.W) ? (unsigned)(gy * a.W + gx) * 4u : BUF_OOB;
       const int c = cout0 + cg * 8;
       float v[8];
+#ifdef EXP_W_NOYLOAD
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = __builtin_bit_cast(float, vo + j);
+#else
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = buf_load(rsy, vo, (unsigned)min(c + j, a.Cout) * (unsigned)HW * 4u);
+#endif
       u32x4v t0, t1, t2;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         unsigned q0, q1, q2;
-        split3_pair(v[2 * j], v[2 * j + 1], q0, q1, q2);
+        WSPLIT(v[2 * j], v[2 * j + 1], q0, q1, q2);
         t0[j] = q0; t1[j] = q1; t2[j] = q2;
       }
-      Ys[(0 * NCG + cg) * YP + px] = t0;
-      Ys[(1 * NCG + cg) * YP + px] = t1;
-      Ys[(2 * NCG + cg) * YP + px] = t2;
+      WSTORE(Ys[(0 * NCG + cg) * YP + px], t0);
+      WSTORE(Ys[(1 * NCG + cg) * YP + px], t1);
+      WSTORE(Ys[(2 * NCG + cg) * YP + px], t2);
     }
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
@@ -773,6 +794,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_k(WgradX3Args a) {
         if (tap == TAPS - 1) load_a(s + 1, af[acur ^ 1]);
       }
       __builtin_amdgcn_sched_barrier(0);
+#ifdef EXP_W_NOMFMA
+      continue;
+#endif
       f32x16 c = acc[tap];
       c = mfma_bf16(af[acur][0], bfr[cur][2], c);
       c = mfma_bf16(af[acur][1], bfr[cur][1], c);
