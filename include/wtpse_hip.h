@@ -58,15 +58,6 @@ int wtpse_conv_fwd_x3(const float* in0, int C0, const float* in1, int C1, const 
                       const float* pro0, const float* pro1, int pro_relu, float* out0, float* out1, int Csplit, float* stats,
                       int B, int H, int W, int Cout, int ksize, int relu_out, const float* mask_ref, void* stream);
 
-/* An operand split ONCE per tensor: x [B][C][HW] fp32 -> [B][C/8][term 3][HW][8 ch] bf16 (C % 8 == 0; 6 bytes per element),
- * the three 16-byte LDS rows the x3 loaders form per (position, 8-channel group).  wtpse_conv_fwd_x3_pre is
- * wtpse_conv_fwd_x3 (3x3, one input, no prologue: the data gradient's dY, C0 % 16 == 0) on such a tensor: its loader only
- * copies rows; results are bit-identical.  Reference op: the nn.Conv2d data gradient (autograd of algorithms.py:882-888). */
-int wtpse_split3_pack(const float* x, unsigned short* out, int B, int C, int HW, void* stream);
-int wtpse_conv_fwd_x3_pre(const unsigned short* in_split, int C0, const unsigned short* wpacked, const float* bias, float* out0,
-                          float* out1, int Csplit, float* stats, int B, int H, int W, int Cout, int relu_out,
-                          const float* mask_ref, void* stream);
-
 /* dW[Cout][C0+C1][k][k] (+)= sum dY * X, dbias (+)= sum dY (dbias/dbias_slab NULL: skip).  slab: [ksplit][Cout*Cin*k*k],
  * dbias_slab: [ksplit][Cout], ksplit = wtpse_wgrad_ksplit(...).  x inputs take the same prologue as the forward. */
 int wtpse_conv_wgrad(const float* dy, const float* x0, int C0, const float* x1, int C1, const float* pro0,

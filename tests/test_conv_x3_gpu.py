@@ -147,28 +147,3 @@ def test_conv_x3_wgrad(case):
     assert e3 <= 2.0 * e32 + 2e-8, (e3, e32)
     o.conv_wgrad_x3(*args, dw, accumulate=True, **kw)
     close(dw, 2 * ref64, rtol=2e-4, atol=4e-5 * max(scale, 1.0), what="wgrad x3 accumulate")
-
-
-@pytest.mark.parametrize("case", [(2, 32, 0, 32, 16, 16), (1, 64, 64, 128, 16, 16), (2, 32, 32, 64, 24, 48), (20, 32, 32, 64, 32, 64),
-                                  (3, 48, 0, 96, 12, 20), (2, 64, 0, 64, 40, 72)])
-def test_conv_x3_presplit_bit_identical(case):
-    """The data gradient on a dY that was split once per tensor (wtpse_split3_pack -> wtpse_conv_fwd_x3_pre: the loader copies
-    16-byte rows instead of loading, splitting and packing elements) feeds the MFMAs the same bf16 triples: outputs, split
-    outputs and ReLU-masked outputs equal the split-on-load kernel's bit for bit."""
-    o = ops()
-    B, C0, C1, Co, H, W = case
-    w = rnd(Co, C0 + C1, 3, 3, seed=51, scale=0.2)
-    dy = rnd(B, Co, H, W, seed=52).to(DEV)
-    mref = rnd(B, C0 + C1, H, W, seed=53).to(DEV)
-    packed, _, xd = pack_x3(w)
-    wp = packed.data_ptr() + 2 * xd
-    dys = o.split3_pack(dy)
-    a0, a1, _ = o.conv_fwd_x3(dy, None, wp, None, C0 + C1, 3, split=(C0 if C1 else None))
-    b0, b1, _ = o.conv_fwd_x3_pre(dys, (H, W), wp, None, C0 + C1, split=(C0 if C1 else None))
-    assert torch.equal(a0, b0) and (a1 is None or torch.equal(a1, b1))
-    am = o.conv_fwd_x3(dy, None, wp, None, C0 + C1, 3, mask_ref=mref)[0]
-    bm = o.conv_fwd_x3_pre(dys, (H, W), wp, None, C0 + C1, mask_ref=mref)[0]
-    assert torch.equal(am, bm)
-    a_s = o.conv_fwd_x3(dy, None, wp, None, C0 + C1, 3, want_stats=True)
-    b_s = o.conv_fwd_x3_pre(dys, (H, W), wp, None, C0 + C1, want_stats=True)
-    assert torch.equal(a_s[0], b_s[0]) and torch.equal(a_s[2], b_s[2])

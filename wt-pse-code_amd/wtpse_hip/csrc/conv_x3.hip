@@ -206,10 +206,7 @@ __device__ __forceinline__ void x3_epilogue(const ConvX3Args& a, f32x16 (&acc)[M
 
 // NT = 32-pixel column tiles per wave: 2 (256-pixel workgroup tile) or 1 (128 pixels: twice the workgroups for the 16x16
 // maps, whose 256-pixel tiles would leave one workgroup per CU with nothing to overlap its loader phases with)
-// PRE: `in0` holds the input ALREADY split (wtpse_split3_pack: [B][C/8][term 3][H*W][8 ch] bf16 — the LDS image row by row):
-// the loader's items are 64-position blocks of one (term, k-half) plane, one 16-byte load and one 16-byte LDS store each,
-// no VALU (no concat, no prologue: the data gradients' dY).
-template <int KS, int MT, int TWL, bool MASK, int NT = 2, bool PRE = false>
+template <int KS, int MT, int TWL, bool MASK, int NT = 2>
 __global__ __launch_bounds__(256, 2) void conv_x3_k(ConvX3Args a) {
   constexpr int TAPS = KS * KS, PAD = KS / 2;
   constexpr int TW = 1 << TWL, TH = (128 * NT) / TW;
@@ -266,25 +263,6 @@ __global__ __launch_bounds__(256, 2) void conv_x3_k(ConvX3Args a) {
     voff[i] = iin[i] ? (unsigned)(gy * a.W + gx) * 4u + (unsigned)ihalf[i] * 8u * (unsigned)HW * 4u : BUF_OOB;
   }
 
-  constexpr int NITP = PRE ? (6 * PB + 3) / 4 : 1;
-  int ppos[NITP], pplane[NITP];
-  unsigned pvoff[NITP];
-  if constexpr (PRE) {
-#pragma unroll
-    for (int i = 0; i < NITP; ++i) {
-      const int blk = __builtin_amdgcn_readfirstlane(i * 4 + wave);
-      const int q = min(blk / PB, 5);               // LDS plane: term * 2 + k-half
-      const int p = (blk - (blk / PB) * PB) * 64 + lane;
-      const bool valid = blk < 6 * PB && p < PE;
-      const int r = p / PITCH, x = p - r * PITCH;
-      const int gy = ty * TH + r - PAD, gx = tx * TW + x - PAD;
-      const bool in = valid && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-      ppos[i] = valid ? q * PEP + p : -1;
-      pplane[i] = (q & 1) * 3 + (q >> 1);           // split-tensor plane relative to the chunk's first channel group
-      pvoff[i] = in ? (unsigned)(gy * a.W + gx) * 16u : BUF_OOB;
-    }
-  }
-
   f32x16 acc[MT][NT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
@@ -293,9 +271,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_k(ConvX3Args a) {
 #pragma unroll
       for (int r = 0; r < NACC; ++r) acc[mt][nt][r] = 0.f;
 
-  const __amdgpu_buffer_rsrc_t rs0 = PRE ? make_rsrc(reinterpret_cast<const unsigned short*>(a.in0) + (size_t)b * (a.C0 / 8) * 3 * HW * 8,
-                                                     (unsigned)(a.C0 / 8) * 3u * (unsigned)HW * 16u)
-                                         : make_rsrc(a.in0 + (size_t)b * a.C0 * HW, (unsigned)a.C0 * HW * 4u);
+  const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(a.in0 + (size_t)b * a.C0 * HW, (unsigned)a.C0 * HW * 4u);
   const __amdgpu_buffer_rsrc_t rs1 = a.in1 ? make_rsrc(a.in1 + (size_t)b * a.C1 * HW, (unsigned)a.C1 * HW * 4u) : rs0;
   // packed weights: [chunk][cout block of 32][tap][term][half][32][8] bf16 = 16-byte slots [chunk][cb][tap][term*2+half][32]
   const int ncb32 = a.CoutP / 32;
@@ -307,35 +283,23 @@ __global__ __launch_bounds__(256, 2) void conv_x3_k(ConvX3Args a) {
   // loads of the next row's weights — and, on a chunk's last row, of the next chunk's input tile — are issued before the
   // row's MFMAs and land in registers behind them; the weights go to the other half of a double-buffered LDS slab right
   // after the MFMAs (one barrier per row), the input tile is split and stored once every wave has left the chunk.
-  float xv[PRE ? 1 : NIT][8];
-  u32x4v xq[NITP];
+  float xv[NIT][8];
   u32x4v wv[NW];
   auto issue_x = [&](int c0) {
-    if constexpr (PRE) {
+    const bool first = c0 < a.C0;
+    const __amdgpu_buffer_rsrc_t rs = first ? rs0 : rs1;
+    const int cbase = first ? c0 : c0 - a.C0;
+    const int cn = first ? a.C0 : a.C1;
 #pragma unroll
-      for (int i = 0; i < NITP; ++i)
-        xq[i] = __builtin_bit_cast(u32x4v, buf_load4(rs0, pvoff[i], (unsigned)((c0 / 8) * 3 + pplane[i]) * (unsigned)HW * 16u));
-    } else {
-      const bool first = c0 < a.C0;
-      const __amdgpu_buffer_rsrc_t rs = first ? rs0 : rs1;
-      const int cbase = first ? c0 : c0 - a.C0;
-      const int cn = first ? a.C0 : a.C1;
+    for (int j = 0; j < 8; ++j) {
+      // channels past the end of the tensor are out of the buffer's range and read as zero (their packed weight rows are
+      // zero too); min() keeps the scalar offset <= num_records so that the range check cannot wrap
+      const unsigned soff = (unsigned)min(cbase + j, cn) * (unsigned)HW * 4u;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        // channels past the end of the tensor are out of the buffer's range and read as zero (their packed weight rows are
-        // zero too); min() keeps the scalar offset <= num_records so that the range check cannot wrap
-        const unsigned soff = (unsigned)min(cbase + j, cn) * (unsigned)HW * 4u;
-#pragma unroll
-        for (int i = 0; i < NIT; ++i) xv[i][j] = buf_load(rs, voff[i], soff);
-      }
+      for (int i = 0; i < NIT; ++i) xv[i][j] = buf_load(rs, voff[i], soff);
     }
   };
   auto stash_x = [&](int c0) {
-    if constexpr (PRE) {
-#pragma unroll
-      for (int i = 0; i < NITP; ++i)
-        if (ppos[i] >= 0) Xs[ppos[i]] = xq[i];
-    } else {
     if (any_pro) {   // zero padding applies AFTER the fused affine/ReLU, as in the reference graph
       const bool first = c0 < a.C0;
       const int cbase = first ? c0 : c0 - a.C0;
@@ -370,7 +334,6 @@ __global__ __launch_bounds__(256, 2) void conv_x3_k(ConvX3Args a) {
         Xs[(2 * 2 + ihalf[i]) * PEP + ipos[i]] = t2;
       }
     }
-  }
   };
   // one kernel row of weights: LDS slot s = ((tl*6 + q) * CB + co), tl = tap within the row, q = term*2 + half
   unsigned wslot[NW];
@@ -532,7 +495,7 @@ static bool x3_small_tiles(int B, int H, int W, int CoutP, bool mt2) {
   return B * ceil_div(H, 16) * ceil_div(W, 16) * (CoutP / 32) < 512;
 }
 
-template <int KS, int MT, bool MASK, bool PRE = false>
+template <int KS, int MT, bool MASK>
 static int launch_x3(const ConvX3Args& a, hipStream_t st) {
   ConvX3Args args = a;
   const bool narrow = a.W <= 16;
@@ -542,11 +505,11 @@ static int launch_x3(const ConvX3Args& a, hipStream_t st) {
   args.tiles_y = ceil_div(a.H, TH);
   dim3 grid((unsigned)(a.B * args.tiles_x * args.tiles_y), (unsigned)ceil_div(a.CoutP, 32 * MT));
   if (small) {
-    if constexpr (MT == 1) hipLaunchKernelGGL((conv_x3_k<KS, 1, 4, MASK, 1, PRE>), grid, dim3(256), 0, st, args);
+    if constexpr (MT == 1) hipLaunchKernelGGL((conv_x3_k<KS, 1, 4, MASK, 1>), grid, dim3(256), 0, st, args);
   } else if (narrow)
-    hipLaunchKernelGGL((conv_x3_k<KS, MT, 4, MASK, 2, PRE>), grid, dim3(256), 0, st, args);
+    hipLaunchKernelGGL((conv_x3_k<KS, MT, 4, MASK>), grid, dim3(256), 0, st, args);
   else
-    hipLaunchKernelGGL((conv_x3_k<KS, MT, 5, MASK, 2, PRE>), grid, dim3(256), 0, st, args);
+    hipLaunchKernelGGL((conv_x3_k<KS, MT, 5, MASK>), grid, dim3(256), 0, st, args);
   return wtpse_status();
 }
 
@@ -596,61 +559,6 @@ extern "C" int wtpse_conv_fwd_x3(const float* in0, int C0, const float* in1, int
   if (ksize == 3) return mt2 ? X3(3, 2) : X3(3, 1);
   return mt2 ? X3(1, 2) : X3(1, 1);
 #undef X3
-}
-
-// ---- operands split once per tensor -----------------------------------------------------------------------------
-// x [B][C][HW] fp32 -> [B][C/8][term 3][HW][8 ch] bf16: exactly the three 16-byte LDS rows the loaders above form per
-// (position, 8-channel group), so that a consumer only copies them.  C % 8 == 0.
-__global__ __launch_bounds__(256) void split3_pack_k(const float* __restrict__ x, u32x4v* __restrict__ out, int C, int HW) {
-  const int p = blockIdx.x * 256 + threadIdx.x;
-  const int cg = blockIdx.y, b = blockIdx.z;
-  if (p >= HW) return;
-  const float* src = x + ((size_t)b * C + cg * 8) * HW + p;
-  float v[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) v[j] = src[(size_t)j * HW];
-  u32x4v t0, t1, t2;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    unsigned q0, q1, q2;
-    split3_pair(v[2 * j], v[2 * j + 1], q0, q1, q2);
-    t0[j] = q0; t1[j] = q1; t2[j] = q2;
-  }
-  u32x4v* dst = out + ((size_t)b * (C / 8) + cg) * 3 * HW + p;
-  dst[0] = t0;
-  dst[(size_t)HW] = t1;
-  dst[(size_t)2 * HW] = t2;
-}
-
-extern "C" int wtpse_split3_pack(const float* x, unsigned short* out, int B, int C, int HW, void* stream) {
-  WTPSE_REQUIRE(x && out && B > 0 && C > 0 && C % 8 == 0 && HW > 0);
-  hipLaunchKernelGGL(split3_pack_k, dim3((unsigned)ceil_div(HW, 256), (unsigned)(C / 8), (unsigned)B), dim3(256), 0, (hipStream_t)stream, x,
-                     reinterpret_cast<u32x4v*>(out), C, HW);
-  return wtpse_status();
-}
-
-// wtpse_conv_fwd_x3 on an input in the wtpse_split3_pack layout (3x3, one input tensor, no prologue: the data gradient's dY).
-// C0 % 16 == 0.  Results are bit-identical to wtpse_conv_fwd_x3 on the fp32 tensor.
-extern "C" int wtpse_conv_fwd_x3_pre(const unsigned short* in_split, int C0, const unsigned short* wpacked, const float* bias,
-                                     float* out0, float* out1, int Csplit, float* stats, int B, int H, int W, int Cout,
-                                     int relu_out, const float* mask_ref, void* stream) {
-  WTPSE_REQUIRE(in_split && wpacked && out0 && B > 0 && H > 0 && W > 0 && C0 > 0 && C0 % 16 == 0 && Cout > 0);
-  WTPSE_REQUIRE(Csplit > 0 && Csplit <= Cout && ((Csplit == Cout) == (out1 == nullptr)));
-  WTPSE_REQUIRE(Csplit == Cout || Csplit % 16 == 0);
-  WTPSE_REQUIRE(!(stats && relu_out));
-  WTPSE_REQUIRE(!(stats && mask_ref));
-  WTPSE_REQUIRE(!(mask_ref && out1));
-  ConvX3Args a;
-  a.in0 = reinterpret_cast<const float*>(in_split); a.in1 = nullptr; a.wx = wpacked; a.bias = bias; a.pro0 = nullptr; a.pro1 = nullptr;
-  a.out0 = out0; a.out1 = out1; a.stats = stats; a.mask = mask_ref;
-  a.B = B; a.H = H; a.W = W; a.C0 = C0; a.C1 = 0; a.Cin = C0; a.CinP = C0;
-  a.Cout = Cout; a.CoutP = (Cout + 31) & ~31; a.Csplit = Csplit; a.pro_relu = 0; a.relu_out = relu_out;
-  a.tiles_x = a.tiles_y = 0;
-  hipStream_t st = (hipStream_t)stream;
-  const bool mt2 = x3_mt2(B, H, W, a.CoutP);
-#define X3P(M) (mask_ref ? launch_x3<3, M, true, true>(a, st) : launch_x3<3, M, false, true>(a, st))
-  return mt2 ? X3P(2) : X3P(1);
-#undef X3P
 }
 
 // ================================================================================================

@@ -109,35 +109,6 @@ def conv_fwd_x3(in0, in1, wpacked_ptr, bias, cout, ksize, pro0=None, pro_relu=0,
     return out0, out1, stats
 
 
-def split3_pack(x):
-    """[B,C,H,W] fp32 -> int16 [B, C/8, 3, H*W, 8]: bf16 triples in the x3 loaders' row order (wtpse_split3_pack)."""
-    _chk(x, "x")
-    B, C, H, W = x.shape
-    out = torch.empty((B, C // 8, 3, H * W, 8), dtype=torch.int16, device=x.device)
-    lib().call("wtpse_split3_pack", ptr(x), ptr(out), B, C, H * W, stream_ptr())
-    return out
-
-
-def conv_fwd_x3_pre(in_split, hw, wpacked_ptr, bias, cout, relu_out=False, want_stats=False, split=None, mask_ref=None):
-    """conv_fwd_x3 (3x3) on a split3_pack'ed input; hw = (H, W)."""
-    B, cg = in_split.shape[0], in_split.shape[1]
-    H, W = hw
-    L = lib()
-    dev = in_split.device
-    if split is None:
-        out0, out1, csplit = torch.empty((B, cout, H, W), dtype=torch.float32, device=dev), None, cout
-    else:
-        csplit = int(split)
-        out0 = torch.empty((B, csplit, H, W), dtype=torch.float32, device=dev)
-        out1 = torch.empty((B, cout - csplit, H, W), dtype=torch.float32, device=dev)
-    stats = None
-    if want_stats:
-        stats = torch.empty((L.query("wtpse_conv_x3_stats_blocks", B, H, W, cout), cout, 2), dtype=torch.float32, device=dev)
-    L.call("wtpse_conv_fwd_x3_pre", ptr(in_split), cg * 8, wpacked_ptr, ptr(bias), ptr(out0), ptr(out1), csplit, ptr(stats), B, H, W,
-           cout, int(relu_out), ptr(mask_ref), stream_ptr())
-    return out0, out1, stats
-
-
 def conv_wgrad(dy, x0, x1, ksize, dw, dbias, pro0=None, pro_relu=0, accumulate=False, pro1=None):
     """dw / dbias are views into the flat gradient buffer ([Cout,Cin,k,k] / [Cout] or None)."""
     _chk(dy, "dy"); _chk(x0, "x0"); _chk(x1, "x1")
