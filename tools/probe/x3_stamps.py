@@ -56,9 +56,15 @@ def main():
     nwg = tiles * ((cout + 32 * mt - 1) // (32 * mt))
     stamps = torch.zeros(nwg * 64, dtype=torch.int64, device=dev)
 
+    want_stats, want_pro = os.environ.get("STATS", "0") != "0", os.environ.get("PRO", "0") != "0"     # as the forward pass runs it
+    nrows = dll.wtpse_conv_x3_stats_blocks(B, hw, hw, cout)
+    stats_t = torch.zeros(nrows * cout * 2, device=dev) if want_stats else None
+    pro_t = torch.stack([torch.rand(cin, device=dev) + 0.5, torch.randn(cin, device=dev) * 0.1], 1).contiguous() if want_pro else None
+
     def run():
-        return dll.wtpse_conv_fwd_x3(vp(x.data_ptr()), cin, None, 0, vp(packed.data_ptr()), None, None, None, 0, vp(y.data_ptr()),
-                                     None, cout, None, B, hw, hw, cout, 3, 0, None, None)
+        return dll.wtpse_conv_fwd_x3(vp(x.data_ptr()), cin, None, 0, vp(packed.data_ptr()), None, vp(pro_t.data_ptr()) if want_pro else None,
+                                     None, 1 if want_pro else 0, vp(y.data_ptr()), None, cout, vp(stats_t.data_ptr()) if want_stats else None,
+                                     B, hw, hw, cout, 3, 0, None, None)
     for _ in range(3):
         assert run() == 0
     torch.cuda.synchronize()
@@ -72,7 +78,7 @@ def main():
     us = e0.elapsed_time(e1) * 1e3 / nrep
     print("%s operands, %d back-to-back launches: %.1f us, %.1f TFLOP/s fp32-equivalent = %.0f TFLOP/s of bf16 MFMA  [%s]" % (
         "zero" if zeros else "random", nrep, us, 2.0 * B * hw * hw * cin * cout * 9 / us * 1e-6,
-        12.0 * B * hw * hw * cin * cout * 9 / us * 1e-6, os.environ.get("PROBE_DEFS", "")))
+        12.0 * B * hw * hw * cin * cout * 9 / us * 1e-6, os.environ.get("PROBE_DEFS", "") + (" +stats" if want_stats else "") + (" +prologue" if want_pro else "")))
     if not STAMPS:
         return
     assert dll.wtpse_probe_set_stamps_x3(vp(stamps.data_ptr())) == 0
