@@ -196,9 +196,12 @@ def test_batchnorm_train_offset_input(offset, amp):
     """Train-mode statistics are folded from per-tile (sum, sum of squares) partials that the conv epilogue rounds to fp32; the
     variance E[y^2] - mean^2 loses digits when |mean| >> std.  The inputs that could do that here are the near-constant ones —
     the all -1 ROI image of an empty disc prediction (Trainer.py:842-853), offset images — but a zero-padded 3x3 conv of a
-    constant map has borders: |mean| / std of its output stays near 5, and the normalised output stays within 2e-5 of the fp64
-    result (measured <= 9e-6 at amp = 0; stock fp32 BatchNorm on the host: 1e-6), far inside the path's 1e-4
-    (tools/probe/bn_offset.py prints the table)."""
+    constant map has borders: |mean| / std of its output stays near 5, and the normalised output stays within 5e-5 of the fp64
+    result (tools/probe/bn_offset.py prints the table): 1-2e-6 as soon as the input carries any noise, 0.9-2.5e-5 for an EXACTLY
+    constant input — every interior tile then holds the same values and rounds its 256-element sums the same way, so the
+    partials' fp32 rounding (~1e-6 of E[y^2]) does not average out over the tiles and is multiplied by mean^2/var = 28.  Stock
+    fp32 BatchNorm on the host: 1e-6.  Inside the path's 1e-4; the fix if it ever matters is a per-channel pivot (the previous
+    step's batch mean) subtracted before the epilogue accumulates."""
     o = ops()
     B, C, H, W = 8, 32, 64, 64
     xin = offset + amp * rnd(B, 16, H, W, seed=41)
@@ -213,7 +216,7 @@ def test_batchnorm_train_offset_input(offset, amp):
                                      torch.zeros(C, device=DEV), torch.ones(C, device=DEV), nbt)
     z = o.affine_act(y, ss, False).cpu().double()
     err = float((z - z64).abs().max() / z64.abs().max())
-    assert err <= 2e-5, err
+    assert err <= (5e-5 if amp == 0.0 else 1e-5), err
     close(mean, y64.mean((0, 2, 3)).float(), rtol=1e-5, atol=1e-6, what="batch mean")
 
 
