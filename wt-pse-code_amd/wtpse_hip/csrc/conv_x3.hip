@@ -848,9 +848,19 @@ extern "C" int wtpse_wgrad_x3_supported(int Cin, int Cout, int ksize, int C0) {
   return ksize == 3 && Cin >= 32 && Cout >= 32 && Cin % 32 == 0 && Cout % 32 == 0 && C0 % 8 == 0;
 }
 
+// Pixel tiles of the weight gradient are 16 wide (16x4 / 16x8) on every map: the halo tile of X is then 18x6 = 108 (18x10 = 180)
+// positions instead of the 34x4 = 136 (34x6 = 204) of a 32-wide tile — a fifth less to load, split and store in a kernel that
+// waits for exactly that (layer set 2022 -> 1864 us; the forward kernel prefers 32x8: its 16x16 form measured 6-8 % slower).
+// WTPSE_X3_WGRAD_TW32=1 restores the 32-wide tiles on maps wider than 16 (comparison runs).
+static bool wgrad_x3_tw16(int W) {
+  if (W <= 16) return true;
+  const char* e = getenv("WTPSE_X3_WGRAD_TW32");
+  return !(e && e[0] == '1');
+}
+
 extern "C" int wtpse_wgrad_x3_ksplit(int B, int H, int W, int Cin, int Cout) {
   const bool q = wgrad_x3_quadrants(Cin, Cout);
-  const int TW = W <= 16 ? 16 : 32, TH = (q ? 64 : 128) / TW;
+  const int TW = wgrad_x3_tw16(W) ? 16 : 32, TH = (q ? 64 : 128) / TW;
   const int ntiles = B * ceil_div(W, TW) * ceil_div(H, TH);
   const int blk = q ? 64 : 32;
   const int nx = (Cout / blk) * (Cin / blk);
@@ -876,7 +886,7 @@ extern "C" int wtpse_conv_wgrad_x3(const float* dy, const float* x0, int C0, con
   WgradX3Args a;
   a.dy = dy; a.x0 = x0; a.x1 = x1; a.pro0 = pro0; a.pro1 = pro1; a.slab = slab;
   a.B = B; a.H = H; a.W = W; a.C0 = C0; a.C1 = C1; a.Cin = Cin; a.Cout = Cout; a.pro_relu = pro_relu;
-  const bool narrow = W <= 16;
+  const bool narrow = wgrad_x3_tw16(W);
   const int TW = narrow ? 16 : 32, TH = (q ? 64 : 128) / TW;
   a.tiles_x = ceil_div(W, TW);
   a.tiles_y = ceil_div(H, TH);
