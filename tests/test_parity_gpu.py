@@ -92,13 +92,23 @@ def oracle_grads(fn, sds, dtype):
     return [{k: sd[k].grad.double() for k in sd if not O.is_buffer(k) and sd[k].grad is not None} for sd in cast]
 
 
-def assert_calibrated(module, g32, g64, what):
+CAL = 3.0      # the HIP path may be at most this many times as far from the fp64 evaluation as the reference's own fp32 CPU path
+CAL_KINK = 10.0  # ... on the 32x32 / 64x64 fixtures at B=6, where kink flips (not rounding) set both distances: see below
+
+
+def assert_calibrated(module, g32, g64, what, cal=CAL):
     """The HIP path must be an fp32 implementation of the reference's graph of the same quality as the reference's own
     CPU path.  Yardstick: relative L2 distance to the oracle evaluated in fp64.
-      * over ALL gradients of the network concatenated: HIP <= 10x CPU-fp32 + 2e-4
-      * per tensor: HIP <= 10x CPU-fp32 + 5e-4 for at least 97 % of the tensors, and <= 2e-2 for every tensor
+      * over ALL gradients of the network concatenated: HIP <= cal x CPU-fp32 + 2e-4
+      * per tensor: HIP <= cal x CPU-fp32 + 5e-4 for at least 97 % of the tensors, and <= 2e-2 for every tensor
         (a ReLU / max-pool unit within rounding of its kink may switch side in one of the two fp32 runs; that moves
-        the few tensors fed by it by ~1e-3 and says nothing about kernel accuracy)."""
+        the few tensors fed by it by ~1e-3 and says nothing about kernel accuracy)
+      * the MEDIAN over tensors of (HIP distance / CPU-fp32 distance) <= 3 in every case.
+    cal = 3 at the benchmark's resolution (measured ratio of the totals 1.17 / 1.28 for calls A / B at 256x256, 0.81 / 1.22 at
+    B=3 32x32).  On the B=6 32x32 / 64x64 cases both fp32 runs sit 1e-3..4e-3 from the fp64 run — 100x rounding level: units on
+    kinks that flip in one run and not in the other — and the ratio of two such draws scatters (measured 0.37 .. 4.14 between
+    calls of the same case), so those keep cal = 10 for the totals and are pinned by the median ratio instead.
+    -> (HIP distance, CPU-fp32 distance); messages carry the measured ratios."""
     num_h = num_c = den = 0.0
     per = []
     for k, p in module.named_parameters():
@@ -114,9 +124,14 @@ def assert_calibrated(module, g32, g64, what):
         num_h += eh2; num_c += ec2; den += n2
         per.append(((eh2 / n2) ** 0.5, (ec2 / n2) ** 0.5, k))
     tot_h, tot_c = (num_h / den) ** 0.5, (num_c / den) ** 0.5
-    assert tot_h <= 10.0 * tot_c + 2e-4, f"{what}: all gradients: HIP {tot_h:.3e} vs CPU-fp32 {tot_c:.3e}"
-    bad = [(h, c, k) for h, c, k in per if h > 10.0 * c + 5e-4]
-    assert len(bad) <= 0.03 * len(per), f"{what}: {len(bad)}/{len(per)} tensors off, e.g. {sorted(bad, reverse=True)[:3]}"
+    ratio = tot_h / max(tot_c, 1e-30)
+    med = float(np.median([h / max(c, 1e-30) for h, c, _ in per]))
+    print(f"[calibrated {what}] all gradients: HIP {tot_h:.3e} vs CPU-fp32 {tot_c:.3e} from the fp64 oracle: ratio {ratio:.2f} "
+          f"(bound {cal:.0f}x + 2e-4); median per-tensor ratio {med:.2f} (bound 3)")
+    assert tot_h <= cal * tot_c + 2e-4, f"{what}: all gradients: HIP {tot_h:.3e} vs CPU-fp32 {tot_c:.3e} (ratio {ratio:.2f}, bound {cal:.0f}x + 2e-4)"
+    assert med <= 3.0, f"{what}: median per-tensor ratio HIP / CPU-fp32 = {med:.2f} > 3"
+    bad = [(h, c, k) for h, c, k in per if h > cal * c + 5e-4]
+    assert len(bad) <= 0.03 * len(per), f"{what}: {len(bad)}/{len(per)} tensors beyond {cal:.0f}x + 5e-4, e.g. {sorted(bad, reverse=True)[:3]}"
     worst = max(per)
     assert worst[0] <= 2e-2, f"{what}.{worst[2]}: HIP {worst[0]:.3e} vs CPU-fp32 {worst[1]:.3e}"
     return tot_h, tot_c
@@ -317,7 +332,8 @@ def test_gradients_calibrated(B, pb, H):
         o, _, _, i2, d2 = O.wt_pse_update(sd, HP, img.to(dt), od.to(dt), img.to(dt), True, eps.to(dt), 3, pb)
         return O.seg_loss_od(o, od.to(dt)) + i2 + d2
     (g32,), (g64,) = oracle_grads(loss_a, [sd_m], torch.float32), oracle_grads(loss_a, [sd_m], torch.float64)
-    assert_calibrated(main, g32, g64, "A")
+    cal = CAL if (H >= 256 or B == 3) else CAL_KINK
+    assert_calibrated(main, g32, g64, "A", cal)
     shape.zero_grad(); main.zero_grad()
     kd, ins_t, _, _, dom_s = shape.update(main, img.to(DEV), od.to(DEV), two_stage_inputs=img.to(DEV), two_step=True)
     (kd + ins_t + dom_s).backward()
@@ -329,7 +345,7 @@ def test_gradients_calibrated(B, pb, H):
         return r[0] + r[1] + r[4]
     g32 = oracle_grads(loss_b, [sd_s, sd_m2], torch.float32)[0]
     g64 = oracle_grads(loss_b, [sd_s, sd_m2], torch.float64)[0]
-    assert_calibrated(shape, g32, g64, "B")
+    assert_calibrated(shape, g32, g64, "B", cal)
 
 
 # ---------------------------------------------------------------- a-11: full A-D iterations
@@ -357,19 +373,54 @@ def _check_params_vs_golden(nets, g, iters=3, lr=5e-4):
 
 
 def _loss_tol(k, it):
-    """Iteration 0, call A sees identical weights and inputs: the 1e-4 bar applies.  Everything later has passed
-    through Adam's sign-like first steps and the 0.75 ROI threshold (Trainer.py:842), which amplify fp32 rounding:
-    the oracle run in fp64 departs from the fp32 reference by 5e-4 (kd, iteration 0), 0.5-2.5 % (iteration 1) and up
-    to 3 % / 14 % (kd / MMD terms, iteration 2) — measured; tolerances are ~4x those figures."""
-    if it == 0 and k in ("seg_od", "ins_od"):
+    """Iteration 0 against the reference's fixture: call A sees identical weights and inputs, so the 1e-4 bar applies; the
+    other calls of iteration 0 come after one Adam step.  Iterations 1-2 are checked by _check_later_iterations."""
+    assert it == 0
+    if k in ("seg_od", "ins_od"):
         return dict(rtol=1e-4, atol=1e-5)
-    if it == 0 and k == "dom_od":
+    if k == "dom_od":
         return dict(rtol=1e-3, atol=5e-7)
-    if it == 0:
-        return dict(rtol=5e-3, atol=1e-4)
-    if k.startswith("dom"):
-        return dict(rtol=0.6, atol=1e-3)
-    return dict(rtol=0.1, atol=1e-3)
+    return dict(rtol=5e-3, atol=1e-4)
+
+
+TRAJ_CAL = 5.0     # measured worst ratio 4.15 (an MMD term of iteration 1); the old bounds were rtol 0.1 / 0.6
+
+
+def _oracle_trajectories(g, nets):
+    """The CPU oracle's own trajectory over the fixture's iterations from the HIP networks' initial state, evaluated in fp32
+    and in fp64 -> ([losses per iteration] fp32, the same fp64)."""
+    out = []
+    for dt in (torch.float32, torch.float64):
+        sds = [{k: (v.detach().cpu().clone().to(dt) if v.is_floating_point() else v.detach().cpu().clone())
+                for k, v in n.state_dict().items()} for n in nets]
+        on = O.Nets(*sds)
+        pb = int(g["meta"][1])
+        traj = []
+        for it, img, od, oc, nz in _iteration_inputs(g):
+            traj.append(O.train_iteration(on, HP, img.to(dt), od.to(dt), oc.to(dt), {k: v.to(dt) for k, v in nz.items()}, pb))
+        out.append(traj)
+    return out
+
+
+def _check_later_iterations(results, traj32, traj64):
+    """Iterations 1-2 have passed through Adam's sign-like first steps and the 0.75 ROI threshold (Trainer.py:842), which
+    amplify fp32 rounding: the oracle run in fp64 departs from its own fp32 run by 0.5-14 % there.  So the yardstick is that
+    departure itself: per iteration and loss, |HIP - fp64 oracle| <= TRAJ_CAL x max(|fp32 oracle - fp64 oracle|, the median of
+    that departure over the iteration's losses) + 1e-4 x |value| — the HIP trajectory must stay as close to the fp64
+    trajectory as the reference's own fp32 arithmetic does."""
+    for it in range(1, len(results)):
+        keys = [k for k in traj64[it] if k in results[it]]
+        rel = lambda a, b: abs(float(a) - float(b)) / (abs(float(b)) + 1e-6)
+        dc = {k: rel(traj32[it][k], traj64[it][k]) for k in keys}
+        dh = {k: rel(results[it][k], traj64[it][k]) for k in keys}
+        med = float(np.median(list(dc.values())))
+        worst = max(keys, key=lambda k: dh[k] / (max(dc[k], med) + 1e-12))
+        print(f"[trajectory it{it}] median departure fp32-oracle {med:.3e}, HIP {float(np.median(list(dh.values()))):.3e}; "
+              f"worst ratio {dh[worst] / (max(dc[worst], med) + 1e-12):.2f} ({worst})")
+        for k in keys:
+            bound = TRAJ_CAL * max(dc[k], med) + 1e-4
+            assert dh[k] <= bound, (f"it{it}.{k}: HIP departs {dh[k]:.3e} from the fp64 oracle, the fp32 oracle {dc[k]:.3e} "
+                                    f"(median over losses {med:.3e}); bound {bound:.3e}")
 
 
 def test_iterations_harness_vs_golden(golden_dir):
@@ -378,14 +429,18 @@ def test_iterations_harness_vs_golden(golden_dir):
     g = np.load(os.path.join(golden_dir, "iteration.npz"))
     pb = int(g["meta"][1])
     main, shape, main_oc, shape_oc = build_nets(pb)
+    traj32, traj64 = _oracle_trajectories(g, [main, shape, main_oc, shape_oc])
     ts = TrainStep(main, shape, main_oc, shape_oc, HP)
     keys = [str(k) for k in g["loss_keys"]]
+    results = []
     for it, img, od, oc, nz in _iteration_inputs(g):
         res = ts.step(img.to(DEV), od.to(DEV), oc.to(DEV), {"a": nz["a"], "c": nz["c"]})
+        results.append({k: float(v) for k, v in res.items()})
         for j, k in enumerate(keys):
-            if k not in res:
+            if k not in res or it > 0:
                 continue           # main_od / shape_od ... are sums formed by the caller
             close(res[k], g["losses"][it][j], what=f"it{it}.{k}", **_loss_tol(k, it))
+    _check_later_iterations(results, traj32, traj64)
     _check_params_vs_golden([main, shape, main_oc, shape_oc], g)
 
 
@@ -400,6 +455,8 @@ def test_iterations_dropin_vs_golden(golden_dir):
     optim, optim_shape, optim_oc, optim_shape_oc = opts
     bce = torch.nn.BCELoss()
     keys = [str(k) for k in g["loss_keys"]]
+    traj32, traj64 = _oracle_trajectories(g, nets)
+    results = []
     for n in nets:
         n.train()
     for it, image, target_od, target_oc, nz in _iteration_inputs(g):
@@ -436,8 +493,11 @@ def test_iterations_dropin_vs_golden(golden_dir):
         loss_shape_oc = kd2 + HP["instance_wt_gm"] * ins_t2 + HP["domain_wt_gm"] * dom_s2
         loss_shape_oc.backward(); optim_shape_oc.step()
         res.update(kd_oc=kd2, ins_shape_oc=ins_t2, dom_shape_oc=dom_s2, shape_oc=loss_shape_oc)
-        for j, k in enumerate(keys):
-            close(res[k], g["losses"][it][j], what=f"it{it}.{k}", **_loss_tol(k, it))
+        results.append({k: float(v) for k, v in res.items()})
+        if it == 0:
+            for j, k in enumerate(keys):
+                close(res[k], g["losses"][it][j], what=f"it{it}.{k}", **_loss_tol(k, it))
+    _check_later_iterations(results, traj32, traj64)
     _check_params_vs_golden(nets, g)
 
 
@@ -464,6 +524,36 @@ def test_update_256_vs_oracle():
         pred, _ = main.predict(shape, img.to(DEV))
         ref_pred, _ = O.wt_pse_predict(sd_main, sd_shape, HP, img, False)
     close(pred, ref_pred, atol=TOL, what="predict@256")
+    for b in range(B):
+        d_hip = O.dice_coefficient((torch.sigmoid(pred[b, 0]) > 0.75).cpu().numpy(), od[b, 0].numpy())
+        d_ref = O.dice_coefficient((torch.sigmoid(ref_pred[b, 0]) > 0.75).numpy(), od[b, 0].numpy())
+        assert abs(d_hip - d_ref) <= 1e-4, (b, d_hip, d_ref)
+
+
+def test_update_predict_256_B32_vs_oracle():
+    """BASELINE.json configs[2] exactly: 3x256x256, batch 32, per_domain_batch 10 (rows 30-31 take part in the instance loss
+    and in BatchNorm but not in the MMD, algorithms.py:107).  Train-mode `update()` (logits, WT-loss values) and eval-mode
+    `predict()` against the CPU oracle on the same inputs at the 1e-4 bar, plus Dice of every thresholded prediction."""
+    B, pb, H = 32, 10, 256
+    img, od, oc = make_inputs(97, B, H, H)
+    eps = make_noise(98, (B, 1, H, H))
+    main, shape, _, _ = build_nets(pb)
+    sd_main = {k: v.detach().cpu().clone() for k, v in main.state_dict().items()}
+    sd_shape = {k: v.detach().cpu().clone() for k, v in shape.state_dict().items()}
+    main.train()
+    main.set_noise([eps])
+    with torch.no_grad():
+        out, _, _, ins, dom = main.update(img.to(DEV), od.to(DEV), two_stage_inputs=img.to(DEV), two_step=True)
+        ref_out, _, _, ref_ins, ref_dom = O.wt_pse_update(dict(sd_main), HP, img, od, img, True, eps, 3, pb)
+    close(out, ref_out, atol=TOL, what="logits@256,B=32")
+    close(ins, ref_ins, rtol=1e-4, atol=1e-6, what="ins@256,B=32")
+    close(dom, ref_dom, rtol=1e-3, atol=1e-6, what="dom@256,B=32")
+    main.eval(); shape.eval()
+    with torch.no_grad():
+        pred, att = main.predict(shape, img.to(DEV))
+        ref_pred, ref_att = O.wt_pse_predict(sd_main, sd_shape, HP, img, False)
+    close(pred, ref_pred, atol=TOL, what="predict@256,B=32")
+    close(att, ref_att, atol=TOL, what="attention@256,B=32")
     for b in range(B):
         d_hip = O.dice_coefficient((torch.sigmoid(pred[b, 0]) > 0.75).cpu().numpy(), od[b, 0].numpy())
         d_ref = O.dice_coefficient((torch.sigmoid(ref_pred[b, 0]) > 0.75).numpy(), od[b, 0].numpy())

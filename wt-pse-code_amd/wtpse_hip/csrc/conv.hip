@@ -864,6 +864,18 @@ extern "C" void wtpse_wgrad_reduce_launch(const float* slab, int ksplit, int n, 
                        ceil_div(n, 32), (const float*)nullptr, 0, (float*)nullptr);
 }
 
+// the same with the bias-gradient slabs folded in the same launch (wgrad_r.hip)
+extern "C" void wtpse_wgrad_reduce_launch2(const float* slab, int ksplit, int n, float* dw, int accumulate, const float* slab_b,
+                                           int n_b, float* db, void* stream) {
+  if (!db) {
+    wtpse_wgrad_reduce_launch(slab, ksplit, n, dw, accumulate, stream);
+    return;
+  }
+  const int nblk_w = ceil_div(n, 32), nblk_b = ceil_div(n_b, 32);
+  hipLaunchKernelGGL(wgrad_reduce_k, dim3(nblk_w + nblk_b), dim3(256), 0, (hipStream_t)stream, slab, ksplit, n, dw, accumulate, nblk_w,
+                     slab_b, n_b, db);
+}
+
 extern "C" int wtpse_wgrad_ksplit(int B, int H, int W, int Cin, int Cout) {
   const int TW = W <= 16 ? 16 : 32, TH = 256 / TW;
   const int ntiles = B * ceil_div(W, TW) * ceil_div(H, TH);
