@@ -147,3 +147,58 @@ def test_conv_x3_wgrad(case):
     assert e3 <= 2.0 * e32 + 2e-8, (e3, e32)
     o.conv_wgrad_x3(*args, dw, accumulate=True, **kw)
     close(dw, 2 * ref64, rtol=2e-4, atol=4e-5 * max(scale, 1.0), what="wgrad x3 accumulate")
+
+
+@pytest.mark.parametrize("case", [
+    # B, C0, C1, Cout, H, W, bias
+    (2, 16, 0, 16, 8, 32, True),      # one 16x16 block, one strip, bias gradient (the DeepWT layers)
+    (3, 16, 0, 16, 20, 64, True),     # two strips: the pixels left / right of a strip come from the neighbouring one
+    (2, 32, 0, 32, 16, 32, False),    # 32x32 block per wave
+    (2, 16, 16, 32, 12, 64, False),   # concat whose halves are one 16-channel fragment each (up4.conv3)
+    (2, 64, 0, 32, 9, 32, False),     # two cin blocks, odd height
+    (1, 128, 128, 256, 5, 32, False), # many (cout, cin) pairs, fewer rows than the ring is deep
+    (2, 16, 0, 32, 7, 96, False),     # 16 -> 32 (down1.conv1): 2 x 1 fragments
+    (2, 48, 0, 16, 33, 32, True),     # 1 x 1 fragments, three cin blocks, bias
+    (24, 32, 32, 64, 32, 64, False),  # several units per wave
+    (40, 16, 0, 16, 64, 64, True),    # row segments (more waves than columns) and several units per wave
+])
+def test_conv_wgrad_r(case):
+    """The register-resident x3 weight gradient (csrc/wgrad_r.hip) against the fp64 gradient of stock conv2d, at the tolerance
+    of the LDS-based x3 kernel, with the fp32-MFMA kernel as the yardstick, plus the bias gradient and accumulation."""
+    o = ops()
+    B, C0, C1, Co, H, W, bias = case
+    k = 3
+    x0 = rnd(B, C0, H, W, seed=11)
+    x1 = rnd(B, C1, H, W, seed=12) if C1 else None
+    w = rnd(Co, C0 + C1, k, k, seed=13, scale=0.2).requires_grad_(True)
+    bb = rnd(Co, seed=14).requires_grad_(True)
+    dy = rnd(B, Co, H, W, seed=15)
+    pro = torch.stack([rnd(C0 + C1, seed=7) * 0.5 + 1.0, rnd(C0 + C1, seed=8)], 1).contiguous()
+    xin = torch.cat([x0, x1], 1) if C1 else x0
+    act = F.relu(xin * pro[:, 0].view(1, -1, 1, 1) + pro[:, 1].view(1, -1, 1, 1))
+    F.conv2d(act.double(), w.double(), bb.double(), padding=1).backward(dy.double())
+    ref64, refb = w.grad.double(), bb.grad.double()
+    assert o.wgrad_r_supported(C0 + C1, Co, k, C0 if C1 else 16, W)
+    dw = torch.full_like(w.detach(), float("nan")).to(DEV)
+    db = torch.full((Co,), float("nan"), device=DEV) if bias else None
+    args = (dy.to(DEV), x0.to(DEV), x1.to(DEV) if C1 else None)
+    kw = dict(pro0=pro[:C0].contiguous().to(DEV), pro_relu=3, pro1=(pro[C0:].contiguous().to(DEV) if C1 else None))
+    o.conv_wgrad_r(*args, dw, db, **kw)
+    scale = float(ref64.abs().max())
+    close(dw, ref64, rtol=2e-4, atol=2e-5 * max(scale, 1.0), what="wgrad r")
+    if bias:
+        close(db, refb, rtol=1e-4, atol=1e-5 * max(float(refb.abs().max()), 1.0), what="dbias r")
+    dw32 = torch.empty_like(dw)
+    o.conv_wgrad(args[0], args[1], args[2], k, dw32, None, kw["pro0"], 3, False, kw["pro1"])
+    e3 = float((dw.cpu().double() - ref64).norm() / ref64.norm())
+    e32 = float((dw32.cpu().double() - ref64).norm() / ref64.norm())
+    print("relative L2 error vs fp64: wgrad_r %.2e, fp32 MFMA %.2e" % (e3, e32))
+    assert e3 <= 2.0 * e32 + 2e-8, (e3, e32)
+    o.conv_wgrad_r(*args, dw, db, accumulate=True, **kw)
+    close(dw, 2 * ref64, rtol=2e-4, atol=4e-5 * max(scale, 1.0), what="wgrad r accumulate")
+    # without a prologue (a dense input), no bias
+    F.conv2d(xin.double(), w.double(), None, padding=1)
+    w.grad = None
+    F.conv2d(xin.double(), w.double(), None, padding=1).backward(dy.double())
+    o.conv_wgrad_r(*args, dw, None)
+    close(dw, w.grad.double(), rtol=2e-4, atol=2e-5 * max(float(w.grad.abs().max()), 1.0), what="wgrad r, no prologue")

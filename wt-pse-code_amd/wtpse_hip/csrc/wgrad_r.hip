@@ -75,7 +75,7 @@ __device__ __forceinline__ void wr_split8(const f32x4& lo, const f32x4& hi, u32x
 }
 
 template <int MF, int NF, bool PRO, bool BIAS>
-__global__ __launch_bounds__(256, (MF * NF >= 4) ? 1 : 2) void wgrad_r_k(WgradRArgs a) {
+__global__ __launch_bounds__(256, (MF * NF >= 2) ? 1 : 2) void wgrad_r_k(WgradRArgs a) {
   constexpr int NT = 9;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c16 = lane & 15, g = lane >> 4;
@@ -337,7 +337,7 @@ static bool wgrad_r_plan(int B, int H, int W, int Cin, int Cout, WgradRPlan& p) 
   p.pairs = (Cout / (16 * p.mf)) * p.nci;
   p.strips = W / 32;
   // waves: one per SIMD for the 32 x 32 blocks (more than 256 registers), two per SIMD otherwise
-  const int target = (p.mf * p.nf >= 4) ? 1024 : 2048;
+  const int target = (p.mf * p.nf >= 2) ? 1024 : 2048;
   int wpp = (target / p.pairs) & ~3;
   if (wpp < 4) wpp = 4;
   const int cols = B * p.strips;                          // (image, strip) columns of H rows

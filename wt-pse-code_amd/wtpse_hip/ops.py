@@ -142,6 +142,25 @@ def conv_wgrad_x3(dy, x0, x1, ksize, dw, pro0=None, pro_relu=0, accumulate=False
            int(accumulate), B, H, W, cout, ksize, stream_ptr())
 
 
+def wgrad_r_supported(cin, cout, ksize, c0, w):
+    return bool(lib().query("wtpse_wgrad_r_supported", int(cin), int(cout), int(ksize), int(c0), int(w)))
+
+
+def conv_wgrad_r(dy, x0, x1, dw, dbias=None, pro0=None, pro_relu=0, accumulate=False, pro1=None):
+    """3x3 conv_wgrad in the x3 arithmetic with register-resident operands (csrc/wgrad_r.hip); with bias gradient."""
+    _chk(dy, "dy"); _chk(x0, "x0"); _chk(x1, "x1")
+    B, cout, H, W = dy.shape
+    C0 = x0.shape[1]
+    C1 = 0 if x1 is None else x1.shape[1]
+    cin = C0 + C1
+    L = lib()
+    ns = L.query("wtpse_wgrad_r_slabs", B, H, W, cin, cout)
+    slab = workspace("wgrad_slab", ns * cout * cin * 9, dy.device)
+    dbs = workspace("wgrad_dbias", ns * cout, dy.device) if dbias is not None else None
+    L.call("wtpse_conv_wgrad_r", ptr(dy), ptr(x0), C0, ptr(x1), C1, ptr(pro0), ptr(pro1), int(pro_relu), ptr(slab), ptr(dbs), ns,
+           ptr(dw), ptr(dbias), int(accumulate), B, H, W, cout, stream_ptr())
+
+
 # ----------------------------------------------------------------------------------------------- batch norm
 def bn_finalize(stats, count, gamma, beta, rmean, rvar, nbt, momentum=0.1, eps=1e-5):
     nblk, C, _ = stats.shape
