@@ -20,6 +20,7 @@
 // slabs are folded in fp64 in fixed order by wgrad_reduce_k / wgrad_fold4_k (conv.hip): bitwise reproducible, no atomics.
 // Bias gradient (layers without BatchNorm): sum of the dY values the A fragments are made from, in the waves of cin block 0.
 #include <type_traits>
+#include <utility>
 #include "common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -42,6 +43,10 @@ struct WgradRArgs {
   int wpp;         // waves per (cout block, cin block) pair (multiple of 4)
   int nci;         // cin blocks
 };
+
+template <int I> using IC = std::integral_constant<int, I>;
+template <class F, int... Is> __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(IC<Is>{}), ...); }
+template <int N, class F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 __device__ __forceinline__ unsigned wr_pack_rne(float a, float b) {
   bf16x2 v = {(__bf16)a, (__bf16)b};
@@ -74,15 +79,22 @@ __device__ __forceinline__ void wr_split8(const f32x4& lo, const f32x4& hi, u32x
   }
 }
 
+// waves per workgroup: the 16 x 16 blocks (under 256 registers, two waves per SIMD) run as ONE 8-wave workgroup per CU whose
+// waves walk down eight adjacent strips in step — a whole 256-pixel row of every channel between them; the larger blocks have
+// their SIMD to themselves: four waves
+template <int MF, int NF> struct WgradRGeom { static constexpr int NW = (MF * NF >= 2) ? 4 : 8; };
+
 template <int MF, int NF, bool PRO, bool BIAS>
-__global__ __launch_bounds__(256, (MF * NF >= 2) ? 1 : 2) void wgrad_r_k(WgradRArgs a) {
-  constexpr int NT = 9;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__global__ __launch_bounds__((64 * WgradRGeom<MF, NF>::NW), 1) void wgrad_r_k(WgradRArgs a) {
+  constexpr int NT = 9, NW = WgradRGeom<MF, NF>::NW;
+  // (the wave id is wave-uniform, but only readfirstlane tells the compiler: everything derived from it — the unit, the image,
+  // the buffer descriptors — then stays in SGPRs instead of being re-derived per lane behind waterfall loops)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c16 = lane & 15, g = lane >> 4;
-  const int wgpp = a.wpp >> 2;                           // workgroups per pair
+  const int wgpp = a.wpp / NW;                           // workgroups per pair
   const int pair = blockIdx.x / wgpp, wg = blockIdx.x - pair * wgpp;
   const int cin0 = (pair % a.nci) * (16 * NF), cout0 = (pair / a.nci) * (16 * MF);
-  const int wv = wg * 4 + wave;
+  const int wv = wg * NW + wave;
   const int u0 = (int)((long long)wv * a.units / a.wpp), u1 = (int)((long long)(wv + 1) * a.units / a.wpp);
   const int HW = a.H * a.W;
   const unsigned W4 = (unsigned)a.W * 4u;
@@ -120,10 +132,11 @@ __global__ __launch_bounds__(256, (MF * NF >= 2) ? 1 : 2) void wgrad_r_k(WgradRA
   const int src_up = (lane + 16) & 63, src_dn = (lane - 16) & 63;
 
   for (int u = u0; u < u1; ++u) {
-    // unit -> (image, 32-pixel strip, row segment)
-    const int seg = u % a.nseg;
-    const int bs = u / a.nseg;
-    const int strip = bs % a.strips, b = bs / a.strips;
+    // unit -> (image, row segment, 32-pixel strip), strips fastest: the four waves of a workgroup then walk down four adjacent
+    // strips in step, i.e. read 512 contiguous bytes of every channel row between them (DRAM pages, L2 lines)
+    const int strip = u % a.strips;
+    const int bs = u / a.strips;
+    const int seg = bs % a.nseg, b = bs / a.nseg;
     const int x0 = strip * 32;
     const int y0 = seg * a.rseg, y1 = min(a.H, y0 + a.rseg);
     const int rfirst = max(y0 - 1, 0), rlast = min(y1, a.H - 1);
@@ -142,84 +155,100 @@ __global__ __launch_bounds__(256, (MF * NF >= 2) ? 1 : 2) void wgrad_r_k(WgradRA
 #pragma unroll
       for (int n = 0; n < NF; ++n) {
         xbase[n] = ((unsigned)xch[n] * HW + x0 + 8 * g) * 4u;
-        ebase[n] = ((unsigned)xch[n] * HW + ex) * 4u;
+        ebase[n] = evalid ? ((unsigned)xch[n] * HW + ex) * 4u : BUF_OOB;
       }
     }
 
-    f32x4 rawx[NF][2], rawy[MF][2];
-    float rawe[NF];
-    // loads of X row r and dY row r + 1 (rows outside their range read as zero: out-of-range buffer offsets)
-    auto issue = [&](int r, bool want_x) {
-      const bool xv = want_x && r <= rlast;
-      const unsigned ro = (unsigned)r * W4;
+    // ---- software pipeline over "stages": stage s = (X row s, dY row s + 1).  While the matrix cores work on X row r, the
+    // stage r + 1 that has landed in registers is converted (prologue, bf16 split) for the next step, and the loads of stage
+    // r + 3 are issued into the raw slot it frees: two stages (8 KB per wave at 16 x 16 channels) are in flight at any time.
+    // All ring slots are static: the row loop is unrolled by four.  Rows outside [y0, y1) / the image read as zero
+    // (out-of-range buffer offsets), so the products need no edge cases.
+    f32x4 rawx[2][NF][2], rawy[2][MF][2];
+    float rawe[2][NF];
+    u32x4v ay[4][MF][3];          // split dY rows: row y in slot (y - rfirst) & 3      [slot][cout fragment][term]
+    u32x4v xb[2][NF][3];          // split X row s in slot (s - rfirst) & 1
+    unsigned eq[2][NF][3];        // its edge pixel (lane groups 0 and 3)
+    // (branch-free: a row outside its range turns into an out-of-range buffer offset by OR-ing the top bit in — every valid
+    // offset is below 2^31 — and the row's byte offset rides in the scalar offset operand)
+    auto issue = [&](auto Sc, int s, bool want_x) {
+      constexpr int S = decltype(Sc)::value;
+      const int xv = (int)want_x & (int)(s <= rlast);     // (bitwise on purpose: no short-circuit branch inside the row loop)
+      const unsigned xo = xv ? 0u : BUF_OOB;
+      const unsigned ro = xv ? (unsigned)s * W4 : 0u;
 #pragma unroll
       for (int n = 0; n < NF; ++n) {
         const __amdgpu_buffer_rsrc_t rs = xfirst[n] ? rsx0 : rsx1;
-        const unsigned vo = xv ? xbase[n] + ro : BUF_OOB;
-        rawx[n][0] = buf_load4(rs, vo, 0);
-        rawx[n][1] = buf_load4(rs, vo, 16);
-        rawe[n] = buf_load(rs, (xv && evalid) ? ebase[n] + ro : BUF_OOB, 0);
+        const unsigned vo = xbase[n] | xo;
+        rawx[S][n][0] = buf_load4(rs, vo, ro);
+        rawx[S][n][1] = buf_load4(rs, vo + 16u, ro);
+        rawe[S][n] = buf_load(rs, ebase[n] | xo, ro);
       }
-      const int y = r + 1;
-      const bool yv = y >= y0 && y < y1;
-      const unsigned yo = (unsigned)y * W4;
+      const int y = s + 1;
+      const int yv = (int)(y >= y0) & (int)(y < y1);
+      const unsigned yo = yv ? (unsigned)y * W4 : 0u, ym = yv ? 0u : BUF_OOB;
 #pragma unroll
       for (int m = 0; m < MF; ++m) {
-        const unsigned vo = yv ? ybase[m] + yo : BUF_OOB;
-        rawy[m][0] = buf_load4(rsy, vo, 0);
-        rawy[m][1] = buf_load4(rsy, vo, 16);
+        const unsigned vo = ybase[m] | ym;
+        rawy[S][m][0] = buf_load4(rsy, vo, yo);
+        rawy[S][m][1] = buf_load4(rsy, vo + 16u, yo);
       }
     };
-
-    u32x4v ay[3][MF][3];          // ring of split dY rows: [slot][cout fragment][term]
-#pragma unroll
-    for (int s = 0; s < 3; ++s)
-#pragma unroll
-      for (int m = 0; m < MF; ++m)
-#pragma unroll
-        for (int t = 0; t < 3; ++t) ay[s][m][t] = (u32x4v){0u, 0u, 0u, 0u};
-
-    // one X row: J = (r - rfirst) mod 3 selects the ring slots statically.  dY row y lives in slot (y - rfirst + 3) mod 3.
-    auto step = [&](auto Jc, int r) {
-      constexpr int J = decltype(Jc)::value;
-      // ---- the dY row that arrived (row r + 1) -> slot (J + 1) % 3
-#pragma unroll
-      for (int m = 0; m < MF; ++m) {
-        if (BIAS) bsum[m] += ((rawy[m][0][0] + rawy[m][0][1]) + (rawy[m][0][2] + rawy[m][0][3])) +
-                             ((rawy[m][1][0] + rawy[m][1][1]) + (rawy[m][1][2] + rawy[m][1][3]));
-        wr_split8(rawy[m][0], rawy[m][1], ay[(J + 1) % 3][m]);
-      }
-      // ---- the X row that arrived (row r): prologue, split; edge pixel
-      u32x4v xb[NF][3];
-      unsigned eq[NF][3];
-#pragma unroll
-      for (int n = 0; n < NF; ++n) {
-        f32x4 lo = rawx[n][0], hi = rawx[n][1];
-        float e = rawe[n];
+    // Conversion of the stage in raw slot S (-> X slot S, dY slot AS), cut into NP pieces of about a dozen vector instructions:
+    //   [0, 4 MF)            one pair of a dY fragment's 8 pixels: split into the three bf16 terms (+ bias sum)
+    //   [4 MF, 4 MF + 4 NF)  one pair of an X fragment's 8 pixels: prologue, split
+    //   next NF              the edge pixel of an X fragment
+    //   last                 the loads of the stage that will take this raw slot (`next`; < 0: none)
+    constexpr int NP = 4 * MF + 4 * NF + NF + 1;
+    auto piece = [&](auto Pc, auto Sc, auto ASc, int next) {
+      constexpr int P = decltype(Pc)::value, S = decltype(Sc)::value, AS = decltype(ASc)::value;
+      if constexpr (P < 4 * MF) {
+        constexpr int m = P / 4, q = P % 4;
+        const float v0 = rawy[S][m][q >> 1][2 * (q & 1)], v1 = rawy[S][m][q >> 1][2 * (q & 1) + 1];
+        if (BIAS) bsum[m] += v0 + v1;
+        unsigned q0, q1, q2;
+        wr_split3_pair(v0, v1, q0, q1, q2);
+        ay[AS][m][0][q] = q0; ay[AS][m][1][q] = q1; ay[AS][m][2][q] = q2;
+      } else if constexpr (P < 4 * MF + 4 * NF) {
+        constexpr int n = (P - 4 * MF) / 4, q = (P - 4 * MF) % 4;
+        float v0 = rawx[S][n][q >> 1][2 * (q & 1)], v1 = rawx[S][n][q >> 1][2 * (q & 1) + 1];
         if (PRO) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            lo[j] = fmaxf(fmaf(lo[j], psc[n], psh[n]), plo[n]);
-            hi[j] = fmaxf(fmaf(hi[j], psc[n], psh[n]), plo[n]);
-          }
-          e = evalid ? fmaxf(fmaf(e, psc[n], psh[n]), plo[n]) : 0.f;     // zero padding applies after the activation
+          v0 = fmaxf(fmaf(v0, psc[n], psh[n]), plo[n]);
+          v1 = fmaxf(fmaf(v1, psc[n], psh[n]), plo[n]);
         }
-        wr_split8(lo, hi, xb[n]);
-        wr_split3_pair(e, 0.f, eq[n][0], eq[n][1], eq[n][2]);
+        unsigned q0, q1, q2;
+        wr_split3_pair(v0, v1, q0, q1, q2);
+        xb[S][n][0][q] = q0; xb[S][n][1][q] = q1; xb[S][n][2][q] = q2;
+      } else if constexpr (P < NP - 1) {
+        constexpr int n = P - 4 * MF - 4 * NF;
+        float e = rawe[S][n];
+        if (PRO) e = evalid ? fmaxf(fmaf(e, psc[n], psh[n]), plo[n]) : 0.f;     // zero padding applies after the activation
+        wr_split3_pair(e, 0.f, eq[S][n][0], eq[S][n][1], eq[S][n][2]);
+      } else {
+        if (next >= 0) issue(Sc, next, true);
       }
-      // ---- next rows' loads behind this row's arithmetic
-      issue(r + 1, true);
-      // ---- products
-#pragma unroll
-      for (int n = 0; n < NF; ++n) {
+    };
+    auto convert_all = [&](auto Sc, auto ASc, bool with_x) {
+      static_for<4 * MF>([&](auto p) { piece(p, Sc, ASc, -1); });
+      if (with_x) static_for<4 * NF + NF>([&](auto p) { piece(IC<4 * MF + decltype(p)::value>{}, Sc, ASc, -1); });
+    };
+    // One X row r (k = r - rfirst, J = k & 3): its products with the dY rows r + 1, r, r - 1 — chains of six dependent MFMAs, one
+    // per (cin fragment, vertical tap, cout fragment, horizontal tap) — with the conversion pieces of stage r + 1 dealt out
+    // behind the chains.  A wave of the 32 x 32 blocks has its SIMD to itself and issues in order, so the ORDER of the stream is
+    // the overlap: a 16x16x32 MFMA holds the vector issue for 8 of its 16 cycles, two vector instructions fit behind each.
+    constexpr int NC = NF * 9 * MF;
+    auto step = [&](auto Jc, int r) {
+      constexpr int J = decltype(Jc)::value, XS = J & 1, CS = (J + 1) & 1, AS = (J + 2) & 3;
+      static_for<NF>([&](auto nc) {
+        constexpr int n = decltype(nc)::value;
         u32x4v xs[3][3];          // [kx][term]: the row shifted by kx - 1 pixels
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
-          const u32x4v d = xb[n][t];
+          const u32x4v d = xb[XS][n][t];
           // pixel 8 of this lane's group = pixel 0 of the next group (lane + 16); for the last group the strip's right edge,
           // which lane group 0 holds.  Pixel -1 = pixel 7 of the previous group (lane - 16); for group 0 the left edge (group 3).
-          const unsigned sup_r = g == 0 ? eq[n][t] : d[0];
-          const unsigned sup_l = g == 3 ? (eq[n][t] << 16) : d[3];
+          const unsigned sup_r = g == 0 ? eq[XS][n][t] : d[0];
+          const unsigned sup_l = g == 3 ? (eq[XS][n][t] << 16) : d[3];
           const unsigned nb_r = (unsigned)__builtin_amdgcn_ds_bpermute(src_up * 4, (int)sup_r);
           const unsigned nb_l = (unsigned)__builtin_amdgcn_ds_bpermute(src_dn * 4, (int)sup_l);
           xs[1][t] = d;
@@ -232,53 +261,62 @@ __global__ __launch_bounds__(256, (MF * NF >= 2) ? 1 : 2) void wgrad_r_k(WgradRA
           xs[0][t][2] = __builtin_amdgcn_alignbit(d[2], d[1], 16);
           xs[0][t][3] = __builtin_amdgcn_alignbit(d[3], d[2], 16);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<9 * MF>([&](auto cc) {
+          constexpr int c = decltype(cc)::value;
+          constexpr int ky = c / (3 * MF), m = (c / 3) % MF, kx = c % 3;
+          constexpr int slot = (J + 1 - ky + 4) & 3;         // dY row r + 1 - ky
+          f32x4 v = acc[m][n][ky * 3 + kx];
+          // the six leading cross terms, smallest first (as conv_x3.hip)
+          v = mfma16x32(ay[slot][m][0], xs[kx][2], v);
+          v = mfma16x32(ay[slot][m][1], xs[kx][1], v);
+          v = mfma16x32(ay[slot][m][2], xs[kx][0], v);
+          v = mfma16x32(ay[slot][m][0], xs[kx][1], v);
+          v = mfma16x32(ay[slot][m][1], xs[kx][0], v);
+          v = mfma16x32(ay[slot][m][0], xs[kx][0], v);
+          acc[m][n][ky * 3 + kx] = v;
+          constexpr int cg = n * 9 * MF + c;                 // chain index within the step
+          constexpr int plo_ = (cg * NP + NC - 1) / NC, phi_ = ((cg + 1) * NP + NC - 1) / NC;
+          static_for<phi_ - plo_>([&](auto pp) { piece(IC<plo_ + decltype(pp)::value>{}, IC<CS>{}, IC<AS>{}, r + 3); });
+#ifndef WGRAD_R_NO_INTERLEAVE
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-          const int y = r + 1 - ky;                      // the dY row this X row meets under vertical tap ky
-          if (y < y0 || y >= y1) continue;               // wave-uniform
-          const int slot = (J + 1 - ky + 3) % 3;         // folds: J and ky are compile-time
-#pragma unroll
-          for (int m = 0; m < MF; ++m)
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-              f32x4 c = acc[m][n][ky * 3 + kx];
-              // the six leading cross terms, smallest first (as conv_x3.hip)
-              c = mfma16x32(ay[slot][m][0], xs[kx][2], c);
-              c = mfma16x32(ay[slot][m][1], xs[kx][1], c);
-              c = mfma16x32(ay[slot][m][2], xs[kx][0], c);
-              c = mfma16x32(ay[slot][m][0], xs[kx][1], c);
-              c = mfma16x32(ay[slot][m][1], xs[kx][0], c);
-              c = mfma16x32(ay[slot][m][0], xs[kx][0], c);
-              acc[m][n][ky * 3 + kx] = c;
-            }
-        }
-      }
+          for (int i = 0; i < 6; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);      // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x2, 2, 0);      // 2 VALU
+          }
+#endif
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      });
     };
 
-    // dY row rfirst (needed by the first X row under ky = 1) arrives with the "previous" row's loads
-    issue(rfirst - 1, false);                             // (no X row: rfirst - 1 lies outside the unit or the image)
-    {
-      // consume the dY row into slot 0
 #pragma unroll
-      for (int m = 0; m < MF; ++m) {
-        if (BIAS) bsum[m] += ((rawy[m][0][0] + rawy[m][0][1]) + (rawy[m][0][2] + rawy[m][0][3])) +
-                             ((rawy[m][1][0] + rawy[m][1][1]) + (rawy[m][1][2] + rawy[m][1][3]));
-        wr_split8(rawy[m][0], rawy[m][1], ay[0][m]);
-      }
-      issue(rfirst, true);
-    }
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int m = 0; m < MF; ++m)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) ay[s][m][t] = (u32x4v){0u, 0u, 0u, 0u};
+    // stages rfirst - 1 (its dY row only: X row rfirst - 1 lies outside the unit or the image) and rfirst, then two in flight
+    issue(std::integral_constant<int, 1>{}, rfirst - 1, false);
+    issue(std::integral_constant<int, 0>{}, rfirst, true);
+    convert_all(IC<1>{}, IC<0>{}, false);
+    convert_all(IC<0>{}, IC<1>{}, true);
+    issue(std::integral_constant<int, 1>{}, rfirst + 1, true);
+    issue(std::integral_constant<int, 0>{}, rfirst + 2, true);
     int r = rfirst;
-    for (; r + 2 <= rlast; r += 3) {
+    for (; r + 3 <= rlast; r += 4) {
       step(std::integral_constant<int, 0>{}, r);
       step(std::integral_constant<int, 1>{}, r + 1);
       step(std::integral_constant<int, 2>{}, r + 2);
+      step(std::integral_constant<int, 3>{}, r + 3);
     }
     if (r <= rlast) step(std::integral_constant<int, 0>{}, r);
     if (r + 1 <= rlast) step(std::integral_constant<int, 1>{}, r + 1);
+    if (r + 2 <= rlast) step(std::integral_constant<int, 2>{}, r + 2);
   }
 
   // ---- the four waves' partial sums meet in LDS, one vertical tap (3 x MF x NF tiles) at a time
-  __shared__ f32x4 red[4][3 * MF * NF][64];
+  __shared__ f32x4 red[NW][3 * MF * NF][64];
   float* out = a.slab + (size_t)wg * a.Cout * a.Cin * NT;      // slab `wg`: every pair writes its own (cout, cin) block of it
 #pragma unroll
   for (int ky = 0; ky < 3; ++ky) {
@@ -290,10 +328,11 @@ __global__ __launch_bounds__(256, (MF * NF >= 2) ? 1 : 2) void wgrad_r_k(WgradRA
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) red[wave][(m * NF + n) * 3 + kx][lane] = acc[m][n][ky * 3 + kx];
     __syncthreads();
-    for (int e = tid; e < 3 * MF * NF * 64; e += 256) {
+    for (int e = tid; e < 3 * MF * NF * 64; e += 64 * NW) {
       const int l = e & 63, f = e >> 6;
       const int kx = f % 3, mn = f / 3, n = mn % NF, m = mn / NF;
-      const f32x4 s = (red[0][f][l] + red[1][f][l]) + (red[2][f][l] + red[3][f][l]);
+      f32x4 s = (red[0][f][l] + red[1][f][l]) + (red[2][f][l] + red[3][f][l]);
+      if (NW == 8) s += (red[4][f][l] + red[5][f][l]) + (red[6][f][l] + red[7][f][l]);
       const int ci = cin0 + 16 * n + (l & 15);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -316,8 +355,10 @@ __global__ __launch_bounds__(256, (MF * NF >= 2) ? 1 : 2) void wgrad_r_k(WgradRA
       __syncthreads();
       if (tid < 16 * MF) {
         const int m = tid >> 4, c = tid & 15;
-        const float s = (redb[(0 * MF + m) * 16 + c] + redb[(1 * MF + m) * 16 + c]) +
-                        (redb[(2 * MF + m) * 16 + c] + redb[(3 * MF + m) * 16 + c]);
+        float s = (redb[(0 * MF + m) * 16 + c] + redb[(1 * MF + m) * 16 + c]) +
+                  (redb[(2 * MF + m) * 16 + c] + redb[(3 * MF + m) * 16 + c]);
+        if (NW == 8) s += (redb[(4 * MF + m) * 16 + c] + redb[(5 * MF + m) * 16 + c]) +
+                          (redb[(6 * MF + m) * 16 + c] + redb[(7 * MF + m) * 16 + c]);
         a.slab_b[(size_t)wg * a.Cout + cout0 + 16 * m + c] = s;
       }
     }
@@ -326,7 +367,7 @@ __global__ __launch_bounds__(256, (MF * NF >= 2) ? 1 : 2) void wgrad_r_k(WgradRA
 
 // ---------------------------------------------------------------------------------------------------------------------------
 struct WgradRPlan {
-  int mf, nf, pairs, nci, wpp, nseg, rseg, units, strips;
+  int mf, nf, nw, pairs, nci, wpp, nseg, rseg, units, strips;
 };
 
 static bool wgrad_r_plan(int B, int H, int W, int Cin, int Cout, WgradRPlan& p) {
@@ -336,10 +377,11 @@ static bool wgrad_r_plan(int B, int H, int W, int Cin, int Cout, WgradRPlan& p) 
   p.nci = Cin / (16 * p.nf);
   p.pairs = (Cout / (16 * p.mf)) * p.nci;
   p.strips = W / 32;
-  // waves: one per SIMD for the 32 x 32 blocks (more than 256 registers), two per SIMD otherwise
+  // waves: one per SIMD for the blocks of two or four fragments (more than 256 registers), two per SIMD for the 16 x 16 blocks
+  p.nw = (p.mf * p.nf >= 2) ? 4 : 8;
   const int target = (p.mf * p.nf >= 2) ? 1024 : 2048;
-  int wpp = (target / p.pairs) & ~3;
-  if (wpp < 4) wpp = 4;
+  int wpp = (target / p.pairs) / p.nw * p.nw;
+  if (wpp < p.nw) wpp = p.nw;
   const int cols = B * p.strips;                          // (image, strip) columns of H rows
   int nseg = 1;
   if (cols < wpp) nseg = ceil_div(wpp, cols);
@@ -347,7 +389,7 @@ static bool wgrad_r_plan(int B, int H, int W, int Cin, int Cout, WgradRPlan& p) 
   p.rseg = ceil_div(H, nseg);
   p.nseg = ceil_div(H, p.rseg);
   p.units = cols * p.nseg;
-  if (wpp > p.units) wpp = (p.units + 3) & ~3;            // trailing waves get no unit: they contribute zero slabs
+  if (wpp > p.units) wpp = (p.units + p.nw - 1) / p.nw * p.nw;   // trailing waves get no unit: they contribute zero slabs
   p.wpp = wpp;
   return true;
 }
@@ -360,7 +402,7 @@ extern "C" int wtpse_wgrad_r_supported(int Cin, int Cout, int ksize, int C0, int
 extern "C" int wtpse_wgrad_r_slabs(int B, int H, int W, int Cin, int Cout) {
   WgradRPlan p;
   if (!wgrad_r_plan(B, H, W, Cin, Cout, p)) return 0;
-  return p.wpp / 4;
+  return p.wpp / p.nw;
 }
 
 extern "C" void wtpse_wgrad_reduce_launch2(const float* slab, int ksplit, int n, float* dw, int accumulate, const float* slab_b,
@@ -377,7 +419,8 @@ extern "C" int wtpse_conv_wgrad_r(const float* dy, const float* x0, int C0, cons
   WTPSE_REQUIRE(wtpse_wgrad_r_supported(Cin, Cout, 3, C1 ? C0 : 16, W));
   WgradRPlan p;
   WTPSE_REQUIRE(wgrad_r_plan(B, H, W, Cin, Cout, p));
-  WTPSE_REQUIRE(nslab == p.wpp / 4);
+  WTPSE_REQUIRE(nslab == p.wpp / p.nw);
+  WTPSE_REQUIRE(!dbias || p.mf * p.nf == 1);               // bias gradient: the 16 -> 16 layers without BatchNorm (DeepWT)
   WTPSE_REQUIRE((long long)(C0 > C1 ? C0 : C1) * H * W * 4 < (1ll << 31) && (long long)Cout * H * W * 4 < (1ll << 31));
   WgradRArgs a;
   a.dy = dy; a.x0 = x0; a.x1 = x1; a.pro0 = pro0; a.pro1 = pro1; a.slab = slab; a.slab_b = dbias_slab;
@@ -385,17 +428,19 @@ extern "C" int wtpse_conv_wgrad_r(const float* dy, const float* x0, int C0, cons
   a.strips = p.strips; a.nseg = p.nseg; a.rseg = p.rseg; a.units = p.units; a.wpp = p.wpp; a.nci = p.nci;
   const bool pro = pro0 != nullptr || pro1 != nullptr || pro_relu != 0;
   const bool bias = dbias != nullptr;
-  dim3 grid((unsigned)(p.pairs * (p.wpp / 4)));
+  dim3 grid((unsigned)(p.pairs * (p.wpp / p.nw)));
+  const dim3 blk((unsigned)(64 * p.nw));
   hipStream_t st = (hipStream_t)stream;
 #define WR_LAUNCH(M, N) do { \
-    if (pro) { if (bias) hipLaunchKernelGGL((wgrad_r_k<M, N, true, true>), grid, dim3(256), 0, st, a); \
-               else hipLaunchKernelGGL((wgrad_r_k<M, N, true, false>), grid, dim3(256), 0, st, a); } \
-    else { if (bias) hipLaunchKernelGGL((wgrad_r_k<M, N, false, true>), grid, dim3(256), 0, st, a); \
-           else hipLaunchKernelGGL((wgrad_r_k<M, N, false, false>), grid, dim3(256), 0, st, a); } } while (0)
+    if (pro) hipLaunchKernelGGL((wgrad_r_k<M, N, true, false>), grid, blk, 0, st, a); \
+    else hipLaunchKernelGGL((wgrad_r_k<M, N, false, false>), grid, blk, 0, st, a); } while (0)
   if (p.mf == 2 && p.nf == 2) WR_LAUNCH(2, 2);
   else if (p.mf == 2) WR_LAUNCH(2, 1);
   else if (p.nf == 2) WR_LAUNCH(1, 2);
-  else WR_LAUNCH(1, 1);
+  else if (bias) {
+    if (pro) hipLaunchKernelGGL((wgrad_r_k<1, 1, true, true>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((wgrad_r_k<1, 1, false, true>), grid, blk, 0, st, a);
+  } else WR_LAUNCH(1, 1);
 #undef WR_LAUNCH
   int rc = wtpse_status();
   if (rc) return rc;

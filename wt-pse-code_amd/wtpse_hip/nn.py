@@ -407,6 +407,7 @@ def _relu_bits(a0, a1):
 # fp32-input MFMA (csrc/conv.hip).  WTPSE_X3=0 routes everything to the fp32-input MFMA.
 X3 = os.environ.get("WTPSE_X3", "1") != "0"
 X3_WGRAD = os.environ.get("WTPSE_X3_WGRAD", "1") != "0"
+WGRAD_R = os.environ.get("WTPSE_WGRAD_R", "1") != "0"      # =0: the LDS-based weight-gradient kernels of rounds 1-2
 
 
 def x3_eligible(k_dim, rows, ksize):
@@ -510,6 +511,14 @@ def _wgrad(layer, dy, a0, a1=None, with_bias=True):
     a1 = as_act(a1) if a1 is not None else None
     dw = root.gview(layer.weight)
     db = root.gview(layer.bias) if with_bias else None
+    # 3x3 layers on maps that are a multiple of 32 pixels wide: the x3 weight gradient with register-resident operands
+    # (csrc/wgrad_r.hip; bias gradient only in its 16 x 16-channel form: the DeepWT layers)
+    if (X3 and X3_WGRAD and WGRAD_R and layer.k == 3 and
+            ops.wgrad_r_supported(layer.cin, layer.cout, 3, a0.t.shape[1] if a1 is not None else 16, a0.t.shape[3]) and
+            (db is None or (layer.cin % 32 != 0 and layer.cout % 32 != 0))):
+        ops.conv_wgrad_r(dy, a0.t, a1.t if a1 is not None else None, dw, db, a0.pro, _relu_bits(a0, a1), False,
+                         a1.pro if a1 is not None else None)
+        return
     if (X3 and X3_WGRAD and db is None and
             ops.wgrad_x3_supported(layer.cin, layer.cout, layer.k, a0.t.shape[1] if a1 is not None else 8)):
         ops.conv_wgrad_x3(dy, a0.t, a1.t if a1 is not None else None, layer.k, dw, a0.pro, _relu_bits(a0, a1), False,
