@@ -58,6 +58,21 @@ int wtpse_conv_fwd_x3(const float* in0, int C0, const float* in1, int C1, const 
                       const float* pro0, const float* pro1, int pro_relu, float* out0, float* out1, int Csplit, float* stats,
                       int B, int H, int W, int Cout, int ksize, int relu_out, const float* mask_ref, void* stream);
 
+/* A data gradient (= wtpse_conv_fwd / wtpse_conv_fwd_x3 on dY with the `wd` / x3 data-gradient layout: C = the conv's output
+ * channels, Cout = its input channels) that also performs the FIRST HALF of the BatchNorm backward of the conv + BatchNorm
+ * (+ReLU) layer the gradient flows into (autograd of algorithms.py:883-889,904-917): output channels [bn_c0, bn_c1) — all of
+ * them, or exactly one side of the Csplit split — are masked with the ReLU of that layer (bn_relu: [fmaf(bn_y, scale, shift)
+ * > 0], bn_ss [Cbn][2], bn_y [B][Cbn][H][W] = its raw conv output, Cbn = bn_c1 - bn_c0) and the per-workgroup partials
+ * (sum g, sum g * (bn_y - bn_mean)) are written to stats [wtpse_conv_stats_blocks | wtpse_conv_x3_stats_blocks][Cbn][2]:
+ * wtpse_bn_bwd_from_stats finishes the BatchNorm backward without re-reading the two tensors for the reductions.
+ * bn_c0, bn_c1 multiples of 16 (bn_c1 may equal Cout). */
+int wtpse_dgrad_bnb(const float* dy, int C, const float* wpacked, float* out0, float* out1, int Csplit, const float* bn_y,
+                    const float* bn_ss, const float* bn_mean, int bn_relu, int bn_c0, int bn_c1, float* stats, int B, int H, int W,
+                    int Cout, int ksize, void* stream);
+int wtpse_dgrad_x3_bnb(const float* dy, int C, const unsigned short* wpacked, float* out0, float* out1, int Csplit,
+                       const float* bn_y, const float* bn_ss, const float* bn_mean, int bn_relu, int bn_c0, int bn_c1, float* stats,
+                       int B, int H, int W, int Cout, int ksize, void* stream);
+
 /* dW[Cout][C0+C1][k][k] (+)= sum dY * X, dbias (+)= sum dY (dbias/dbias_slab NULL: skip).  slab: [ksplit][Cout*Cin*k*k],
  * dbias_slab: [ksplit][Cout], ksplit = wtpse_wgrad_ksplit(...).  x inputs take the same prologue as the forward. */
 int wtpse_conv_wgrad(const float* dy, const float* x0, int C0, const float* x1, int C1, const float* pro0,
@@ -109,6 +124,12 @@ int wtpse_bn_bwd_apply(const float* dz, const float* y, const float* scale_shift
                        const float* save_mean, const float* save_invstd, const float* sums_local, const float* sums_global,
                        long long count_global, float* coef, float* dgamma, float* dbeta, int accumulate, float* dy, int B,
                        int C, int HW, void* stream);
+/* second half of a BatchNorm backward whose reductions came out of a data gradient's epilogue (wtpse_dgrad_bnb /
+ * wtpse_dgrad_x3_bnb): g = the already-masked incoming gradient, stats_partial [nblk][C][2] = (sum g, sum g * (y - mean))
+ * per workgroup; dgamma / dbeta (+)=, dy = k1 * g + k2 * y + k3.  coef: [C][3] scratch. */
+int wtpse_bn_bwd_from_stats(const float* g, const float* y, const float* stats_partial, int nblk, const float* gamma,
+                            const float* save_mean, const float* save_invstd, float* coef, float* dgamma, float* dbeta,
+                            int accumulate, float* dy, int B, int C, int HW, void* stream);
 
 /* ---- WT (whitening) loss: compute_whitening_loss + compute_MMD (algorithms.py:1277-1309,59-121;
  *      shape_networks.py:561-594,240-309) ------------------------------------------------------------------------ */

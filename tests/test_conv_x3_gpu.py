@@ -202,3 +202,71 @@ def test_conv_wgrad_r(case):
     F.conv2d(xin.double(), w.double(), None, padding=1).backward(dy.double())
     o.conv_wgrad_r(*args, dw, None)
     close(dw, w.grad.double(), rtol=2e-4, atol=2e-5 * max(float(w.grad.abs().max()), 1.0), what="wgrad r, no prologue")
+
+
+@pytest.mark.parametrize("case", [
+    # B, Cl (channels of the BatchNorm'd tensor), Cother (other side of the split, 0: none), bn_second, Cn (next conv's outputs), H, W, k, relu, x3
+    (3, 16, 0, False, 16, 24, 40, 3, True, False),     # 16-channel fp32 path (inc), ragged tiles
+    (2, 32, 0, False, 32, 16, 32, 3, True, False),     # fp32 32-wide path
+    (2, 32, 0, False, 32, 16, 32, 3, False, True),     # x3, no activation (ConvD.conv1)
+    (4, 64, 0, False, 64, 16, 16, 3, True, True),      # x3, 16-wide tiles
+    (20, 64, 0, False, 64, 32, 64, 3, True, True),     # x3, 64-cout blocks
+    (2, 32, 32, True, 64, 12, 36, 3, True, True),      # ConvU.conv3: gradient of a concat, the BatchNorm'd tensor is the second half
+    (2, 16, 16, False, 16, 20, 20, 1, True, False),    # teacher fusion (1x1): the first half
+    (2, 128, 0, False, 64, 8, 8, 1, True, True),       # ConvU.conv2 (1x1) on the x3 path
+])
+def test_dgrad_bnb(case):
+    """Data gradient with the BatchNorm-backward reductions in its epilogue + wtpse_bn_bwd_from_stats, against autograd (fp64)
+    through conv -> BatchNorm(train) [-> ReLU] -> [cat] -> conv, and against the stand-alone path (dgrad, then bn_bwd)."""
+    o = ops()
+    B, Cl, Co, bn_second, Cn, H, W, k, relu, x3 = case
+    y = rnd(B, Cl, H, W, seed=31).double().requires_grad_(True)            # raw conv output of the layer below
+    other = rnd(B, Co, H, W, seed=32).double().requires_grad_(True) if Co else None
+    gamma = (rnd(Cl, seed=33) * 0.2 + 1).double().requires_grad_(True)
+    beta = (rnd(Cl, seed=34) * 0.2).double().requires_grad_(True)
+    w = rnd(Cn, Cl + Co, k, k, seed=35, scale=0.2)
+    du = rnd(B, Cn, H, W, seed=36)
+    z = F.batch_norm(y, None, None, gamma, beta, True, 0.1, 1e-5)
+    on_kink = z.detach().abs() < 2e-6 if relu else torch.zeros_like(z, dtype=torch.bool)
+    if relu:
+        z = F.relu(z)
+    zin = z if other is None else (torch.cat([other, z], 1) if bn_second else torch.cat([z, other], 1))
+    F.conv2d(zin, w.double(), None, padding=k // 2).backward(du.double())
+    # forward-side quantities as the engine has them
+    yd = y.detach().float().to(DEV)
+    mean = yd.double().mean((0, 2, 3))
+    var = yd.double().var((0, 2, 3), unbiased=False)
+    invstd = (1.0 / torch.sqrt(var + 1e-5))
+    g_d, b_d = gamma.detach().float().to(DEV), beta.detach().float().to(DEV)
+    ss = torch.stack([g_d.double() * invstd, b_d.double() - mean * g_d.double() * invstd], 1).float().contiguous()
+    mean_f, invstd_f = mean.float().contiguous(), invstd.float().contiguous()
+    if x3:
+        packed, _, xd = pack_x3(w)
+        wptr = packed.data_ptr() + 2 * xd
+    else:
+        packed, _, wd = pack(w)
+        wptr = packed.data_ptr() + 4 * wd
+    split = None if not Co else (Co if bn_second else Cl)
+    g0, g1, stats = o.dgrad_bnb(du.to(DEV), wptr, x3, Cl + Co, k, yd, ss, mean_f, relu, split, bn_second)
+    g = g1 if (Co and bn_second) else g0
+    dg, dbt = torch.empty(Cl, device=DEV), torch.empty(Cl, device=DEV)
+    dy = o.bn_bwd_from_stats(g, yd, stats, g_d, mean_f, invstd_f, dg, dbt)
+    kz = lambda t: torch.where(on_kink.to(t.device), torch.zeros_like(t), t)
+    assert int(on_kink.sum()) <= max(2, on_kink.numel() // 100000)
+    sc = float(y.grad.abs().max())
+    close(kz(dy), kz(y.grad.float()), rtol=1e-3, atol=2e-4 * sc, what="dy")
+    close(dg, gamma.grad, rtol=1e-3, atol=2e-4 * float(gamma.grad.abs().max()) + 1e-5, what="dgamma")
+    close(dbt, beta.grad, rtol=1e-3, atol=2e-4 * float(beta.grad.abs().max()) + 1e-5, what="dbeta")
+    if Co:
+        close(g0 if bn_second else g1, other.grad, rtol=1e-3, atol=2e-4 * float(other.grad.abs().max()), what="other half")
+    # the stand-alone path: plain data gradient, then the three-kernel BatchNorm backward
+    if x3:
+        d0, d1, _ = o.conv_fwd_x3(du.to(DEV), None, wptr, None, Cl + Co, k, split=split)
+    else:
+        d0, d1, _ = o.conv_fwd(du.to(DEV), None, wptr, None, Cl + Co, k, split=split)
+    dz = d1 if (Co and bn_second) else d0
+    dg2, dbt2 = torch.empty(Cl, device=DEV), torch.empty(Cl, device=DEV)
+    dy2 = o.bn_bwd(dz, yd, ss, relu, g_d, mean_f, invstd_f, dg2, dbt2)
+    close(dy, dy2, rtol=1e-4, atol=2e-5 * sc, what="fused vs stand-alone dy")
+    close(dg, dg2, rtol=1e-4, atol=1e-4 * float(dg2.abs().max()) + 1e-6, what="fused vs stand-alone dgamma")
+    close(dbt, dbt2, rtol=1e-4, atol=1e-4 * float(dbt2.abs().max()) + 1e-6, what="fused vs stand-alone dbeta")

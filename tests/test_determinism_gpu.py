@@ -80,3 +80,62 @@ def test_captured_step_equals_eager_step(mode):
     assert le == lg, (le, lg)
     for x, y in zip(pe + be, pg + bg):
         assert torch.equal(x, y)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("x3,C,H,W,k", [(True, 64, 32, 64, 3), (True, 32, 16, 32, 3), (True, 128, 8, 8, 1), (False, 16, 32, 64, 3),
+                                        (False, 32, 16, 32, 3)])
+def test_dgrad_bnb_repeatable(x3, C, H, W, k):
+    """The data gradient with the BatchNorm-backward epilogue, 150 launches on the same operands with the allocator's blocks
+    dirtied in between: masked gradient and partials must come out bit-identical every time.  (Round 3 found a form of this
+    epilogue — the two ReLU decisions of a register fused into one v_pk_fma_f32 — whose masks were wrong for a few lanes in
+    ~10 % of the launches; this is the regression test.)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_kernels_gpu import rnd, ops, pack, DEV
+    from test_conv_x3_gpu import pack_x3
+    o = ops()
+    B = 20 if H * W >= 2048 else 8
+    y = rnd(B, C, H, W, seed=41).to(DEV)
+    du = rnd(B, C, H, W, seed=42).to(DEV)
+    w = rnd(C, C, k, k, seed=43, scale=0.2)
+    ss = torch.stack([rnd(C, seed=44) * 0.2 + 1.0, rnd(C, seed=45) * 0.3], 1).contiguous().to(DEV)
+    mean = (rnd(C, seed=46) * 0.1).to(DEV)
+    if x3:
+        packed, _, xd = pack_x3(w)
+        wptr = packed.data_ptr() + 2 * xd
+    else:
+        packed, _, wd = pack(w)
+        wptr = packed.data_ptr() + 4 * wd
+    g0, _, st0 = o.dgrad_bnb(du, wptr, x3, C, k, y, ss, mean, True)
+    g0, st0 = g0.clone(), st0.clone()
+    for it in range(150):
+        junk = torch.empty((1 << 22) + 4096 * it, device=DEV).fill_(float(it))
+        g, _, st = o.dgrad_bnb(du, wptr, x3, C, k, y, ss, mean, True)
+        assert torch.equal(g, g0), "launch %d: %d masked-gradient elements differ" % (it, int((g != g0).sum()))
+        assert torch.equal(st, st0), "launch %d: partials differ" % it
+        del junk
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Cin,Cout,H,W,bias", [(16, 16, 64, 64, True), (32, 32, 32, 64, False), (64, 32, 16, 32, False)])
+def test_wgrad_r_repeatable(Cin, Cout, H, W, bias):
+    """The register-resident weight gradient: 100 launches, bit-identical gradients (fixed-order folds, no atomics)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_kernels_gpu import rnd, ops, DEV
+    o = ops()
+    B = 12
+    x = rnd(B, Cin, H, W, seed=51).to(DEV)
+    dy = rnd(B, Cout, H, W, seed=52).to(DEV)
+    pro = torch.stack([rnd(Cin, seed=53) * 0.5 + 1.0, rnd(Cin, seed=54)], 1).contiguous().to(DEV)
+    dw0 = torch.empty(Cout, Cin, 3, 3, device=DEV)
+    db0 = torch.empty(Cout, device=DEV) if bias else None
+    o.conv_wgrad_r(dy, x, None, dw0, db0, pro0=pro, pro_relu=1)
+    for it in range(100):
+        junk = torch.empty((1 << 22) + 4096 * it, device=DEV).fill_(float(it))
+        dw = torch.empty_like(dw0)
+        db = torch.empty_like(db0) if bias else None
+        o.conv_wgrad_r(dy, x, None, dw, db, pro0=pro, pro_relu=1)
+        assert torch.equal(dw, dw0), "launch %d: %d weight-gradient elements differ" % (it, int((dw != dw0).sum()))
+        if bias:
+            assert torch.equal(db, db0), "launch %d: bias gradient differs" % it
+        del junk

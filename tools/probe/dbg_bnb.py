@@ -1,0 +1,65 @@
+import sys
+sys.path[:0]=['/root/repo','/root/repo/wt-pse-code_amd','/root/repo/tests']
+import torch, torch.nn.functional as F
+from test_kernels_gpu import rnd, ops, pack, DEV
+from test_conv_x3_gpu import pack_x3
+o=ops()
+B, Cl, Co, bn_second, Cn, H, W, k, relu, x3 = (20, 64, 0, False, 64, 32, 64, 3, True, True)
+y = rnd(B, Cl, H, W, seed=31).double().requires_grad_(True)
+gamma = (rnd(Cl, seed=33) * 0.2 + 1).double().requires_grad_(True)
+beta = (rnd(Cl, seed=34) * 0.2).double().requires_grad_(True)
+w = rnd(Cn, Cl + Co, k, k, seed=35, scale=0.2)
+du = rnd(B, Cn, H, W, seed=36)
+z0 = F.batch_norm(y, None, None, gamma, beta, True, 0.1, 1e-5)
+z = F.relu(z0)
+F.conv2d(z, w.double(), None, padding=1).backward(du.double())
+yd = y.detach().float().to(DEV)
+mean = yd.double().mean((0, 2, 3)); var = yd.double().var((0, 2, 3), unbiased=False); invstd = 1.0/torch.sqrt(var+1e-5)
+g_d, b_d = gamma.detach().float().to(DEV), beta.detach().float().to(DEV)
+ss = torch.stack([g_d.double()*invstd, b_d.double()-mean*g_d.double()*invstd],1).float().contiguous()
+mean_f, invstd_f = mean.float().contiguous(), invstd.float().contiguous()
+packed,_,xd = pack_x3(w); wptr = packed.data_ptr()+2*xd
+g0,g1,stats = o.dgrad_bnb(du.to(DEV), wptr, True, Cl, k, yd, ss, mean_f, relu, None, False)
+dg, dbt = torch.empty(Cl, device=DEV), torch.empty(Cl, device=DEV)
+dy = o.bn_bwd_from_stats(g0, yd, stats, g_d, mean_f, invstd_f, dg, dbt)
+d0,_,_ = o.conv_fwd_x3(du.to(DEV), None, wptr, None, Cl, k)
+dg2, dbt2 = torch.empty(Cl, device=DEV), torch.empty(Cl, device=DEV)
+dy2 = o.bn_bwd(d0, yd, ss, relu, g_d, mean_f, invstd_f, dg2, dbt2)
+ref = y.grad.float()
+e1=(dy.cpu()-ref).abs(); e2=(dy2.cpu()-ref).abs(); e12=(dy-dy2).abs().cpu()
+print('max err fused', float(e1.max()), 'standalone', float(e2.max()), 'fused vs standalone', float(e12.max()))
+idx=(e1>1e-2).nonzero()
+print(idx.shape)
+for i in idx[:10]:
+    b,c,yy,xx=[int(v) for v in i]
+    print((b,c,yy,xx),'z0',float(z0[b,c,yy,xx]),'zhip',float(torch.addcmul(ss[c,1].cpu(), yd[b,c,yy,xx].cpu(), ss[c,0].cpu())),'dy',float(dy[b,c,yy,xx]),'dy2',float(dy2[b,c,yy,xx]),'ref',float(ref[b,c,yy,xx]), 'g0', float(g0[b,c,yy,xx]), 'd0', float(d0[b,c,yy,xx]))
+
+# ---- stress: is anything nondeterministic?
+torch.cuda.synchronize()
+ref_g, ref_st, ref_dy, ref_d0, ref_dy2 = g0.clone(), stats.clone(), dy.clone(), d0.clone(), dy2.clone()
+junk = torch.empty(1 << 26, device=DEV)
+bad = {"g": 0, "stats": 0, "dy": 0, "d0": 0, "dy2": 0}
+for it in range(300):
+    junk.uniform_(-5, 5)          # dirty the allocator's free blocks between iterations
+    del junk
+    junk = torch.empty((1 << 26) + it * 1024, device=DEV); junk.fill_(float(it))
+    g0_, _, st_ = o.dgrad_bnb(du.to(DEV), wptr, True, Cl, k, yd, ss, mean_f, relu, None, False)
+    dy_ = o.bn_bwd_from_stats(g0_, yd, st_, g_d, mean_f, invstd_f, dg, dbt)
+    d0_, _, _ = o.conv_fwd_x3(du.to(DEV), None, wptr, None, Cl, k)
+    dy2_ = o.bn_bwd(d0_, yd, ss, relu, g_d, mean_f, invstd_f, dg2, dbt2)
+    ns1, ns2 = int(((g0_ >= 12345.0) & (g0_ < 12500.0)).sum()), int((g0_ >= 54321.0).sum())
+    if ns1 or ns2:
+        print("iter", it, "sentinels: LDS params differ from global at", ns1, "elements; loaded y differs at", ns2, flush=True)
+    for name, a_, b_ in (("g", g0_, ref_g), ("stats", st_, ref_st), ("dy", dy_, ref_dy), ("d0", d0_, ref_d0), ("dy2", dy2_, ref_dy2)):
+        n = int((a_ != b_).sum())
+        if n:
+            bad[name] += 1
+            if bad[name] <= 3:
+                i = (a_ != b_).nonzero()[:4].tolist()
+                print("iter", it, name, n, "elements differ, e.g.", i, flush=True)
+                if name == "g":
+                    for q in i:
+                        q = tuple(q)
+                        zh = float(torch.addcmul(ss[q[1], 1].cpu(), yd[q].cpu(), ss[q[1], 0].cpu()))
+                        print("    ", q, "now", float(a_[q]), "first", float(b_[q]), "plain dgrad", float(ref_d0[q]), "z", zh)
+print("nondeterministic iterations of 300:", bad)

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_k(const float* __restrict_
                                                         const float* __restrict__ invstd, float* __restrict__ dgamma,
                                                         float* __restrict__ dbeta, int accumulate,
                                                         float* __restrict__ coef, const float* __restrict__ global_sums,
-                                                        float* __restrict__ sums_out) {
+                                                        float* __restrict__ sums_out, int centred_s2) {
   const int c = blockIdx.x, t = threadIdx.x;
   double s1 = 0.0, s2 = 0.0;
   for (int k = t; k < nsplit; k += 64) {
@@ -154,6 +154,7 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_k(const float* __restrict_
     s1 += __shfl_xor(s1, m, 64);
     s2 += __shfl_xor(s2, m, 64);
   }
+  if (centred_s2) s2 *= (double)invstd[c];     // partials of a data-gradient epilogue: sum g * (y - mean), not yet / std
   if (t == 0) {
     if (sums_out) {
       sums_out[2 * c] = (float)s1;
@@ -341,7 +342,7 @@ extern "C" int wtpse_bn_bwd(const float* dz, const float* y, const float* scale_
     hipLaunchKernelGGL(bn_bwd_reduce_k<false>, dim3(C, ns), dim3(256), 0, st, dz, y, scale_shift, relu, save_mean,
                        save_invstd, B, C, HW, partial);
   hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(C), dim3(64), 0, st, partial, ns, C, (double)B * HW, gamma, save_mean,
-                     save_invstd, dgamma, dbeta, accumulate, coef, (const float*)nullptr, (float*)nullptr);
+                     save_invstd, dgamma, dbeta, accumulate, coef, (const float*)nullptr, (float*)nullptr, 0);
   if (vec_ok(HW, dz, y, dy))
     hipLaunchKernelGGL(bn_bwd_apply_k<true>, dim3(ceil_div(HW, 1024) * B * C), dim3(256), 0, st, dz, y, scale_shift,
                        relu, coef, C, HW, ceil_div(HW, 1024), dy);
@@ -367,7 +368,7 @@ extern "C" int wtpse_bn_bwd_reduce(const float* dz, const float* y, const float*
     hipLaunchKernelGGL(bn_bwd_reduce_k<false>, dim3(C, ns), dim3(256), 0, st, dz, y, scale_shift, relu, save_mean,
                        save_invstd, B, C, HW, partial);
   hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(C), dim3(64), 0, st, partial, ns, C, 1.0, (const float*)nullptr, save_mean,
-                     save_invstd, (float*)nullptr, (float*)nullptr, 0, (float*)nullptr, (const float*)nullptr, sums_local);
+                     save_invstd, (float*)nullptr, (float*)nullptr, 0, (float*)nullptr, (const float*)nullptr, sums_local, 0);
   return wtpse_status();
 }
 
@@ -380,12 +381,33 @@ extern "C" int wtpse_bn_bwd_apply(const float* dz, const float* y, const float* 
   hipStream_t st = (hipStream_t)stream;
   // sums_local viewed as a 1-slab partial: [1][C][2]
   hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(C), dim3(64), 0, st, sums_local, 1, C, (double)count_global, gamma, save_mean,
-                     save_invstd, dgamma, dbeta, accumulate, coef, sums_global, (float*)nullptr);
+                     save_invstd, dgamma, dbeta, accumulate, coef, sums_global, (float*)nullptr, 0);
   if (vec_ok(HW, dz, y, dy))
     hipLaunchKernelGGL(bn_bwd_apply_k<true>, dim3(ceil_div(HW, 1024) * B * C), dim3(256), 0, st, dz, y, scale_shift,
                        relu, coef, C, HW, ceil_div(HW, 1024), dy);
   else
     hipLaunchKernelGGL(bn_bwd_apply_k<false>, dim3(ceil_div(HW, 256) * B * C), dim3(256), 0, st, dz, y, scale_shift,
                        relu, coef, C, HW, ceil_div(HW, 256), dy);
+  return wtpse_status();
+}
+
+// Second half of a BatchNorm backward whose reductions were formed in the epilogue of the data gradient that produced the
+// incoming gradient (wtpse_dgrad_bnb / wtpse_dgrad_x3_bnb): g = dz * [z > 0] already masked, stats_partial[nblk][C][2] =
+// per-workgroup (sum g, sum g * (y - mean)).  dgamma / dbeta, then dy = k1 * g + k2 * y + k3 in one elementwise pass.
+extern "C" int wtpse_bn_bwd_from_stats(const float* g, const float* y, const float* stats_partial, int nblk, const float* gamma,
+                                       const float* save_mean, const float* save_invstd, float* coef, float* dgamma, float* dbeta,
+                                       int accumulate, float* dy, int B, int C, int HW, void* stream) {
+  WTPSE_REQUIRE(g && y && stats_partial && gamma && save_mean && save_invstd && coef && dgamma && dbeta && dy);
+  WTPSE_REQUIRE(nblk > 0 && B > 0 && C > 0 && HW > 0);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(C), dim3(64), 0, st, stats_partial, nblk, C, (double)B * HW, gamma, save_mean,
+                     save_invstd, dgamma, dbeta, accumulate, coef, (const float*)nullptr, (float*)nullptr, 1);
+  // (the scale/shift operand is only read for the ReLU mask: relu = 0 here, the coefficients stand in for it)
+  if (vec_ok(HW, g, y, dy))
+    hipLaunchKernelGGL(bn_bwd_apply_k<true>, dim3(ceil_div(HW, 1024) * B * C), dim3(256), 0, st, g, y, coef, 0, coef, C, HW,
+                       ceil_div(HW, 1024), dy);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_k<false>, dim3(ceil_div(HW, 256) * B * C), dim3(256), 0, st, g, y, coef, 0, coef, C, HW,
+                       ceil_div(HW, 256), dy);
   return wtpse_status();
 }

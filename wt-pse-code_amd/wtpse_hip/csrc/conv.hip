@@ -38,6 +38,12 @@ struct ConvArgs {
   float* stats;        // [gridDim.x][Cout][2] or null
   const float* mask;   // [B][Cout][H][W] or null: out = mask > 0 ? value : 0 (ReLU backward fused into a data gradient)
   float* gram;         // [gridDim.x][16][16] or null (16-cout path): the tile's partial Gram  sum_px out[i][px] * out[j][px]
+  // EPI == 2 (BatchNorm backward statistics in a data gradient's epilogue, see conv_x3.hip): output channels [bn_c0, bn_c1) are
+  // masked with the ReLU of the conv + BatchNorm layer they flow into (raw conv output: `mask`, [B][bn_c1 - bn_c0][H][W]) and
+  // (sum g, sum g * (y - mean)) partials go to `stats`
+  const float* bn_ss;
+  const float* bn_mean;
+  int bn_c0, bn_c1, bn_relu;
   int B, H, W;
   int C0, C1, Cin, CinP;
   int Cout, CoutP, Csplit;
@@ -71,8 +77,9 @@ struct PlaneStride {  // smallest S >= PE with S % 32 == 16: the four k-planes a
 // __launch_bounds__(256, 3): at least 3 workgroups per CU (<= 168 registers per lane, accumulators included)
 // MASK is a template parameter, not a run-time test of a.mask: s_waitcnt operands are static, so the waits the mask
 // loads need would also be executed (and drain earlier stores) by launches without a mask.
-template <int KS, int MODE, int TWL, bool DB, bool MASK>
+template <int KS, int MODE, int TWL, bool DB, int EPI>
 __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
+  constexpr bool MASK = EPI == 1, BNB = EPI == 2;
   constexpr int TAPS = KS * KS, PAD = KS / 2;
   constexpr int TW = 1 << TWL, TH = 256 / TW;
   constexpr int PITCH = TW + 2 * PAD, ROWS = TH + 2 * PAD;
@@ -97,8 +104,9 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
   constexpr int GRAM_SZ = (P16 && KS == 3) ? 4 * 16 * 65 + 4 * 256 : 0;   // wave-private [16 ch][64 px (+1)] tiles + 4 partial Grams
   constexpr int RED_SZ = 4 * CB * 2 > GRAM_SZ ? 4 * CB * 2 : GRAM_SZ;
   constexpr int MAIN_SZ = (XS_SZ + WS_SZ) > RED_SZ ? (XS_SZ + WS_SZ) : RED_SZ;
-  __shared__ __attribute__((aligned(16))) float smem[MAIN_SZ + CB];
+  __shared__ __attribute__((aligned(16))) float smem[MAIN_SZ + CB + (BNB ? 4 * CB : 0)];
   float* bias_s = smem + MAIN_SZ;   // this block's biases (written here, visible after the first barrier of the chunk loop)
+  const float* bnp_s = bias_s + CB; // EPI 2: [3][CB] (scale | shift | mean) of the BatchNorm'd output channels, (0, 1, 0) elsewhere
   float* Xs = smem;
   float* Ws = smem + XS_SZ;
 
@@ -111,6 +119,14 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
   const int cout0 = blockIdx.y * CB;
   const int HW = a.H * a.W;
   if (tid < CB) bias_s[tid] = (a.bias && cout0 + tid < a.Cout) ? a.bias[cout0 + tid] : 0.f;
+  if (BNB && tid < CB) {
+    const int c = cout0 + tid;
+    const bool bn = c >= a.bn_c0 && c < a.bn_c1;
+    float* q = bias_s + CB + tid;          // three planes [scale | shift | mean] of CB floats
+    q[0] = (bn && a.bn_relu) ? a.bn_ss[2 * (c - a.bn_c0)] : 0.f;
+    q[CB] = (bn && a.bn_relu) ? a.bn_ss[2 * (c - a.bn_c0) + 1] : 1.f;
+    q[2 * CB] = bn ? a.bn_mean[c - a.bn_c0] : 0.f;
+  }
 
   int off[NT];
 #pragma unroll
@@ -281,7 +297,9 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
   // (voffset >= num_records - soffset).
   const __amdgpu_buffer_rsrc_t rs_o0 = make_rsrc(a.out0 + (size_t)b * a.Csplit * HW, (unsigned)a.Csplit * HW * 4u);
   const __amdgpu_buffer_rsrc_t rs_o1 = a.out1 ? make_rsrc(a.out1 + (size_t)b * C1out * HW, (unsigned)C1out * HW * 4u) : rs_o0;
-  const __amdgpu_buffer_rsrc_t rs_m = MASK ? make_rsrc(a.mask + (size_t)b * a.Cout * HW, (unsigned)a.Cout * HW * 4u) : rs_o0;
+  const int Cbn = a.bn_c1 - a.bn_c0;
+  const __amdgpu_buffer_rsrc_t rs_m = MASK ? make_rsrc(a.mask + (size_t)b * a.Cout * HW, (unsigned)a.Cout * HW * 4u)
+                                      : BNB ? make_rsrc(a.mask + (size_t)b * Cbn * HW, (unsigned)Cbn * HW * 4u) : rs_o0;
   const int clane = P16 ? (lane >> 4) * 4 : (lane >> 5) * 4;   // channel offset of this lane within a register's group
   const float relu_lo = a.relu_out ? 0.f : -INFINITY;
   unsigned pvo[NT];
@@ -345,6 +363,19 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
         for (int nt = 0; nt < NT; ++nt) mk[r][nt] = buf_load(rs_m, pvo[nt], (unsigned)min(cbase, a.Cout) * hw4);
       }
     }
+    if (BNB) {
+      // whether a register belongs to the BatchNorm'd tensor is wave-uniform (bn_c0 / bn_c1 multiples of 16); the others load
+      // out of range (0)
+#pragma unroll
+      for (int r = 0; r < NACC; ++r) {
+        const int cbase = cout0 + (P16 ? r : (mt * 32 + (r & 3) + 8 * (r >> 2)));
+        const bool bn = cbase >= a.bn_c0 && cbase < a.bn_c1;
+        const unsigned soff = (unsigned)(bn ? cbase - a.bn_c0 : 0) * hw4;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) mk[r][nt] = buf_load(rs_m, bn ? pvo[nt] : BUF_OOB, soff);
+      }
+    }
+    float bmu[NACC];
 #pragma unroll
     for (int r = 0; r < NACC; ++r) {
       // the channels one register holds across the wave lie in one aligned group of 8 (16 on the 16-wide path) and
@@ -354,10 +385,24 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
       const __amdgpu_buffer_rsrc_t rs_o = second ? rs_o1 : rs_o0;
       // min(): soffset stays <= num_records for the zero-padded channels past Cout, so num_records - soffset cannot wrap
       const unsigned soff = (unsigned)(second ? min(cbase, a.Cout) - a.Csplit : min(cbase, a.Csplit)) * hw4;
+      float bsc = 0.f, bsh = 1.f;
+      bmu[r] = 0.f;
+      if (BNB) {
+        const int crel = (P16 ? r : (mt * 32 + (r & 3) + 8 * (r >> 2))) + clane;
+        bsc = bnp_s[crel];
+        bsh = bnp_s[CB + crel];
+        bmu[r] = bnp_s[2 * CB + crel];
+      }
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         float v = fmaxf(acc[mt][nt][r], relu_lo);
         if (MASK && !(mk[r][nt] > 0.f)) v = 0.f;
+        if (BNB) {     // the ReLU decision of the forward pass: fmaf(y, scale, shift) > 0
+          float zz = __builtin_fmaf(mk[r][nt], bsc, bsh);
+          asm volatile("" : "+v"(zz));     // no v_pk_fma_f32 here: see x3_epilogue (conv_x3.hip)
+          if (!(zz > 0.f)) v = 0.f;
+          acc[mt][nt][r] = v;
+        }
         buf_store(rs_o, pvo[nt], soff, v);
       }
     }
@@ -369,9 +414,15 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
 #pragma clang fp contract(off)   // square, then add: the partials must not depend on which pairs the compiler fuses
-          const float v = fmaxf(acc[mt][nt][r], relu_lo);   // statistics are never combined with a ReLU mask (host check)
-          s1 += v;
-          s2 += v * v;
+          if (BNB) {
+            const float v = acc[mt][nt][r];
+            s1 += v;
+            s2 += v * (mk[r][nt] - bmu[r]);
+          } else {
+            const float v = fmaxf(acc[mt][nt][r], relu_lo);   // forward statistics are never combined with a ReLU mask (host check)
+            s1 += v;
+            s2 += v * v;
+          }
         }
         sv[r * 2 + 0] = s1;
         sv[r * 2 + 1] = s2;
@@ -411,8 +462,11 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
     __syncthreads();
     if (tid < CB * 2) {
       int crel = tid >> 1;
-      if (cout0 + crel < a.Cout) {
-        float s = red[tid] + red[CB * 2 + tid] + red[2 * CB * 2 + tid] + red[3 * CB * 2 + tid];
+      const float s = red[tid] + red[CB * 2 + tid] + red[2 * CB * 2 + tid] + red[3 * CB * 2 + tid];
+      if (BNB) {
+        const int c = cout0 + crel;
+        if (c >= a.bn_c0 && c < a.bn_c1) a.stats[((size_t)blockIdx.x * Cbn + c - a.bn_c0) * 2 + (tid & 1)] = s;
+      } else if (cout0 + crel < a.Cout) {
         a.stats[((size_t)blockIdx.x * a.Cout + cout0 + crel) * 2 + (tid & 1)] = s;
       }
     }
@@ -420,7 +474,7 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
   STAMP(61);
 }
 
-template <int KS, int MODE, bool DB, bool MASK>
+template <int KS, int MODE, bool DB, int EPI>
 static int launch_fwd(const ConvArgs& a, hipStream_t st) {
   constexpr int CB = MODE == 0 ? 16 : 32 * MODE;
   ConvArgs args = a;
@@ -430,9 +484,9 @@ static int launch_fwd(const ConvArgs& a, hipStream_t st) {
   args.tiles_y = ceil_div(a.H, TH);
   dim3 grid((unsigned)(a.B * args.tiles_x * args.tiles_y), (unsigned)ceil_div(a.CoutP, CB));
   if (narrow)
-    hipLaunchKernelGGL((conv_fwd_k<KS, MODE, 4, DB, MASK>), grid, dim3(256), 0, st, args);
+    hipLaunchKernelGGL((conv_fwd_k<KS, MODE, 4, DB, EPI>), grid, dim3(256), 0, st, args);
   else
-    hipLaunchKernelGGL((conv_fwd_k<KS, MODE, 5, DB, MASK>), grid, dim3(256), 0, st, args);
+    hipLaunchKernelGGL((conv_fwd_k<KS, MODE, 5, DB, EPI>), grid, dim3(256), 0, st, args);
   return wtpse_status();
 }
 
@@ -446,20 +500,30 @@ extern "C" int wtpse_conv_stats_blocks(int B, int H, int W) {
   return B * ceil_div(W, TW) * ceil_div(H, TH);
 }
 
+struct BnbArgs {   // EPI 2 parameters of conv_fwd_impl (all null / 0: none)
+  const float* ss;
+  const float* mean;
+  int relu, c0, c1;
+};
+
 static int conv_fwd_impl(const float* in0, int C0, const float* in1, int C1, const float* wpacked, const float* bias,
                          const float* pro0, const float* pro1, int pro_relu, float* out0, float* out1, int Csplit, float* stats,
                          int B, int H, int W, int Cout, int ksize, int relu_out, const float* mask_ref, float* gram,
-                         void* stream) {
+                         void* stream, BnbArgs bn = BnbArgs{nullptr, nullptr, 0, 0, 0}) {
   WTPSE_REQUIRE(in0 && wpacked && out0 && B > 0 && H > 0 && W > 0 && C0 > 0 && C1 >= 0 && Cout > 0);
   WTPSE_REQUIRE(ksize == 1 || ksize == 3);
   WTPSE_REQUIRE((C1 == 0) == (in1 == nullptr));
   WTPSE_REQUIRE(Csplit > 0 && Csplit <= Cout && ((Csplit == Cout) == (out1 == nullptr)));
   WTPSE_REQUIRE(Csplit == Cout || Csplit % 16 == 0);   // the epilogue picks the output tensor per register, not per lane
   WTPSE_REQUIRE(!(stats && relu_out));
-  WTPSE_REQUIRE(!(stats && mask_ref));
-  WTPSE_REQUIRE(!(mask_ref && out1));
+  const bool bnb = bn.mean != nullptr;
+  WTPSE_REQUIRE(bnb || !(stats && mask_ref));
+  WTPSE_REQUIRE(bnb || !(mask_ref && out1));
+  WTPSE_REQUIRE(!bnb || (mask_ref && stats && bn.ss && !bias && !relu_out && !gram && bn.c0 >= 0 && bn.c0 < bn.c1 && bn.c1 <= Cout &&
+                         bn.c0 % 16 == 0 && (bn.c1 % 16 == 0 || bn.c1 == Cout)));
   WTPSE_REQUIRE(C1 == 0 || C0 % 16 == 0);   // a channel chunk must not straddle the two inputs
   ConvArgs a;
+  a.bn_ss = bn.ss; a.bn_mean = bn.mean; a.bn_relu = bn.relu; a.bn_c0 = bnb ? bn.c0 : 0; a.bn_c1 = bnb ? bn.c1 : 0;
   a.in0 = in0; a.in1 = in1; a.wp = wpacked; a.bias = bias; a.pro0 = pro0; a.pro1 = pro1; a.out0 = out0; a.out1 = out1; a.stats = stats; a.mask = mask_ref; a.gram = gram;
   a.B = B; a.H = H; a.W = W; a.C0 = C0; a.C1 = C1; a.Cin = C0 + C1; a.CinP = (a.Cin + 3) & ~3;
   a.Cout = Cout; a.CoutP = (Cout + 15) & ~15; a.Csplit = Csplit; a.pro_relu = pro_relu; a.relu_out = relu_out;
@@ -473,8 +537,9 @@ static int conv_fwd_impl(const float* in0, int C0, const float* in1, int C1, con
   if (mode == 1 && tiles * ceil_div(a.CoutP, 32) < 384) mode = 0;   // still under two workgroups per CU: 16-cout blocks
   const int cb = mode == 0 ? 16 : 32 * mode;
   const bool db = tiles * ceil_div(a.CoutP, cb) < 768 && a.CinP > (mode == 0 ? WTPSE_P16_KC(ksize) : 8);
-#define FWD(KS, M) (mask_ref ? (db ? launch_fwd<KS, M, true, true>(a, st) : launch_fwd<KS, M, false, true>(a, st)) \
-                         : (db ? launch_fwd<KS, M, true, false>(a, st) : launch_fwd<KS, M, false, false>(a, st)))
+#define FWD(KS, M) (bnb ? (db ? launch_fwd<KS, M, true, 2>(a, st) : launch_fwd<KS, M, false, 2>(a, st)) \
+                    : mask_ref ? (db ? launch_fwd<KS, M, true, 1>(a, st) : launch_fwd<KS, M, false, 1>(a, st)) \
+                               : (db ? launch_fwd<KS, M, true, 0>(a, st) : launch_fwd<KS, M, false, 0>(a, st)))
   if (ksize == 3) {
     if (mode == 0) return FWD(3, 0);
     if (mode == 1) return FWD(3, 1);
@@ -493,6 +558,15 @@ extern "C" int wtpse_conv_fwd(const float* in0, int C0, const float* in1, int C1
                               const float* mask_ref, void* stream) {
   return conv_fwd_impl(in0, C0, in1, C1, wpacked, bias, pro0, pro1, pro_relu, out0, out1, Csplit, stats, B, H, W, Cout, ksize,
                        relu_out, mask_ref, nullptr, stream);
+}
+
+// Data gradient that also performs the first half of the BatchNorm backward of the layer it flows into (include/wtpse_hip.h).
+extern "C" int wtpse_dgrad_bnb(const float* dy, int C, const float* wpacked, float* out0, float* out1, int Csplit,
+                               const float* bn_y, const float* bn_ss, const float* bn_mean, int bn_relu, int bn_c0, int bn_c1,
+                               float* stats, int B, int H, int W, int Cout, int ksize, void* stream) {
+  WTPSE_REQUIRE(bn_y && bn_ss && bn_mean && stats);
+  return conv_fwd_impl(dy, C, nullptr, 0, wpacked, nullptr, nullptr, nullptr, 0, out0, out1, Csplit, stats, B, H, W, Cout, ksize, 0,
+                       bn_y, nullptr, stream, BnbArgs{bn_ss, bn_mean, bn_relu, bn_c0, bn_c1});
 }
 
 // 3x3 convolution with exactly 16 output channels that also emits the per-tile partial Grams of its output

@@ -45,6 +45,12 @@ struct ConvX3Args {
   float* out1;
   float* stats;
   const float* mask;
+  // EPI == 2 (BatchNorm backward statistics in a data gradient's epilogue): output channels [bn_c0, bn_c1) are the gradient
+  // wrt the activated output of a conv + BatchNorm (+ReLU) layer whose raw conv output is `mask` ([B][bn_c1 - bn_c0][H][W]):
+  // they are masked with [mask * scale + shift > 0] (bn_relu) and (sum g, sum g * (y - mean)) partials go to `stats`
+  const float* bn_ss;         // [bn_c1 - bn_c0][2]
+  const float* bn_mean;       // [bn_c1 - bn_c0]
+  int bn_c0, bn_c1, bn_relu;
   int B, H, W;
   int C0, C1, Cin, CinP;      // CinP: multiple of 16
   int Cout, CoutP, Csplit;    // CoutP: multiple of 32
@@ -78,11 +84,15 @@ __device__ __forceinline__ void split3_pair(float a, float b, unsigned& p0, unsi
 // Epilogue shared by the x3 forward kernels (as conv.hip): + bias, ReLU / ReLU mask, branch-free buffer stores, BatchNorm
 // (sum, sum^2) partials into row `stats_row`.  `tid` counts within the 256 threads that own the tile; `live` = false drops
 // every store (a padding tile).
-template <int MT, int NT, int TWL, bool MASK, bool RED_ALIASES>
+// EPI: 0 plain, 1 ReLU mask (out = mask > 0 ? value : 0), 2 BatchNorm-backward statistics (ConvX3Args::bn_*): the gradient is
+// masked with the ReLU of the layer it flows into and the two reductions of that layer's BatchNorm backward (reference
+// algorithms.py:883-889 via autograd) are formed from the accumulators, so bn_bwd_reduce_k never re-reads the two tensors.
+template <int MT, int NT, int TWL, int EPI, bool RED_ALIASES>
 __device__ __forceinline__ void x3_epilogue(const ConvX3Args& a, f32x16 (&acc)[MT][NT], int b, int ty, int tx, int cout0, int tid,
                                             float* red, const float* bias_s, int stats_row, bool live) {
   constexpr int TW = 1 << TWL, TH = (128 * NT) / TW;
   constexpr int CB = 32 * MT, NACC = 16;
+  constexpr bool MASK = EPI == 1, BNB = EPI == 2;
   const int lane = tid & 63, wave = tid >> 6;
   const int r32 = lane & 31, h = lane >> 5;
   const int HW = a.H * a.W;
@@ -97,8 +107,10 @@ __device__ __forceinline__ void x3_epilogue(const ConvX3Args& a, f32x16 (&acc)[M
       }
   }
   const bool want_stats = a.stats != nullptr;
+  const float* bnp_s = bias_s + CB;                   // EPI 2: [3][CB] (scale | shift | mean) of this block's channels
   if (want_stats && RED_ALIASES) __syncthreads();   // red[4 waves][CB][2] reuses the operand images
   const int C1out = a.Cout - a.Csplit;
+  const int Cbn = a.bn_c1 - a.bn_c0;
   int poff[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
@@ -108,7 +120,8 @@ __device__ __forceinline__ void x3_epilogue(const ConvX3Args& a, f32x16 (&acc)[M
   }
   const __amdgpu_buffer_rsrc_t rs_o0 = make_rsrc(a.out0 + (size_t)b * a.Csplit * HW, (unsigned)a.Csplit * HW * 4u);
   const __amdgpu_buffer_rsrc_t rs_o1 = a.out1 ? make_rsrc(a.out1 + (size_t)b * C1out * HW, (unsigned)C1out * HW * 4u) : rs_o0;
-  const __amdgpu_buffer_rsrc_t rs_m = MASK ? make_rsrc(a.mask + (size_t)b * a.Cout * HW, (unsigned)a.Cout * HW * 4u) : rs_o0;
+  const __amdgpu_buffer_rsrc_t rs_m = MASK ? make_rsrc(a.mask + (size_t)b * a.Cout * HW, (unsigned)a.Cout * HW * 4u)
+                                      : BNB ? make_rsrc(a.mask + (size_t)b * Cbn * HW, (unsigned)Cbn * HW * 4u) : rs_o0;
   const int clane = h * 4;
   const float relu_lo = a.relu_out ? 0.f : -INFINITY;
   unsigned pvo[NT];
@@ -138,16 +151,46 @@ __device__ __forceinline__ void x3_epilogue(const ConvX3Args& a, f32x16 (&acc)[M
         for (int nt = 0; nt < NT; ++nt) mk[r][nt] = buf_load(rs_m, pvo[nt], (unsigned)min(cbase, a.Cout) * hw4);
       }
     }
+    if (BNB) {
+      // the channels one register holds across the wave lie in one aligned group of 8 and bn_c0 / bn_c1 are multiples of 16:
+      // whether a register belongs to the BatchNorm'd tensor is wave-uniform; the others load out of range (0)
+#pragma unroll
+      for (int r = 0; r < NACC; ++r) {
+        const int cbase = cout0 + mt * 32 + (r & 3) + 8 * (r >> 2);
+        const bool bn = cbase >= a.bn_c0 && cbase < a.bn_c1;
+        const unsigned soff = (unsigned)(bn ? cbase - a.bn_c0 : 0) * hw4;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) mk[r][nt] = buf_load(rs_m, bn ? pvo[nt] : BUF_OOB, soff);
+      }
+    }
+    float bmu[NACC];
 #pragma unroll
     for (int r = 0; r < NACC; ++r) {
       const int cbase = cout0 + mt * 32 + (r & 3) + 8 * (r >> 2);
       const bool second = a.out1 != nullptr && cbase >= a.Csplit;
       const __amdgpu_buffer_rsrc_t rs_o = second ? rs_o1 : rs_o0;
       const unsigned soff = (unsigned)(second ? min(cbase, a.Cout) - a.Csplit : min(cbase, a.Csplit)) * hw4;
+      float bsc = 0.f, bsh = 1.f;
+      bmu[r] = 0.f;
+      if (BNB) {
+        const int crel = mt * 32 + (r & 3) + 8 * (r >> 2) + clane;
+        bsc = bnp_s[crel];
+        bsh = bnp_s[CB + crel];
+        bmu[r] = bnp_s[2 * CB + crel];
+      }
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         float v = fmaxf(acc[mt][nt][r], relu_lo);
         if (MASK && !(mk[r][nt] > 0.f)) v = 0.f;
+        if (BNB) {     // the ReLU decision of the forward pass: fmaf(y, scale, shift) > 0 (channels outside [bn_c0, bn_c1): 0, 1)
+          // (opaque to the vectoriser on purpose: with the two pixels' decisions fused into one v_pk_fma_f32 the masks of a few
+          // lanes of the upper half-wave came out wrong in ~10 % of the launches — tools/probe/dbg_bnb.py; scalar
+          // v_fma_f32 has been bitwise reproducible over thousands of launches)
+          float zz = __builtin_fmaf(mk[r][nt], bsc, bsh);
+          asm volatile("" : "+v"(zz));
+          if (!(zz > 0.f)) v = 0.f;
+          acc[mt][nt][r] = v;
+        }
         buf_store(rs_o, pvo[nt], soff, v);
       }
     }
@@ -159,9 +202,15 @@ __device__ __forceinline__ void x3_epilogue(const ConvX3Args& a, f32x16 (&acc)[M
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
 #pragma clang fp contract(off)
-          const float v = fmaxf(acc[mt][nt][r], relu_lo);
-          s1 += v;
-          s2 += v * v;
+          if (BNB) {
+            const float v = acc[mt][nt][r];
+            s1 += v;
+            s2 += v * (mk[r][nt] - bmu[r]);
+          } else {
+            const float v = fmaxf(acc[mt][nt][r], relu_lo);
+            s1 += v;
+            s2 += v * v;
+          }
         }
         sv[r * 2 + 0] = s1;
         sv[r * 2 + 1] = s2;
@@ -196,8 +245,11 @@ __device__ __forceinline__ void x3_epilogue(const ConvX3Args& a, f32x16 (&acc)[M
     __syncthreads();
     if (tid < CB * 2) {
       const int crel = tid >> 1;
-      if (live && cout0 + crel < a.Cout) {
-        const float s = red[tid] + red[CB * 2 + tid] + red[2 * CB * 2 + tid] + red[3 * CB * 2 + tid];
+      const float s = red[tid] + red[CB * 2 + tid] + red[2 * CB * 2 + tid] + red[3 * CB * 2 + tid];
+      if (BNB) {
+        const int c = cout0 + crel;
+        if (live && c >= a.bn_c0 && c < a.bn_c1) a.stats[((size_t)stats_row * Cbn + c - a.bn_c0) * 2 + (tid & 1)] = s;
+      } else if (live && cout0 + crel < a.Cout) {
         a.stats[((size_t)stats_row * a.Cout + cout0 + crel) * 2 + (tid & 1)] = s;
       }
     }
@@ -206,7 +258,7 @@ __device__ __forceinline__ void x3_epilogue(const ConvX3Args& a, f32x16 (&acc)[M
 
 // NT = 32-pixel column tiles per wave: 2 (256-pixel workgroup tile) or 1 (128 pixels: twice the workgroups for the 16x16
 // maps, whose 256-pixel tiles would leave one workgroup per CU with nothing to overlap its loader phases with)
-template <int KS, int MT, int TWL, bool MASK, int NT = 2>
+template <int KS, int MT, int TWL, int EPI, int NT = 2>
 __global__ __launch_bounds__(256, 2) void conv_x3_k(ConvX3Args a) {
   constexpr int TAPS = KS * KS, PAD = KS / 2;
   constexpr int TW = 1 << TWL, TH = (128 * NT) / TW;
@@ -221,7 +273,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_k(ConvX3Args a) {
   constexpr int NW = (WS_U4 + 255) / 256;          // 16-byte weight loads per thread and kernel row
   constexpr int RED_F = 4 * CB * 2;
   constexpr int MAIN_U4 = (XS_U4 + 2 * WS_U4) > (RED_F + 3) / 4 ? (XS_U4 + 2 * WS_U4) : (RED_F + 3) / 4;
-  __shared__ u32x4v smem[MAIN_U4 + CB / 4];
+  __shared__ u32x4v smem[MAIN_U4 + CB / 4 + (EPI == 2 ? CB : 0)];
   u32x4v* Xs = smem;
   u32x4v* Ws = smem + XS_U4;
   float* bias_s = reinterpret_cast<float*>(smem + MAIN_U4);
@@ -236,6 +288,14 @@ __global__ __launch_bounds__(256, 2) void conv_x3_k(ConvX3Args a) {
   const int cout0 = blockIdx.y * CB;
   const int HW = a.H * a.W;
   if (tid < CB) bias_s[tid] = (a.bias && cout0 + tid < a.Cout) ? a.bias[cout0 + tid] : 0.f;
+  if (EPI == 2 && tid < CB) {                     // (scale, shift, mean) of the BatchNorm'd output channels; (0, 1, 0) elsewhere
+    const int c = cout0 + tid;
+    const bool bn = c >= a.bn_c0 && c < a.bn_c1;
+    float* q = bias_s + CB + tid;          // three planes [scale | shift | mean] of CB floats
+    q[0] = (bn && a.bn_relu) ? a.bn_ss[2 * (c - a.bn_c0)] : 0.f;
+    q[CB] = (bn && a.bn_relu) ? a.bn_ss[2 * (c - a.bn_c0) + 1] : 1.f;
+    q[2 * CB] = bn ? a.bn_mean[c - a.bn_c0] : 0.f;
+  }
 
   int off[NT];                                    // halo position of this lane's pixel (tap 0,0 corner)
 #pragma unroll
@@ -440,7 +500,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_k(ConvX3Args a) {
   }
 
   XSTAMP(60);
-  x3_epilogue<MT, NT, TWL, MASK, true>(a, acc, b, ty, tx, cout0, tid, reinterpret_cast<float*>(smem), bias_s, (int)blockIdx.x, true);
+  x3_epilogue<MT, NT, TWL, EPI, true>(a, acc, b, ty, tx, cout0, tid, reinterpret_cast<float*>(smem), bias_s, (int)blockIdx.x, true);
   XSTAMP(61);
   XSTAMPV(59, __builtin_amdgcn_s_memrealtime());
   XSTAMPV(62, (unsigned long long)nchunks);
@@ -495,7 +555,7 @@ static bool x3_small_tiles(int B, int H, int W, int CoutP, bool mt2) {
   return B * ceil_div(H, 16) * ceil_div(W, 16) * (CoutP / 32) < 512;
 }
 
-template <int KS, int MT, bool MASK>
+template <int KS, int MT, int EPI>
 static int launch_x3(const ConvX3Args& a, hipStream_t st) {
   ConvX3Args args = a;
   const bool narrow = a.W <= 16;
@@ -505,11 +565,11 @@ static int launch_x3(const ConvX3Args& a, hipStream_t st) {
   args.tiles_y = ceil_div(a.H, TH);
   dim3 grid((unsigned)(a.B * args.tiles_x * args.tiles_y), (unsigned)ceil_div(a.CoutP, 32 * MT));
   if (small) {
-    if constexpr (MT == 1) hipLaunchKernelGGL((conv_x3_k<KS, 1, 4, MASK, 1>), grid, dim3(256), 0, st, args);
+    if constexpr (MT == 1) hipLaunchKernelGGL((conv_x3_k<KS, 1, 4, EPI, 1>), grid, dim3(256), 0, st, args);
   } else if (narrow)
-    hipLaunchKernelGGL((conv_x3_k<KS, MT, 4, MASK>), grid, dim3(256), 0, st, args);
+    hipLaunchKernelGGL((conv_x3_k<KS, MT, 4, EPI>), grid, dim3(256), 0, st, args);
   else
-    hipLaunchKernelGGL((conv_x3_k<KS, MT, 5, MASK>), grid, dim3(256), 0, st, args);
+    hipLaunchKernelGGL((conv_x3_k<KS, MT, 5, EPI>), grid, dim3(256), 0, st, args);
   return wtpse_status();
 }
 
@@ -532,33 +592,55 @@ extern "C" int wtpse_conv_x3_stats_blocks(int B, int H, int W, int Cout) {
   return B * ceil_div(W, TW) * ceil_div(H, TH);
 }
 
-// Same contract as wtpse_conv_fwd (include/wtpse_hip.h) with `wpacked` in the x3 layout.  Cout <= 16 runs on a 32-row
-// tile with the upper rows idle (zero weights, stores dropped by the range check): the bf16 MFMAs are cheap enough.
-extern "C" int wtpse_conv_fwd_x3(const float* in0, int C0, const float* in1, int C1, const unsigned short* wpacked,
-                                 const float* bias, const float* pro0, const float* pro1, int pro_relu, float* out0, float* out1,
-                                 int Csplit, float* stats, int B, int H, int W, int Cout, int ksize, int relu_out,
-                                 const float* mask_ref, void* stream) {
+static int conv_x3_impl(const float* in0, int C0, const float* in1, int C1, const unsigned short* wpacked,
+                        const float* bias, const float* pro0, const float* pro1, int pro_relu, float* out0, float* out1,
+                        int Csplit, float* stats, int B, int H, int W, int Cout, int ksize, int relu_out,
+                        const float* mask_ref, const float* bn_ss, const float* bn_mean, int bn_relu, int bn_c0, int bn_c1,
+                        void* stream) {
   WTPSE_REQUIRE(in0 && wpacked && out0 && B > 0 && H > 0 && W > 0 && C0 > 0 && C1 >= 0 && Cout > 0);
   WTPSE_REQUIRE(ksize == 1 || ksize == 3);
   WTPSE_REQUIRE((C1 == 0) == (in1 == nullptr));
   WTPSE_REQUIRE(Csplit > 0 && Csplit <= Cout && ((Csplit == Cout) == (out1 == nullptr)));
   WTPSE_REQUIRE(Csplit == Cout || Csplit % 16 == 0);
   WTPSE_REQUIRE(!(stats && relu_out));
-  WTPSE_REQUIRE(!(stats && mask_ref));
-  WTPSE_REQUIRE(!(mask_ref && out1));
+  const bool bnb = bn_mean != nullptr;
+  WTPSE_REQUIRE(bnb || !(stats && mask_ref));
+  WTPSE_REQUIRE(bnb || !(mask_ref && out1));
+  WTPSE_REQUIRE(!bnb || (mask_ref && stats && bn_ss && !bias && !relu_out && bn_c0 >= 0 && bn_c0 < bn_c1 && bn_c1 <= Cout &&
+                         bn_c0 % 16 == 0 && (bn_c1 % 16 == 0 || bn_c1 == Cout)));
   WTPSE_REQUIRE(C1 == 0 || C0 % 16 == 0);
   ConvX3Args a;
   a.in0 = in0; a.in1 = in1; a.wx = wpacked; a.bias = bias; a.pro0 = pro0; a.pro1 = pro1; a.out0 = out0; a.out1 = out1;
   a.stats = stats; a.mask = mask_ref;
+  a.bn_ss = bn_ss; a.bn_mean = bn_mean; a.bn_relu = bn_relu; a.bn_c0 = bnb ? bn_c0 : 0; a.bn_c1 = bnb ? bn_c1 : 0;
   a.B = B; a.H = H; a.W = W; a.C0 = C0; a.C1 = C1; a.Cin = C0 + C1; a.CinP = (a.Cin + 15) & ~15;
   a.Cout = Cout; a.CoutP = (Cout + 31) & ~31; a.Csplit = Csplit; a.pro_relu = pro_relu; a.relu_out = relu_out;
   a.tiles_x = a.tiles_y = 0;
   hipStream_t st = (hipStream_t)stream;
   const bool mt2 = x3_mt2(B, H, W, a.CoutP);
-#define X3(KS, M) (mask_ref ? launch_x3<KS, M, true>(a, st) : launch_x3<KS, M, false>(a, st))
+#define X3(KS, M) (bnb ? launch_x3<KS, M, 2>(a, st) : mask_ref ? launch_x3<KS, M, 1>(a, st) : launch_x3<KS, M, 0>(a, st))
   if (ksize == 3) return mt2 ? X3(3, 2) : X3(3, 1);
   return mt2 ? X3(1, 2) : X3(1, 1);
 #undef X3
+}
+
+// Same contract as wtpse_conv_fwd (include/wtpse_hip.h) with `wpacked` in the x3 layout.  Cout <= 16 runs on a 32-row
+// tile with the upper rows idle (zero weights, stores dropped by the range check): the bf16 MFMAs are cheap enough.
+extern "C" int wtpse_conv_fwd_x3(const float* in0, int C0, const float* in1, int C1, const unsigned short* wpacked,
+                                 const float* bias, const float* pro0, const float* pro1, int pro_relu, float* out0, float* out1,
+                                 int Csplit, float* stats, int B, int H, int W, int Cout, int ksize, int relu_out,
+                                 const float* mask_ref, void* stream) {
+  return conv_x3_impl(in0, C0, in1, C1, wpacked, bias, pro0, pro1, pro_relu, out0, out1, Csplit, stats, B, H, W, Cout, ksize,
+                      relu_out, mask_ref, nullptr, nullptr, 0, 0, 0, stream);
+}
+
+// Data gradient that also performs the first half of the BatchNorm backward of the layer it flows into (include/wtpse_hip.h).
+extern "C" int wtpse_dgrad_x3_bnb(const float* dy, int C, const unsigned short* wpacked, float* out0, float* out1, int Csplit,
+                                  const float* bn_y, const float* bn_ss, const float* bn_mean, int bn_relu, int bn_c0, int bn_c1,
+                                  float* stats, int B, int H, int W, int Cout, int ksize, void* stream) {
+  WTPSE_REQUIRE(bn_y && bn_ss && bn_mean && stats);
+  return conv_x3_impl(dy, C, nullptr, 0, wpacked, nullptr, nullptr, nullptr, 0, out0, out1, Csplit, stats, B, H, W, Cout, ksize, 0,
+                      bn_y, bn_ss, bn_mean, bn_relu, bn_c0, bn_c1, stream);
 }
 
 // ================================================================================================

@@ -109,6 +109,31 @@ def conv_fwd_x3(in0, in1, wpacked_ptr, bias, cout, ksize, pro0=None, pro_relu=0,
     return out0, out1, stats
 
 
+def dgrad_bnb(dy, wpacked_ptr, x3, cout, ksize, bn_y, bn_ss, bn_mean, bn_relu, split=None, bn_second=False):
+    """Data gradient (`wpacked_ptr`: the layer's data-gradient weights, x3 layout if `x3`) whose epilogue masks the result with
+    the ReLU of the conv + BatchNorm layer it flows into and forms that layer's BatchNorm-backward reductions
+    (include/wtpse_hip.h, wtpse_dgrad_bnb).  With a split the BatchNorm'd tensor is out0, or out1 if `bn_second`.
+    -> (out0, out1 or None, stats [nblk, Cbn, 2])."""
+    _chk(dy, "dy"); _chk(bn_y, "bn_y"); _chk(bn_ss, "bn_ss"); _chk(bn_mean, "bn_mean")
+    B, C, H, W = dy.shape
+    L = lib()
+    if split is None:
+        csplit, c0, c1 = cout, 0, cout
+        out0 = torch.empty((B, cout, H, W), dtype=torch.float32, device=dy.device)
+        out1 = None
+    else:
+        csplit = int(split)
+        c0, c1 = (csplit, cout) if bn_second else (0, csplit)
+        out0 = torch.empty((B, csplit, H, W), dtype=torch.float32, device=dy.device)
+        out1 = torch.empty((B, cout - csplit, H, W), dtype=torch.float32, device=dy.device)
+    assert bn_y.shape == (B, c1 - c0, H, W), (bn_y.shape, (B, c1 - c0, H, W))
+    nblk = L.query("wtpse_conv_x3_stats_blocks", B, H, W, cout) if x3 else L.query("wtpse_conv_stats_blocks", B, H, W)
+    stats = torch.empty((nblk, c1 - c0, 2), dtype=torch.float32, device=dy.device)
+    L.call("wtpse_dgrad_x3_bnb" if x3 else "wtpse_dgrad_bnb", ptr(dy), C, wpacked_ptr, ptr(out0), ptr(out1), csplit, ptr(bn_y),
+           ptr(bn_ss), ptr(bn_mean), int(bool(bn_relu)), c0, c1, ptr(stats), B, H, W, cout, ksize, stream_ptr())
+    return out0, out1, stats
+
+
 def conv_wgrad(dy, x0, x1, ksize, dw, dbias, pro0=None, pro_relu=0, accumulate=False, pro1=None):
     """dw / dbias are views into the flat gradient buffer ([Cout,Cin,k,k] / [Cout] or None)."""
     _chk(dy, "dy"); _chk(x0, "x0"); _chk(x1, "x1")
@@ -198,6 +223,18 @@ def bn_bwd(dz, y, ss, relu, gamma, mean, invstd, dgamma, dbeta, accumulate=False
     dy = torch.empty_like(y)
     L.call("wtpse_bn_bwd", ptr(dz), ptr(y), ptr(ss), int(relu), ptr(gamma), ptr(mean), ptr(invstd), ptr(partial),
            ptr(coef), ptr(dgamma), ptr(dbeta), int(accumulate), ptr(dy), B, C, H * W, stream_ptr())
+    return dy
+
+
+def bn_bwd_from_stats(g, y, stats, gamma, mean, invstd, dgamma, dbeta, accumulate=False):
+    """Second half of a BatchNorm backward after dgrad_bnb: g = masked incoming gradient, stats = its partials.  -> dy."""
+    _chk(g, "g"); _chk(y, "y"); _chk(stats, "stats")
+    B, C, H, W = y.shape
+    assert stats.shape[1] == C
+    coef = workspace("bn_bwd_coef", C * 3, y.device)
+    dy = torch.empty_like(y)
+    lib().call("wtpse_bn_bwd_from_stats", ptr(g), ptr(y), ptr(stats), stats.shape[0], ptr(gamma), ptr(mean), ptr(invstd), ptr(coef),
+               ptr(dgamma), ptr(dbeta), int(accumulate), ptr(dy), B, C, H * W, stream_ptr())
     return dy
 
 
