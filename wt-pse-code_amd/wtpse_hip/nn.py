@@ -430,9 +430,37 @@ def _conv(layer, a0, a1=None, relu_out=False, want_stats=False):
     return y, stats
 
 
-def _dgrad(layer, dy, split=None, mask_ref=None):
-    """Data gradient; mask_ref fuses the ReLU backward of the tensor the gradient flows into (d * [ref > 0])."""
+class PreBN:
+    """A gradient wrt the activated output of a conv + BatchNorm (+ReLU) layer as the data gradient that produced it left it:
+    already masked with that layer's ReLU (`g`), with the two reductions of the BatchNorm backward as per-workgroup partials
+    (`stats`): convbn_bwd / upbn_bwd finish the BatchNorm backward with one elementwise pass (ops.bn_bwd_from_stats) instead
+    of reduce + apply (5 -> 3 HBM passes over the layer's map)."""
+    __slots__ = ("g", "stats")
+
+    def __init__(self, g, stats):
+        self.g, self.stats = g, stats
+
+
+# BatchNorm-backward reductions in the epilogue of the producing data gradient (csrc/conv_x3.hip, conv.hip: EPI 2).
+# WTPSE_BN_FUSED_STATS=0: the stand-alone reduce pass everywhere.
+BN_FUSED_STATS = os.environ.get("WTPSE_BN_FUSED_STATS", "1") != "0"
+
+
+def _dgrad(layer, dy, split=None, mask_ref=None, below0=None, below1=None):
+    """Data gradient; mask_ref fuses the ReLU backward of the tensor the gradient flows into (d * [ref > 0]).
+    below0 / below1: tape of the conv + BatchNorm layer whose activated output the first / second returned gradient is taken
+    with respect to (at most one of them): that gradient comes back as a PreBN."""
     root = layer._root
+    below = below0 if below0 is not None else below1
+    if (BN_FUSED_STATS and below is not None and mask_ref is None and below.mean is not None
+            and not (root._dp is not None and root._dp.bn_sync) and (below1 is None or split is not None)):
+        x3 = layer.xd_off >= 0
+        wptr = root.x3_ptr(layer.xd_off) if x3 else root.packed_ptr(layer.wd_off)
+        d0, d1, stats = ops.dgrad_bnb(dy, wptr, x3, layer.cin, layer.k, below.y, below.ss, below.mean, below.relu, split,
+                                      below1 is not None and below0 is None)
+        if below0 is not None:
+            return PreBN(d0, stats), d1
+        return d0, PreBN(d1, stats)
     if layer.xd_off >= 0:
         return ops.conv_fwd_x3(dy, None, root.x3_ptr(layer.xd_off), None, layer.cin, layer.k, None, 0, False, False, split,
                                mask_ref)[:2]
@@ -554,20 +582,27 @@ def convbn_fwd(conv, bn, a0, a1, relu, training, want_tape=True):
     return z, t
 
 
-def convbn_bwd(conv, bn, t, dz, need_dx=True):
-    """dz: gradient wrt the activated output.  -> (dx0, dx1): gradients wrt the inputs AS LOADED (activated)."""
-    root = conv._root
+def _bn_bwd(bn, t, dz, root):
+    """BatchNorm (+ReLU) backward of a convbn / upbn tape: dz = gradient wrt the activated output, plain or PreBN."""
+    if isinstance(dz, PreBN):
+        return ops.bn_bwd_from_stats(dz.g, t.y, dz.stats, bn.weight, t.mean, t.invstd, root.gview(bn.weight), root.gview(bn.bias))
     if root._dp is not None and root._dp.bn_sync:
-        dy = root._dp.bn_bwd_synced(dz, t, bn, root)
-    else:
-        dy = ops.bn_bwd(dz, t.y, t.ss, t.relu, bn.weight, t.mean, t.invstd, root.gview(bn.weight), root.gview(bn.bias))
+        return root._dp.bn_bwd_synced(dz, t, bn, root)
+    return ops.bn_bwd(dz, t.y, t.ss, t.relu, bn.weight, t.mean, t.invstd, root.gview(bn.weight), root.gview(bn.bias))
+
+
+def convbn_bwd(conv, bn, t, dz, need_dx=True, below0=None, below1=None):
+    """dz: gradient wrt the activated output (plain or PreBN).  -> (dx0, dx1): gradients wrt the inputs AS LOADED (activated);
+    below0 / below1: see _dgrad."""
+    root = conv._root
+    dy = _bn_bwd(bn, t, dz, root)
     # the conv bias in front of a train-mode BatchNorm has an exactly-zero gradient (sum of dy over the batch
     # vanishes); the reference carries rounding noise there (SURVEY.md Appendix A). It is left at 0.
     _wgrad_side(conv, dy, t.a0, t.a1)
     if not need_dx:
         return None, None
     split = t.a0.t.shape[1] if t.a1 is not None else None
-    return _dgrad(conv, dy, split)
+    return _dgrad(conv, dy, split, below0=below0, below1=below1)
 
 
 # ---- ConvD (algorithms.py:897-917) ---------------------------------------------------------------------------
@@ -584,8 +619,8 @@ def convd_fwd(blk, x, training, want_tape=True):
 
 def convd_bwd(blk, t, dz, dx_accum=None, need_dx=True):
     """dx_accum: existing gradient buffer of x (skip connection) to accumulate into, or None."""
-    d, _ = convbn_bwd(blk.conv3, blk.bn3, t.c3, dz)
-    d, _ = convbn_bwd(blk.conv2, blk.bn2, t.c2, d)
+    d, _ = convbn_bwd(blk.conv3, blk.bn3, t.c3, dz, below0=t.c2)
+    d, _ = convbn_bwd(blk.conv2, blk.bn2, t.c2, d, below0=t.c1)
     d, _ = convbn_bwd(blk.conv1, blk.bn1, t.c1, d, need_dx=need_dx)
     if not need_dx:
         return None
@@ -631,16 +666,13 @@ def upbn_fwd(conv, bn, a0, training, want_tape=True):
     return out, t
 
 
-def upbn_bwd(conv, bn, t, dz):
-    """-> gradient wrt the (activated, low-resolution) conv input."""
+def upbn_bwd(conv, bn, t, dz, below=None):
+    """-> gradient wrt the (activated, low-resolution) conv input (a PreBN if `below`, the tape of the layer it came from)."""
     root = conv._root
-    if root._dp is not None and root._dp.bn_sync:
-        dy = root._dp.bn_bwd_synced(dz, t, bn, root)
-    else:
-        dy = ops.bn_bwd(dz, t.y, t.ss, t.relu, bn.weight, t.mean, t.invstd, root.gview(bn.weight), root.gview(bn.bias))
+    dy = _bn_bwd(bn, t, dz, root)
     dzl = ops.upsample2x_bwd(dy)
     _wgrad_side(conv, dzl, t.a0, None)                         # bias in front of a train-mode BatchNorm: see convbn_bwd
-    return _dgrad(conv, dzl)[0]
+    return _dgrad(conv, dzl, below0=below)[0]
 
 
 def convu_fwd(blk, x, prev, training, want_tape=True):
@@ -659,16 +691,17 @@ def convu_fwd(blk, x, prev, training, want_tape=True):
     return out, t
 
 
-def convu_bwd(blk, t, dout):
-    """-> (dx, dprev); both wrt the activated tensors."""
-    dprev, dy = convbn_bwd(blk.conv3, blk.bn3, t.c3, dout)
+def convu_bwd(blk, t, dout, below_x=None):
+    """-> (dx, dprev); both wrt the activated tensors.  below_x: tape of the conv + BatchNorm layer that produced the block's
+    input x, when x feeds nothing else (dx then comes back as a PreBN)."""
+    dprev, dy = convbn_bwd(blk.conv3, blk.bn3, t.c3, dout, below1=t.c2)
     if t.swapped:
-        dx = upbn_bwd(blk.conv2, blk.bn2, t.c2, dy)
+        dx = upbn_bwd(blk.conv2, blk.bn2, t.c2, dy, below=(below_x if blk.first else t.c1))
     else:
         du, _ = convbn_bwd(blk.conv2, blk.bn2, t.c2, dy)
         dx = ops.upsample2x_bwd(du)
     if not blk.first:
-        dx, _ = convbn_bwd(blk.conv1, blk.bn1, t.c1, dx)
+        dx, _ = convbn_bwd(blk.conv1, blk.bn1, t.c1, dx, below0=below_x)
     return dx, dprev
 
 
@@ -689,10 +722,11 @@ def unet_fwd(net, x1, training, want_tape=True):
 
 def unet_bwd(net, t, dfeat, need_dx1=True):
     """-> gradient wrt the activated x1 (None if not needed)."""
-    d, g1 = convu_bwd(net.up4, t.u4, dfeat)
-    d, g2 = convu_bwd(net.up3, t.u3, d)
-    d, g3 = convu_bwd(net.up2, t.u2, d)
-    g5, g4 = convu_bwd(net.up1, t.u1, d)
+    # (the output of up3 / up2 / up1 / down4 feeds only the next ConvU: its gradient carries that layer's BatchNorm statistics)
+    d, g1 = convu_bwd(net.up4, t.u4, dfeat, below_x=t.u3.c3)
+    d, g2 = convu_bwd(net.up3, t.u3, d, below_x=t.u2.c3)
+    d, g3 = convu_bwd(net.up2, t.u2, d, below_x=t.u1.c3)
+    g5, g4 = convu_bwd(net.up1, t.u1, d, below_x=t.d4.c3)
     convd_bwd(net.down4, t.d4, g5, g4)
     convd_bwd(net.down3, t.d3, g4, g3)
     convd_bwd(net.down2, t.d2, g3, g2)
@@ -831,8 +865,8 @@ def teacher_bwd(tn, t, dmu, dlogvar):
     dxf = unet_bwd(tn, t.unet, d)
     dxf = ops.relu_mask(dxf, t.xf)
     _wgrad(tn.fusion[0], dxf, t.m2, t.feat)
-    dm2, dfeat = _dgrad(tn.fusion[0], dxf, split=t.m2.t.shape[1])
+    dm2, dfeat = _dgrad(tn.fusion[0], dxf, split=t.m2.t.shape[1], below0=t.i3)
     inc = tn.inc.double_conv
-    dm1, _ = convbn_bwd(inc[3], inc[4], t.i3, dm2)
+    dm1, _ = convbn_bwd(inc[3], inc[4], t.i3, dm2, below0=t.i0)
     convbn_bwd(inc[0], inc[1], t.i0, dm1, need_dx=False)
     return dfeat
