@@ -100,6 +100,13 @@ int wtpse_conv_wgrad_r(const float* dy, const float* x0, int C0, const float* x1
                        const float* pro1, int pro_relu, float* slab, float* dbias_slab, int nslab, float* dw, float* dbias,
                        int accumulate, int B, int H, int W, int Cout, void* stream);
 
+/* wtpse_conv_wgrad_r with dY given as the un-applied second half of a BatchNorm backward (wtpse_bn_bwd_coef):
+ * dY = k1[c] * g + k2[c] * bn_y + k3[c], bn_coef [Cout][3] = (k1, k2, k3): the BatchNorm-apply pass of the backward
+ * (read g, read y, write dY) never runs, the kernel forms dY from the two tensors as it loads its A fragments. */
+int wtpse_conv_wgrad_r_bn(const float* g, const float* bn_y, const float* bn_coef, const float* x0, int C0, const float* x1,
+                          int C1, const float* pro0, const float* pro1, int pro_relu, float* slab, int nslab, float* dw,
+                          int accumulate, int B, int H, int W, int Cout, void* stream);
+
 /* ---- BatchNorm2d, eps 1e-5, momentum 0.1 (algorithms.py:862-864) ---------------------------------------------- */
 /* train mode: fold the conv epilogue's partials -> scale_shift[C][2], save_mean/invstd[C]; update running stats
  * (unbiased variance) and num_batches_tracked (int64) when given. */

@@ -196,6 +196,17 @@ def test_conv_wgrad_r(case):
     assert e3 <= 2.0 * e32 + 2e-8, (e3, e32)
     o.conv_wgrad_r(*args, dw, db, accumulate=True, **kw)
     close(dw, 2 * ref64, rtol=2e-4, atol=4e-5 * max(scale, 1.0), what="wgrad r accumulate")
+    # dY as the un-applied second half of a BatchNorm backward: dY = k1 * g + k2 * y + k3 formed on load
+    gg, yy = rnd(B, Co, H, W, seed=17), rnd(B, Co, H, W, seed=18)
+    coef = torch.stack([rnd(Co, seed=19) * 0.3 + 1.0, rnd(Co, seed=20) * 0.2, rnd(Co, seed=21) * 0.1], 1).contiguous()
+    dyl = coef[:, 0].view(1, -1, 1, 1) * gg + coef[:, 1].view(1, -1, 1, 1) * yy + coef[:, 2].view(1, -1, 1, 1)
+    w.grad = None
+    F.conv2d(act.double(), w.double(), None, padding=1).backward(dyl.double())
+    o.conv_wgrad_r_bn(gg.to(DEV), yy.to(DEV), coef.to(DEV), args[1], args[2], dw, **kw)
+    close(dw, w.grad.double(), rtol=2e-4, atol=2e-5 * max(float(w.grad.abs().max()), 1.0), what="wgrad r, BatchNorm-apply on load")
+    dwp = torch.empty_like(dw)
+    o.conv_wgrad_r(dyl.to(DEV), args[1], args[2], dwp, None, **kw)
+    close(dw, dwp, rtol=2e-5, atol=2e-6 * max(float(w.grad.abs().max()), 1.0), what="fused vs materialised dY")
     # without a prologue (a dense input), no bias
     F.conv2d(xin.double(), w.double(), None, padding=1)
     w.grad = None

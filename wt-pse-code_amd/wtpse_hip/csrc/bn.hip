@@ -138,22 +138,32 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_k(const float* __restrict__
 // `global_sums` (optional, [C][2]): the same two sums over ALL ranks' elements (synchronised BatchNorm); the dy
 // coefficients then use them together with the global `count`, while dgamma/dbeta keep this rank's share (the
 // parameter-gradient all-reduce adds the shares up).  `sums_out` (optional) receives this rank's folded sums.
-__global__ __launch_bounds__(64) void bn_bwd_finalize_k(const float* __restrict__ partial, int nsplit, int C, double count,
-                                                        const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                        const float* __restrict__ invstd, float* __restrict__ dgamma,
-                                                        float* __restrict__ dbeta, int accumulate,
-                                                        float* __restrict__ coef, const float* __restrict__ global_sums,
-                                                        float* __restrict__ sums_out, int centred_s2) {
+__global__ __launch_bounds__(256) void bn_bwd_finalize_k(const float* __restrict__ partial, int nsplit, int C, double count,
+                                                         const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                         const float* __restrict__ invstd, float* __restrict__ dgamma,
+                                                         float* __restrict__ dbeta, int accumulate,
+                                                         float* __restrict__ coef, const float* __restrict__ global_sums,
+                                                         float* __restrict__ sums_out, int centred_s2) {
+  // one workgroup per channel; fp64 fold in a fixed order (lane-strided, butterfly, the four waves in order)
+  __shared__ double shs[2][4];
   const int c = blockIdx.x, t = threadIdx.x;
   double s1 = 0.0, s2 = 0.0;
-  for (int k = t; k < nsplit; k += 64) {
-    s1 += partial[((size_t)k * C + c) * 2];
-    s2 += partial[((size_t)k * C + c) * 2 + 1];
+  for (int k = t; k < nsplit; k += 256) {
+    const float2 p2 = *reinterpret_cast<const float2*>(partial + ((size_t)k * C + c) * 2);
+    s1 += p2.x;
+    s2 += p2.y;
   }
   for (int m = 1; m < 64; m <<= 1) {
     s1 += __shfl_xor(s1, m, 64);
     s2 += __shfl_xor(s2, m, 64);
   }
+  if ((t & 63) == 0) {
+    shs[0][t >> 6] = s1;
+    shs[1][t >> 6] = s2;
+  }
+  __syncthreads();
+  s1 = (shs[0][0] + shs[0][1]) + (shs[0][2] + shs[0][3]);
+  s2 = (shs[1][0] + shs[1][1]) + (shs[1][2] + shs[1][3]);
   if (centred_s2) s2 *= (double)invstd[c];     // partials of a data-gradient epilogue: sum g * (y - mean), not yet / std
   if (t == 0) {
     if (sums_out) {
@@ -341,7 +351,7 @@ extern "C" int wtpse_bn_bwd(const float* dz, const float* y, const float* scale_
   else
     hipLaunchKernelGGL(bn_bwd_reduce_k<false>, dim3(C, ns), dim3(256), 0, st, dz, y, scale_shift, relu, save_mean,
                        save_invstd, B, C, HW, partial);
-  hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(C), dim3(64), 0, st, partial, ns, C, (double)B * HW, gamma, save_mean,
+  hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(C), dim3(256), 0, st, partial, ns, C, (double)B * HW, gamma, save_mean,
                      save_invstd, dgamma, dbeta, accumulate, coef, (const float*)nullptr, (float*)nullptr, 0);
   if (vec_ok(HW, dz, y, dy))
     hipLaunchKernelGGL(bn_bwd_apply_k<true>, dim3(ceil_div(HW, 1024) * B * C), dim3(256), 0, st, dz, y, scale_shift,
@@ -367,7 +377,7 @@ extern "C" int wtpse_bn_bwd_reduce(const float* dz, const float* y, const float*
   else
     hipLaunchKernelGGL(bn_bwd_reduce_k<false>, dim3(C, ns), dim3(256), 0, st, dz, y, scale_shift, relu, save_mean,
                        save_invstd, B, C, HW, partial);
-  hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(C), dim3(64), 0, st, partial, ns, C, 1.0, (const float*)nullptr, save_mean,
+  hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(C), dim3(256), 0, st, partial, ns, C, 1.0, (const float*)nullptr, save_mean,
                      save_invstd, (float*)nullptr, (float*)nullptr, 0, (float*)nullptr, (const float*)nullptr, sums_local, 0);
   return wtpse_status();
 }
@@ -380,7 +390,7 @@ extern "C" int wtpse_bn_bwd_apply(const float* dz, const float* y, const float* 
                 dbeta && dy && B > 0 && C > 0 && HW > 0 && count_global > 0);
   hipStream_t st = (hipStream_t)stream;
   // sums_local viewed as a 1-slab partial: [1][C][2]
-  hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(C), dim3(64), 0, st, sums_local, 1, C, (double)count_global, gamma, save_mean,
+  hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(C), dim3(256), 0, st, sums_local, 1, C, (double)count_global, gamma, save_mean,
                      save_invstd, dgamma, dbeta, accumulate, coef, sums_global, (float*)nullptr, 0);
   if (vec_ok(HW, dz, y, dy))
     hipLaunchKernelGGL(bn_bwd_apply_k<true>, dim3(ceil_div(HW, 1024) * B * C), dim3(256), 0, st, dz, y, scale_shift,
@@ -400,7 +410,7 @@ extern "C" int wtpse_bn_bwd_from_stats(const float* g, const float* y, const flo
   WTPSE_REQUIRE(g && y && stats_partial && gamma && save_mean && save_invstd && coef && dgamma && dbeta && dy);
   WTPSE_REQUIRE(nblk > 0 && B > 0 && C > 0 && HW > 0);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(C), dim3(64), 0, st, stats_partial, nblk, C, (double)B * HW, gamma, save_mean,
+  hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(C), dim3(256), 0, st, stats_partial, nblk, C, (double)B * HW, gamma, save_mean,
                      save_invstd, dgamma, dbeta, accumulate, coef, (const float*)nullptr, (float*)nullptr, 1);
   // (the scale/shift operand is only read for the ReLU mask: relu = 0 here, the coefficients stand in for it)
   if (vec_ok(HW, g, y, dy))

@@ -33,6 +33,10 @@ struct WgradRArgs {
   const float* x1;
   const float* pro0;
   const float* pro1;
+  // AFF: dy is not materialised — it is the second half of a BatchNorm backward, dy = k1[c] * g + k2[c] * y + k3[c] with
+  // g = `dy` (the masked incoming gradient), y = `bn_y` (the layer's raw conv output), coef = `bn_coef` [Cout][3]
+  const float* bn_y;
+  const float* bn_coef;
   float* slab;     // [nslab][Cout][Cin][9]
   float* slab_b;   // [nslab_b][Cout] or null
   int B, H, W, C0, C1, Cin, Cout;
@@ -53,6 +57,8 @@ __device__ __forceinline__ unsigned wr_pack_rne(float a, float b) {
   return __builtin_bit_cast(unsigned, v);
 }
 // (a, b) -> three dwords holding the bf16 pairs (term_i(a), term_i(b)): see split3_pair in conv_x3.hip
+// (the compiler fuses the two subtractions of a level into one v_pk_add_f32; keeping them apart — two v_sub_f32 — measured 7 %
+// slower over the layer set: the row step is bound by the NUMBER of vector instructions that fit behind its MFMAs)
 __device__ __forceinline__ void wr_split3_pair(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2) {
   p0 = wr_pack_rne(a, b);
   const float ra = a - __builtin_bit_cast(float, p0 << 16);
@@ -84,7 +90,7 @@ __device__ __forceinline__ void wr_split8(const f32x4& lo, const f32x4& hi, u32x
 // their SIMD to themselves: four waves
 template <int MF, int NF> struct WgradRGeom { static constexpr int NW = (MF * NF >= 2) ? 4 : 8; };
 
-template <int MF, int NF, bool PRO, bool BIAS>
+template <int MF, int NF, bool PRO, bool BIAS, bool AFF = false>
 __global__ __launch_bounds__((64 * WgradRGeom<MF, NF>::NW), 1) void wgrad_r_k(WgradRArgs a) {
   constexpr int NT = 9, NW = WgradRGeom<MF, NF>::NW;
   // (the wave id is wave-uniform, but only readfirstlane tells the compiler: everything derived from it — the unit, the image,
@@ -129,6 +135,15 @@ __global__ __launch_bounds__((64 * WgradRGeom<MF, NF>::NW), 1) void wgrad_r_k(Wg
       if (a.pro_relu & (xfirst[n] ? 1 : 2)) plo[n] = 0.f;
     }
   }
+  float ak1[MF], ak2[MF], ak3[MF];
+#pragma unroll
+  for (int m = 0; m < MF; ++m) {
+    ak1[m] = 1.f; ak2[m] = 0.f; ak3[m] = 0.f;
+    if (AFF) {
+      const float* q = a.bn_coef + 3 * (cout0 + 16 * m + c16);
+      ak1[m] = q[0]; ak2[m] = q[1]; ak3[m] = q[2];
+    }
+  }
   const int src_up = (lane + 16) & 63, src_dn = (lane - 16) & 63;
 
   for (int u = u0; u < u1; ++u) {
@@ -141,6 +156,7 @@ __global__ __launch_bounds__((64 * WgradRGeom<MF, NF>::NW), 1) void wgrad_r_k(Wg
     const int y0 = seg * a.rseg, y1 = min(a.H, y0 + a.rseg);
     const int rfirst = max(y0 - 1, 0), rlast = min(y1, a.H - 1);
     const __amdgpu_buffer_rsrc_t rsy = make_rsrc(a.dy + (size_t)b * a.Cout * HW, (unsigned)a.Cout * HW * 4u);
+    const __amdgpu_buffer_rsrc_t rsb = AFF ? make_rsrc(a.bn_y + (size_t)b * a.Cout * HW, (unsigned)a.Cout * HW * 4u) : rsy;
     const __amdgpu_buffer_rsrc_t rsx0 = make_rsrc(a.x0 + (size_t)b * a.C0 * HW, (unsigned)a.C0 * HW * 4u);
     const __amdgpu_buffer_rsrc_t rsx1 = a.x1 ? make_rsrc(a.x1 + (size_t)b * a.C1 * HW, (unsigned)a.C1 * HW * 4u) : rsx0;
     // byte offsets of this lane's 8 pixels in row 0
@@ -164,16 +180,20 @@ __global__ __launch_bounds__((64 * WgradRGeom<MF, NF>::NW), 1) void wgrad_r_k(Wg
     // r + 3 are issued into the raw slot it frees: two stages (8 KB per wave at 16 x 16 channels) are in flight at any time.
     // All ring slots are static: the row loop is unrolled by four.  Rows outside [y0, y1) / the image read as zero
     // (out-of-range buffer offsets), so the products need no edge cases.
-    f32x4 rawx[2][NF][2], rawy[2][MF][2];
+    // The fused-BatchNorm form of the 32 x 32 blocks (AFF: two tensors behind the A operand) has no registers for two stages of
+    // them: its A side keeps ONE stage in flight, re-issued as soon as the stage's dY pieces are converted (AD = 1).
+    constexpr int AD = (AFF && MF * NF >= 4) ? 1 : 2;
+    f32x4 rawx[2][NF][2], rawy[AD][MF][2], rawb[AD][AFF ? MF : 1][2];
+    float ak3v[AD][MF];           // AFF: k3 of the stage's dY row, 0 for a row outside [y0, y1)
     float rawe[2][NF];
     u32x4v ay[4][MF][3];          // split dY rows: row y in slot (y - rfirst) & 3      [slot][cout fragment][term]
     u32x4v xb[2][NF][3];          // split X row s in slot (s - rfirst) & 1
     unsigned eq[2][NF][3];        // its edge pixel (lane groups 0 and 3)
     // (branch-free: a row outside its range turns into an out-of-range buffer offset by OR-ing the top bit in — every valid
     // offset is below 2^31 — and the row's byte offset rides in the scalar offset operand)
-    auto issue = [&](auto Sc, int s, bool want_x) {
+    auto issue_x = [&](auto Sc, int s) {                   // X row s -> raw slot S
       constexpr int S = decltype(Sc)::value;
-      const int xv = (int)want_x & (int)(s <= rlast);     // (bitwise on purpose: no short-circuit branch inside the row loop)
+      const int xv = (int)(s <= rlast);
       const unsigned xo = xv ? 0u : BUF_OOB;
       const unsigned ro = xv ? (unsigned)s * W4 : 0u;
 #pragma unroll
@@ -184,33 +204,51 @@ __global__ __launch_bounds__((64 * WgradRGeom<MF, NF>::NW), 1) void wgrad_r_k(Wg
         rawx[S][n][1] = buf_load4(rs, vo + 16u, ro);
         rawe[S][n] = buf_load(rs, ebase[n] | xo, ro);
       }
+    };
+    auto issue_a = [&](auto Sc, int s) {                   // dY row s + 1 -> raw slot S % AD
+      constexpr int S = decltype(Sc)::value % AD;
       const int y = s + 1;
-      const int yv = (int)(y >= y0) & (int)(y < y1);
+      const int yv = (int)(y >= y0) & (int)(y < y1);      // (bitwise on purpose: no short-circuit branch inside the row loop)
       const unsigned yo = yv ? (unsigned)y * W4 : 0u, ym = yv ? 0u : BUF_OOB;
+      if (AFF) {
+#pragma unroll
+        for (int m = 0; m < MF; ++m) ak3v[S][m] = yv ? ak3[m] : 0.f;
+      }
 #pragma unroll
       for (int m = 0; m < MF; ++m) {
         const unsigned vo = ybase[m] | ym;
         rawy[S][m][0] = buf_load4(rsy, vo, yo);
         rawy[S][m][1] = buf_load4(rsy, vo + 16u, yo);
+        if (AFF) {
+          rawb[S][m][0] = buf_load4(rsb, vo, yo);
+          rawb[S][m][1] = buf_load4(rsb, vo + 16u, yo);
+        }
       }
     };
-    // Conversion of the stage in raw slot S (-> X slot S, dY slot AS), cut into NP pieces of about a dozen vector instructions:
-    //   [0, 4 MF)            one pair of a dY fragment's 8 pixels: split into the three bf16 terms (+ bias sum)
-    //   [4 MF, 4 MF + 4 NF)  one pair of an X fragment's 8 pixels: prologue, split
+    // Conversion of stage s in raw slot S (-> X slot S, dY slot AS), cut into NP pieces of about a dozen vector instructions:
+    //   [0, 4 MF)            one pair of a dY fragment's 8 pixels: [BatchNorm-apply,] split into the three bf16 terms (+ bias sum)
+    //   4 MF                 AD = 1 only: the A loads of stage s + 1 (the slot was just consumed)
+    //   next 4 NF            one pair of an X fragment's 8 pixels: prologue, split
     //   next NF              the edge pixel of an X fragment
-    //   last                 the loads of the stage that will take this raw slot (`next`; < 0: none)
-    constexpr int NP = 4 * MF + 4 * NF + NF + 1;
-    auto piece = [&](auto Pc, auto Sc, auto ASc, int next) {
-      constexpr int P = decltype(Pc)::value, S = decltype(Sc)::value, AS = decltype(ASc)::value;
-      if constexpr (P < 4 * MF) {
+    //   last                 the loads of stage s + 2 (X; and A when AD = 2)
+    constexpr int PA = 4 * MF, PX = PA + (AD == 1 ? 1 : 0), PE_ = PX + 4 * NF, NP = PE_ + NF + 1;
+    auto piece = [&](auto Pc, auto Sc, auto ASc, int s_next) {   // s_next: the stage being converted + 1; < 0: no loads
+      constexpr int P = decltype(Pc)::value, S = decltype(Sc)::value, AS = decltype(ASc)::value, SA = S % AD;
+      if constexpr (P < PA) {
         constexpr int m = P / 4, q = P % 4;
-        const float v0 = rawy[S][m][q >> 1][2 * (q & 1)], v1 = rawy[S][m][q >> 1][2 * (q & 1) + 1];
+        float v0 = rawy[SA][m][q >> 1][2 * (q & 1)], v1 = rawy[SA][m][q >> 1][2 * (q & 1) + 1];
+        if (AFF) {   // rows outside [y0, y1) load g = y = 0 and would come out as k3: the row validity rides in ak3v
+          v0 = fmaf(ak1[m], v0, fmaf(ak2[m], rawb[SA][m][q >> 1][2 * (q & 1)], ak3v[SA][m]));
+          v1 = fmaf(ak1[m], v1, fmaf(ak2[m], rawb[SA][m][q >> 1][2 * (q & 1) + 1], ak3v[SA][m]));
+        }
         if (BIAS) bsum[m] += v0 + v1;
         unsigned q0, q1, q2;
         wr_split3_pair(v0, v1, q0, q1, q2);
         ay[AS][m][0][q] = q0; ay[AS][m][1][q] = q1; ay[AS][m][2][q] = q2;
-      } else if constexpr (P < 4 * MF + 4 * NF) {
-        constexpr int n = (P - 4 * MF) / 4, q = (P - 4 * MF) % 4;
+      } else if constexpr (P < PX) {
+        if (s_next >= 0) issue_a(Sc, s_next);
+      } else if constexpr (P < PE_) {
+        constexpr int n = (P - PX) / 4, q = (P - PX) % 4;
         float v0 = rawx[S][n][q >> 1][2 * (q & 1)], v1 = rawx[S][n][q >> 1][2 * (q & 1) + 1];
         if (PRO) {
           v0 = fmaxf(fmaf(v0, psc[n], psh[n]), plo[n]);
@@ -220,18 +258,19 @@ __global__ __launch_bounds__((64 * WgradRGeom<MF, NF>::NW), 1) void wgrad_r_k(Wg
         wr_split3_pair(v0, v1, q0, q1, q2);
         xb[S][n][0][q] = q0; xb[S][n][1][q] = q1; xb[S][n][2][q] = q2;
       } else if constexpr (P < NP - 1) {
-        constexpr int n = P - 4 * MF - 4 * NF;
+        constexpr int n = P - PE_;
         float e = rawe[S][n];
         if (PRO) e = evalid ? fmaxf(fmaf(e, psc[n], psh[n]), plo[n]) : 0.f;     // zero padding applies after the activation
         wr_split3_pair(e, 0.f, eq[S][n][0], eq[S][n][1], eq[S][n][2]);
       } else {
-        if (next >= 0) issue(Sc, next, true);
+        if (s_next >= 0) {
+          issue_x(Sc, s_next + 1);
+          if (AD == 2) issue_a(Sc, s_next + 1);
+        }
       }
     };
-    auto convert_all = [&](auto Sc, auto ASc, bool with_x) {
-      static_for<4 * MF>([&](auto p) { piece(p, Sc, ASc, -1); });
-      if (with_x) static_for<4 * NF + NF>([&](auto p) { piece(IC<4 * MF + decltype(p)::value>{}, Sc, ASc, -1); });
-    };
+    auto convert_a = [&](auto Sc, auto ASc) { static_for<PA>([&](auto p) { piece(p, Sc, ASc, -1); }); };
+    auto convert_x = [&](auto Sc) { static_for<4 * NF + NF>([&](auto p) { piece(IC<PX + decltype(p)::value>{}, Sc, IC<0>{}, -1); }); };
     // One X row r (k = r - rfirst, J = k & 3): its products with the dY rows r + 1, r, r - 1 — chains of six dependent MFMAs, one
     // per (cin fragment, vertical tap, cout fragment, horizontal tap) — with the conversion pieces of stage r + 1 dealt out
     // behind the chains.  A wave of the 32 x 32 blocks has its SIMD to itself and issues in order, so the ORDER of the stream is
@@ -277,7 +316,7 @@ __global__ __launch_bounds__((64 * WgradRGeom<MF, NF>::NW), 1) void wgrad_r_k(Wg
           acc[m][n][ky * 3 + kx] = v;
           constexpr int cg = n * 9 * MF + c;                 // chain index within the step
           constexpr int plo_ = (cg * NP + NC - 1) / NC, phi_ = ((cg + 1) * NP + NC - 1) / NC;
-          static_for<phi_ - plo_>([&](auto pp) { piece(IC<plo_ + decltype(pp)::value>{}, IC<CS>{}, IC<AS>{}, r + 3); });
+          static_for<phi_ - plo_>([&](auto pp) { piece(IC<plo_ + decltype(pp)::value>{}, IC<CS>{}, IC<AS>{}, r + 2); });
 #ifndef WGRAD_R_NO_INTERLEAVE
 #pragma unroll
           for (int i = 0; i < 6; ++i) {
@@ -296,13 +335,30 @@ __global__ __launch_bounds__((64 * WgradRGeom<MF, NF>::NW), 1) void wgrad_r_k(Wg
       for (int m = 0; m < MF; ++m)
 #pragma unroll
         for (int t = 0; t < 3; ++t) ay[s][m][t] = (u32x4v){0u, 0u, 0u, 0u};
-    // stages rfirst - 1 (its dY row only: X row rfirst - 1 lies outside the unit or the image) and rfirst, then two in flight
-    issue(std::integral_constant<int, 1>{}, rfirst - 1, false);
-    issue(std::integral_constant<int, 0>{}, rfirst, true);
-    convert_all(IC<1>{}, IC<0>{}, false);
-    convert_all(IC<0>{}, IC<1>{}, true);
-    issue(std::integral_constant<int, 1>{}, rfirst + 1, true);
-    issue(std::integral_constant<int, 0>{}, rfirst + 2, true);
+    // stages rfirst - 1 (its dY row only: X row rfirst - 1 lies outside the unit or the image) and rfirst are converted up
+    // front; stages rfirst + 1 and rfirst + 2 are in flight when the row loop starts (AD = 1: only rfirst + 1 on the A side)
+    if (AD == 2) {
+      issue_a(IC<1>{}, rfirst - 1);
+      issue_a(IC<0>{}, rfirst);
+      issue_x(IC<0>{}, rfirst);
+      convert_a(IC<1>{}, IC<0>{});
+      convert_a(IC<0>{}, IC<1>{});
+      convert_x(IC<0>{});
+      issue_a(IC<1>{}, rfirst + 1);
+      issue_x(IC<1>{}, rfirst + 1);
+      issue_a(IC<0>{}, rfirst + 2);
+      issue_x(IC<0>{}, rfirst + 2);
+    } else {
+      issue_a(IC<0>{}, rfirst - 1);
+      issue_x(IC<0>{}, rfirst);
+      convert_a(IC<0>{}, IC<0>{});
+      issue_a(IC<0>{}, rfirst);
+      convert_x(IC<0>{});
+      issue_x(IC<1>{}, rfirst + 1);
+      convert_a(IC<0>{}, IC<1>{});
+      issue_a(IC<0>{}, rfirst + 1);
+      issue_x(IC<0>{}, rfirst + 2);
+    }
     int r = rfirst;
     for (; r + 3 <= rlast; r += 4) {
       step(std::integral_constant<int, 0>{}, r);
@@ -408,31 +464,36 @@ extern "C" int wtpse_wgrad_r_slabs(int B, int H, int W, int Cin, int Cout) {
 extern "C" void wtpse_wgrad_reduce_launch2(const float* slab, int ksplit, int n, float* dw, int accumulate, const float* slab_b,
                                            int n_b, float* db, void* stream);
 
-// Same contract as wtpse_conv_wgrad (include/wtpse_hip.h), 3x3 only; requires wtpse_wgrad_r_supported().
-extern "C" int wtpse_conv_wgrad_r(const float* dy, const float* x0, int C0, const float* x1, int C1, const float* pro0,
-                                  const float* pro1, int pro_relu, float* slab, float* dbias_slab, int nslab, float* dw,
-                                  float* dbias, int accumulate, int B, int H, int W, int Cout, void* stream) {
+static int wgrad_r_impl(const float* dy, const float* x0, int C0, const float* x1, int C1, const float* pro0,
+                        const float* pro1, int pro_relu, float* slab, float* dbias_slab, int nslab, float* dw,
+                        float* dbias, int accumulate, int B, int H, int W, int Cout, const float* bn_y, const float* bn_coef,
+                        void* stream) {
   WTPSE_REQUIRE(dy && x0 && slab && dw && B > 0 && H > 0 && W > 0 && C0 > 0 && C1 >= 0 && Cout > 0);
   WTPSE_REQUIRE((C1 == 0) == (x1 == nullptr));
   WTPSE_REQUIRE((dbias == nullptr) == (dbias_slab == nullptr));
+  WTPSE_REQUIRE((bn_y == nullptr) == (bn_coef == nullptr));
   const int Cin = C0 + C1;
   WTPSE_REQUIRE(wtpse_wgrad_r_supported(Cin, Cout, 3, C1 ? C0 : 16, W));
   WgradRPlan p;
   WTPSE_REQUIRE(wgrad_r_plan(B, H, W, Cin, Cout, p));
   WTPSE_REQUIRE(nslab == p.wpp / p.nw);
   WTPSE_REQUIRE(!dbias || p.mf * p.nf == 1);               // bias gradient: the 16 -> 16 layers without BatchNorm (DeepWT)
+  WTPSE_REQUIRE(!(dbias && bn_y));
   WTPSE_REQUIRE((long long)(C0 > C1 ? C0 : C1) * H * W * 4 < (1ll << 31) && (long long)Cout * H * W * 4 < (1ll << 31));
   WgradRArgs a;
   a.dy = dy; a.x0 = x0; a.x1 = x1; a.pro0 = pro0; a.pro1 = pro1; a.slab = slab; a.slab_b = dbias_slab;
+  a.bn_y = bn_y; a.bn_coef = bn_coef;
   a.B = B; a.H = H; a.W = W; a.C0 = C0; a.C1 = C1; a.Cin = Cin; a.Cout = Cout; a.pro_relu = pro_relu;
   a.strips = p.strips; a.nseg = p.nseg; a.rseg = p.rseg; a.units = p.units; a.wpp = p.wpp; a.nci = p.nci;
   const bool pro = pro0 != nullptr || pro1 != nullptr || pro_relu != 0;
-  const bool bias = dbias != nullptr;
+  const bool bias = dbias != nullptr, aff = bn_y != nullptr;
   dim3 grid((unsigned)(p.pairs * (p.wpp / p.nw)));
   const dim3 blk((unsigned)(64 * p.nw));
   hipStream_t st = (hipStream_t)stream;
 #define WR_LAUNCH(M, N) do { \
-    if (pro) hipLaunchKernelGGL((wgrad_r_k<M, N, true, false>), grid, blk, 0, st, a); \
+    if (aff) { if (pro) hipLaunchKernelGGL((wgrad_r_k<M, N, true, false, true>), grid, blk, 0, st, a); \
+               else hipLaunchKernelGGL((wgrad_r_k<M, N, false, false, true>), grid, blk, 0, st, a); } \
+    else if (pro) hipLaunchKernelGGL((wgrad_r_k<M, N, true, false>), grid, blk, 0, st, a); \
     else hipLaunchKernelGGL((wgrad_r_k<M, N, false, false>), grid, blk, 0, st, a); } while (0)
   if (p.mf == 2 && p.nf == 2) WR_LAUNCH(2, 2);
   else if (p.mf == 2) WR_LAUNCH(2, 1);
@@ -446,4 +507,22 @@ extern "C" int wtpse_conv_wgrad_r(const float* dy, const float* x0, int C0, cons
   if (rc) return rc;
   wtpse_wgrad_reduce_launch2(slab, nslab, Cout * Cin * 9, dw, accumulate, dbias_slab, Cout, dbias, stream);
   return wtpse_status();
+}
+
+// Same contract as wtpse_conv_wgrad (include/wtpse_hip.h), 3x3 only; requires wtpse_wgrad_r_supported().
+extern "C" int wtpse_conv_wgrad_r(const float* dy, const float* x0, int C0, const float* x1, int C1, const float* pro0,
+                                  const float* pro1, int pro_relu, float* slab, float* dbias_slab, int nslab, float* dw,
+                                  float* dbias, int accumulate, int B, int H, int W, int Cout, void* stream) {
+  return wgrad_r_impl(dy, x0, C0, x1, C1, pro0, pro1, pro_relu, slab, dbias_slab, nslab, dw, dbias, accumulate, B, H, W, Cout,
+                      nullptr, nullptr, stream);
+}
+
+// The same with dY given as the un-applied second half of a BatchNorm backward: dY = k1[c] * g + k2[c] * bn_y + k3[c],
+// bn_coef [Cout][3] (wtpse_bn_bwd_coef); no bias gradient.
+extern "C" int wtpse_conv_wgrad_r_bn(const float* g, const float* bn_y, const float* bn_coef, const float* x0, int C0,
+                                     const float* x1, int C1, const float* pro0, const float* pro1, int pro_relu, float* slab,
+                                     int nslab, float* dw, int accumulate, int B, int H, int W, int Cout, void* stream) {
+  WTPSE_REQUIRE(bn_y && bn_coef);
+  return wgrad_r_impl(g, x0, C0, x1, C1, pro0, pro1, pro_relu, slab, nullptr, nslab, dw, nullptr, accumulate, B, H, W, Cout, bn_y,
+                      bn_coef, stream);
 }

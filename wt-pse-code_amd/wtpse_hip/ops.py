@@ -186,6 +186,20 @@ def conv_wgrad_r(dy, x0, x1, dw, dbias=None, pro0=None, pro_relu=0, accumulate=F
            ptr(dw), ptr(dbias), int(accumulate), B, H, W, cout, stream_ptr())
 
 
+def conv_wgrad_r_bn(g, bn_y, coef, x0, x1, dw, pro0=None, pro_relu=0, accumulate=False, pro1=None):
+    """conv_wgrad_r with dY = coef[:,0] * g + coef[:,1] * bn_y + coef[:,2] formed on load (no bias gradient)."""
+    _chk(g, "g"); _chk(bn_y, "bn_y"); _chk(x0, "x0"); _chk(x1, "x1")
+    B, cout, H, W = g.shape
+    C0 = x0.shape[1]
+    C1 = 0 if x1 is None else x1.shape[1]
+    cin = C0 + C1
+    L = lib()
+    ns = L.query("wtpse_wgrad_r_slabs", B, H, W, cin, cout)
+    slab = workspace("wgrad_slab", ns * cout * cin * 9, g.device)
+    L.call("wtpse_conv_wgrad_r_bn", ptr(g), ptr(bn_y), ptr(coef), ptr(x0), C0, ptr(x1), C1, ptr(pro0), ptr(pro1), int(pro_relu),
+           ptr(slab), ns, ptr(dw), int(accumulate), B, H, W, cout, stream_ptr())
+
+
 # ----------------------------------------------------------------------------------------------- batch norm
 def bn_finalize(stats, count, gamma, beta, rmean, rvar, nbt, momentum=0.1, eps=1e-5):
     nblk, C, _ = stats.shape
