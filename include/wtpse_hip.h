@@ -42,7 +42,8 @@ int wtpse_conv_fwd(const float* in0, int C0, const float* in1, int C1, const flo
 int wtpse_conv_stats_blocks(int B, int H, int W);
 /* 3x3 convolution with exactly 16 output channels (DeepWT, algorithms.py:1091-1117) that also emits the per-tile partial
  * Grams of its output in the epilogue: gram_partial [wtpse_conv_stats_blocks(B,H,W)][256] = the WT loss's `partial` layout
- * with S = tiles per image (wtpse_wt_loss_fwd_partials), so that compute_whitening_loss never re-reads z from HBM. */
+ * with S = tiles per image (wtpse_wt_loss_fwd_partials), so that compute_whitening_loss never re-reads z from HBM.
+ * relu_out must be 0 (the Gram describes the stored map: the epilogue works on the pre-activation accumulators). */
 int wtpse_conv_fwd_gram(const float* in0, int C0, const float* wpacked, const float* bias, const float* pro0, int pro_relu,
                         float* out0, float* gram_partial, int B, int H, int W, int Cout, int relu_out, void* stream);
 

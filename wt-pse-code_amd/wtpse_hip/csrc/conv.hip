@@ -576,6 +576,7 @@ extern "C" int wtpse_conv_fwd_gram(const float* in0, int C0, const float* wpacke
                                    int pro_relu, float* out0, float* gram_partial, int B, int H, int W, int Cout, int relu_out,
                                    void* stream) {
   WTPSE_REQUIRE(gram_partial && Cout == 16);
+  WTPSE_REQUIRE(!relu_out);     // the Gram epilogue works on the accumulators before the ReLU clamp: it describes the stored map only without one
   return conv_fwd_impl(in0, C0, nullptr, 0, wpacked, bias, pro0, nullptr, pro_relu, out0, nullptr, Cout, nullptr, B, H, W, Cout, 3,
                        relu_out, nullptr, gram_partial, stream);
 }

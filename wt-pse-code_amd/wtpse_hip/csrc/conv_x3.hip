@@ -577,10 +577,11 @@ static bool x3_mt2(int B, int H, int W, int CoutP) {
   const int TW = W <= 16 ? 16 : 32, TH = 256 / TW;
   const int tiles = B * ceil_div(W, TW) * ceil_div(H, TH);
   bool mt2 = (CoutP % 64 == 0) && tiles * (CoutP / 64) >= 512;
-  if (const char* e = getenv("WTPSE_X3_MT")) {   // tuning override: 1 | 2
-    if (e[0] == '1') mt2 = false;
-    if (e[0] == '2' && CoutP % 64 == 0) mt2 = true;
-  }
+  // tuning override 1 | 2, read ONCE per process: the size queries (stats blocks) and the launches must agree on the tiling, also
+  // when a recorded launch plan replays the launches later
+  static const int mt_override = [] { const char* e = getenv("WTPSE_X3_MT"); return (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0; }();
+  if (mt_override == 1) mt2 = false;
+  if (mt_override == 2 && CoutP % 64 == 0) mt2 = true;
   return mt2;
 }
 
@@ -936,8 +937,8 @@ extern "C" int wtpse_wgrad_x3_supported(int Cin, int Cout, int ksize, int C0) {
 // WTPSE_X3_WGRAD_TW32=1 restores the 32-wide tiles on maps wider than 16 (comparison runs).
 static bool wgrad_x3_tw16(int W) {
   if (W <= 16) return true;
-  const char* e = getenv("WTPSE_X3_WGRAD_TW32");
-  return !(e && e[0] == '1');
+  static const bool tw32 = [] { const char* e = getenv("WTPSE_X3_WGRAD_TW32"); return e && e[0] == '1'; }();   // once per process
+  return !tw32;
 }
 
 extern "C" int wtpse_wgrad_x3_ksplit(int B, int H, int W, int Cin, int Cout) {
@@ -947,7 +948,9 @@ extern "C" int wtpse_wgrad_x3_ksplit(int B, int H, int W, int Cin, int Cout) {
   const int blk = q ? 64 : 32;
   const int nx = (Cout / blk) * (Cin / blk);
   int target = 512;    // two workgroups per CU
-  if (const char* e = getenv("WTPSE_X3_WGS")) target = atoi(e);   // tuning override
+  // tuning override, read once per process and range-checked (the slab buffer is sized from this query)
+  static const int wgs_override = [] { const char* e = getenv("WTPSE_X3_WGS"); const int v = e ? atoi(e) : 0; return (v >= 1 && v <= 65536) ? v : 0; }();
+  if (wgs_override) target = wgs_override;
   int ks = target / nx;
   if (ks < 1) ks = 1;
   if (ks > ntiles) ks = ntiles;

@@ -184,12 +184,34 @@ class TrainStep:
             if plan is not None:
                 cur = torch.cuda.current_stream()
                 self._cap_stream.wait_stream(cur)       # the plan's streams start behind the caller's stream ...
-                L.plan_replay(plan)
-                cur.wait_stream(self._cap_stream)       # ... and the caller's stream continues behind the plan
+                try:
+                    L.plan_replay(plan)
+                except Exception:
+                    # a recorded call failed mid-plan: the side streams forked inside the plan were never joined, so nothing
+                    # may run unordered behind them — drain the device before the error propagates
+                    torch.cuda.synchronize()
+                    raise
+                finally:
+                    cur.wait_stream(self._cap_stream)   # ... and the caller's stream continues behind the plan
             else:
                 g.replay()
             if net is not None:
                 self._exchange(net)
+
+    def close(self):
+        """Release the native launch plans (and their hipEvents) of a recorded step."""
+        graphs, self._graphs = self._graphs, None
+        if graphs:
+            L = ops.lib()
+            for _, _, plan in graphs:
+                if plan is not None:
+                    L.plan_destroy(plan)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def step(self, image, target_od, target_oc, noise=None):
         """image [B,3,H,W] in [-1,1], targets [B,1,H,W] in {0,1}; all device fp32, rows domain-major.
