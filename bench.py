@@ -176,7 +176,7 @@ def kernel_rooflines(B, H, dev):
     S = L.query("wtpse_wt_split", B, H * H, 0)
     partial = torch.empty(B * S * 256, device=dev)
     bufs = [torch.empty(B * 256, device=dev), torch.empty(B * 120, device=dev), torch.empty(B, device=dev),
-            torch.empty(B, device=dev), torch.empty(B, dtype=torch.float64, device=dev), torch.empty(B * 120, device=dev),
+            torch.empty(B, device=dev), torch.empty(B + 1, dtype=torch.float64, device=dev), torch.empty(B * 120, device=dev),
             torch.empty(3, device=dev)]
     pb = B // 3
 
@@ -185,7 +185,7 @@ def kernel_rooflines(B, H, dev):
                ops.stream_ptr())
     ms = time_kernel(wt)
     nbytes = B * 16 * H * H * 4.0
-    out["wt_fwd"] = {"kernel": "wtpse_wt_loss_fwd (gram_partial_k + 3 small) [%d,16,%d,%d]" % (B, H, H), "ms": ms,
+    out["wt_fwd"] = {"kernel": "wtpse_wt_loss_fwd (gram_partial_k + 2 tail launches) [%d,16,%d,%d]" % (B, H, H), "ms": ms,
                      "gbs": nbytes / ms / 1e6, "bytes_per_launch": nbytes}
     # in a training step the Gram partials come from the epilogue of the DeepWT conv that writes z (wtpse_conv_fwd_gram):
     # the loss then costs the extra epilogue time plus the tail on the partials, and never reads z

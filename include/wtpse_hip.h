@@ -141,7 +141,8 @@ int wtpse_bn_bwd_from_stats(const float* g, const float* y, const float* stats_p
 
 /* ---- WT (whitening) loss: compute_whitening_loss + compute_MMD (algorithms.py:1277-1309,59-121;
  *      shape_networks.py:561-594,240-309) ------------------------------------------------------------------------ */
-/* z [B,16,HW] -> gram[B][256] (incl. eps*I), v[B][120], offdiag[B], diag[B], rowval[D*n] (fp64), dmmd_dv[D*n][120],
+/* z [B,16,HW] -> gram[B][256] (incl. eps*I), v[B][120], offdiag[B], diag[B], rowval[D*n + 1] (fp64; the extra element is
+ * an 8-byte ticket word of the launch that merges the MMD rows with the final sums), dmmd_dv[D*n][120],
  * losses[3] = {ins_offdiag, ins_diag, domain}.  partial: [B * wtpse_wt_split(B,HW,&chunk)][256]. */
 int wtpse_wt_loss_fwd(const float* z, int B, int C, int HW, float eps, float margin, int domain_num, int per_domain,
                       float* partial, float* gram, float* v, float* offdiag, float* diag, double* rowval,

@@ -63,50 +63,56 @@ __device__ __forceinline__ int triu_index(int i, int j) {  // position of (i<j) 
   return i * (2 * WT_C - i - 1) / 2 + (j - i - 1);
 }
 
-__device__ __forceinline__ float block_sum_256(float v, float* sh) {
-  v = wave_xor_sum(v, 32);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
-  __syncthreads();
-  return sh[0] + sh[1] + sh[2] + sh[3];
-}
 
-// one workgroup per image: fold the S partials, finish G, emit v and the two L1 sums
-__global__ __launch_bounds__(256) void gram_finalize_k(const float* __restrict__ partial, int S, int HW, float eps,
-                                                       float* __restrict__ gram, float* __restrict__ v,
-                                                       float* __restrict__ offdiag, float* __restrict__ diag) {
-  __shared__ float sh[4];
+// one workgroup per image: fold the S partials, finish G, emit v and the two L1 sums.  NW waves (4 | 16): per-tile partials
+// from a conv epilogue (wtpse_conv_fwd_gram) come in hundreds per image (8 MB per call at B = 32, 256 x 256), and one
+// workgroup per image only streams them fast enough with sixteen waves' loads in flight.
+// `ticket` (optional): zeroed here for the launch that follows in the stream (mmd_final_k).
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void gram_finalize_k(const float* __restrict__ partial, int S, int HW, float eps,
+                                                           float* __restrict__ gram, float* __restrict__ v,
+                                                           float* __restrict__ offdiag, float* __restrict__ diag,
+                                                           unsigned* __restrict__ ticket) {
+  __shared__ float fold[NW][256];
+  __shared__ float shw[2][4];
   const int b = blockIdx.x, t = threadIdx.x;
-  const int i = t >> 4, j = t & 15;
-  float s = 0.f;
-  if (S >= 64) {
-    // per-tile partials from a conv epilogue (wtpse_conv_fwd_gram), hundreds per image: the four waves take every fourth
-    // partial with one 16-byte load per lane (a 1 KB row per wave and load, two rows in flight), then meet in LDS
-    __shared__ float fold[4][256];
+  if (ticket && b == 0 && t == 0) *ticket = 0u;
+  {
+    // the waves take every NW-th partial with one 16-byte load per lane (a 1 KB row per wave and load, two rows in flight),
+    // then meet in LDS; fixed order: bitwise reproducible
     const int q = t >> 6, l = t & 63;
     f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
     int k = q;
-    for (; k + 4 < S; k += 8) {
+    for (; k + NW < S; k += 2 * NW) {
       a0 += *reinterpret_cast<const f32x4*>(partial + ((size_t)b * S + k) * 256 + 4 * l);
-      a1 += *reinterpret_cast<const f32x4*>(partial + ((size_t)b * S + k + 4) * 256 + 4 * l);
+      a1 += *reinterpret_cast<const f32x4*>(partial + ((size_t)b * S + k + NW) * 256 + 4 * l);
     }
-    for (; k < S; k += 4) a0 += *reinterpret_cast<const f32x4*>(partial + ((size_t)b * S + k) * 256 + 4 * l);
+    for (; k < S; k += NW) a0 += *reinterpret_cast<const f32x4*>(partial + ((size_t)b * S + k) * 256 + 4 * l);
     a0 += a1;
 #pragma unroll
     for (int e = 0; e < 4; ++e) fold[q][4 * l + e] = a0[e];
-    __syncthreads();
-    s = (fold[0][t] + fold[1][t]) + (fold[2][t] + fold[3][t]);
-  } else {
-    for (int k = 0; k < S; ++k) s += partial[((size_t)b * S + k) * 256 + t];
   }
-  float g = s / (float)(HW - 1) + (i == j ? eps : 0.f);
-  gram[(size_t)b * 256 + t] = g;
-  if (i < j) v[(size_t)b * WT_NV + triu_index(i, j)] = g;
-  float so = block_sum_256(i < j ? fabsf(g) : 0.f, sh);
-  float sd = block_sum_256(i == j ? fabsf(g - 1.f) : 0.f, sh);
+  __syncthreads();
+  float so = 0.f, sd = 0.f;
+  if (t < 256) {
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) s += fold[q][t];
+    const int i = t >> 4, j = t & 15;
+    const float g = s / (float)(HW - 1) + (i == j ? eps : 0.f);
+    gram[(size_t)b * 256 + t] = g;
+    if (i < j) v[(size_t)b * WT_NV + triu_index(i, j)] = g;
+    so = wave_xor_sum(i < j ? fabsf(g) : 0.f, 32);
+    sd = wave_xor_sum(i == j ? fabsf(g - 1.f) : 0.f, 32);
+    if ((t & 63) == 0) {
+      shw[0][t >> 6] = so;
+      shw[1][t >> 6] = sd;
+    }
+  }
+  __syncthreads();
   if (t == 0) {
-    offdiag[b] = so;
-    diag[b] = sd;
+    offdiag[b] = (shw[0][0] + shw[0][1]) + (shw[0][2] + shw[0][3]);
+    diag[b] = (shw[1][0] + shw[1][1]) + (shw[1][2] + shw[1][3]);
   }
 }
 
@@ -116,10 +122,22 @@ __global__ __launch_bounds__(256) void gram_finalize_k(const float* __restrict__
 //   rowval_i = sum_j c_ij K_ij,  c_ij = (D-1)/(n^2 npairs) within a domain, -1/(n^2 npairs) across domains
 //   d mmd / d x_i = (4/(n^2 npairs)) * sum_j s_ij K_ij (x_i - x_j),  s_ij = -(D-1) within, +1 across
 // Arithmetic is fp64: the value is a difference of O(1) kernel means that is ~1e-6 at initialisation.
+// `fin` (optional): the whole tail in this launch.  The workgroup whose row value arrives last (an agent-scope ticket) also
+// forms the three loss values that wt_final_k would: one dependent launch (and its ~5 us of latency) fewer per loss call.
+struct WtFinalArgs {
+  const float* offdiag;
+  const float* diag;
+  int B, Bnorm;
+  float margin;
+  float* losses;
+  unsigned* ticket;     // zero when the launch starts (gram_finalize_k); left at zero for the next call
+};
+
 __global__ __launch_bounds__(128) void mmd_rows_k(const float* __restrict__ v, int D, int n, double* __restrict__ rowval,
-                                                  float* __restrict__ dmmd_dv) {
+                                                  float* __restrict__ dmmd_dv, WtFinalArgs fin) {
   extern __shared__ double kbuf[];  // [R] signed kernel weights s_ij * K_ij
   __shared__ double shred[2];
+  __shared__ int last_s;
   const int R = D * n;
   const int i = blockIdx.x, t = threadIdx.x;
   const float* xi = v + (size_t)i * WT_NV;
@@ -147,12 +165,55 @@ __global__ __launch_bounds__(128) void mmd_rows_k(const float* __restrict__ v, i
   for (int m = 1; m < 64; m <<= 1) part += __shfl_xor(part, m, 64);
   if ((t & 63) == 0) shred[t >> 6] = part;
   __syncthreads();
-  if (t == 0) rowval[i] = D > 1 ? (shred[0] + shred[1]) * inv : 0.0;
+  const double rv = D > 1 ? (shred[0] + shred[1]) * inv : 0.0;
+  if (t == 0) {
+    if (fin.ticket) {
+      // publish the row value write-through (an 8-byte agent-scope store), drain it, then take a ticket: the last arriver
+      // reads every row value with agent-scope loads (MI355X_MICROARCH.md, inter-workgroup visibility: all-sc1 hand-off)
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(rowval) + i, (unsigned long long)__double_as_longlong(rv),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned old = __hip_atomic_fetch_add(fin.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last_s = old == (unsigned)(R - 1);
+    } else {
+      rowval[i] = rv;
+      last_s = 0;
+    }
+  }
   if (t < WT_NV) {
     double g = 0.0;
     double xik = xi[t];
     for (int j = 0; j < R; ++j) g += kbuf[j] * (xik - (double)v[(size_t)j * WT_NV + t]);
     dmmd_dv[(size_t)i * WT_NV + t] = D > 1 ? (float)(4.0 * inv * g) : 0.f;
+  }
+  __syncthreads();
+  if (!last_s) return;
+  // ---- the last row's workgroup: the three loss values (as wt_final_k; offdiag / diag come from the previous launch)
+  double a = 0.0, d = 0.0, m = 0.0;
+  for (int b = t; b < fin.B; b += 128) {
+    a += fmaxf((fin.offdiag[b] - fin.margin) / (float)WT_NV, 0.f);
+    d += fmaxf((fin.diag[b] - fin.margin) / (float)WT_C, 0.f);
+  }
+  for (int r = t; r < R; r += 128)
+    m += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(rowval) + r, __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_AGENT));
+  for (int k = 1; k < 64; k <<= 1) {
+    a += __shfl_xor(a, k, 64);
+    d += __shfl_xor(d, k, 64);
+    m += __shfl_xor(m, k, 64);
+  }
+  __shared__ double fsh[3][2];
+  if ((t & 63) == 0) {
+    fsh[0][t >> 6] = a;
+    fsh[1][t >> 6] = d;
+    fsh[2][t >> 6] = m;
+  }
+  __syncthreads();
+  if (t == 0) {
+    fin.losses[0] = (float)((fsh[0][0] + fsh[0][1]) / fin.Bnorm);
+    fin.losses[1] = (float)((fsh[1][0] + fsh[1][1]) / fin.Bnorm);
+    fin.losses[2] = (float)(fsh[2][0] + fsh[2][1]);
+    __hip_atomic_store(fin.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -286,6 +347,21 @@ __global__ __launch_bounds__(256) void gram_bwd_k(const float* __restrict__ z, c
 }
 
 // ------------------------------------------------------------------------------------------------ C ABI
+// The tail of a forward call in two launches: per-image fold (+ G, v, L1 sums), then the MMD rows with the final sums taken by
+// the last row's workgroup.  rowval holds D*n doubles plus one 8-byte ticket word.
+static void wt_tail_launch(const float* partial, int S, int B, int HW, float eps, float margin, int domain_num, int per_domain,
+                           float* gram, float* v, float* offdiag, float* diag, double* rowval, float* dmmd_dv, float* losses,
+                           hipStream_t st) {
+  const int R = domain_num * per_domain;
+  unsigned* ticket = reinterpret_cast<unsigned*>(rowval + R);
+  if (S >= 32)
+    hipLaunchKernelGGL(gram_finalize_k<16>, dim3(B), dim3(1024), 0, st, partial, S, HW, eps, gram, v, offdiag, diag, ticket);
+  else
+    hipLaunchKernelGGL(gram_finalize_k<4>, dim3(B), dim3(256), 0, st, partial, S, HW, eps, gram, v, offdiag, diag, ticket);
+  WtFinalArgs fin{offdiag, diag, B, B, margin, losses, ticket};
+  hipLaunchKernelGGL(mmd_rows_k, dim3(R), dim3(128), R * sizeof(double), st, v, domain_num, per_domain, rowval, dmmd_dv, fin);
+}
+
 extern "C" int wtpse_wt_split(int B, int HW, int* chunk_out) {
   // aim for ~768 workgroups (3 per CU) of at least 2048 pixels, chunks a multiple of 512 pixels (one full
   // wave-iteration per wave): few, fat partials keep the per-image fold short
@@ -313,9 +389,7 @@ extern "C" int wtpse_wt_loss_fwd(const float* z, int B, int C, int HW, float eps
     hipLaunchKernelGGL(gram_partial_k<true>, dim3(B * S), dim3(256), 0, st, z, HW, S, chunk, partial);
   else
     hipLaunchKernelGGL(gram_partial_k<false>, dim3(B * S), dim3(256), 0, st, z, HW, S, chunk, partial);
-  hipLaunchKernelGGL(gram_finalize_k, dim3(B), dim3(256), 0, st, partial, S, HW, eps, gram, v, offdiag, diag);
-  hipLaunchKernelGGL(mmd_rows_k, dim3(R), dim3(128), R * sizeof(double), st, v, domain_num, per_domain, rowval, dmmd_dv);
-  hipLaunchKernelGGL(wt_final_k, dim3(1), dim3(256), 0, st, offdiag, diag, B, B, margin, rowval, R, losses);
+  wt_tail_launch(partial, S, B, HW, eps, margin, domain_num, per_domain, gram, v, offdiag, diag, rowval, dmmd_dv, losses, st);
   return wtpse_status();
 }
 
@@ -329,9 +403,7 @@ extern "C" int wtpse_wt_loss_fwd_partials(const float* partial, int S, int B, in
   const int R = domain_num * per_domain;
   WTPSE_REQUIRE(R <= B);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(gram_finalize_k, dim3(B), dim3(256), 0, st, partial, S, HW, eps, gram, v, offdiag, diag);
-  hipLaunchKernelGGL(mmd_rows_k, dim3(R), dim3(128), R * sizeof(double), st, v, domain_num, per_domain, rowval, dmmd_dv);
-  hipLaunchKernelGGL(wt_final_k, dim3(1), dim3(256), 0, st, offdiag, diag, B, B, margin, rowval, R, losses);
+  wt_tail_launch(partial, S, B, HW, eps, margin, domain_num, per_domain, gram, v, offdiag, diag, rowval, dmmd_dv, losses, st);
   return wtpse_status();
 }
 
@@ -371,7 +443,7 @@ extern "C" int wtpse_wt_gram_fwd(const float* z, int B, int C, int HW, float eps
     hipLaunchKernelGGL(gram_partial_k<true>, dim3(B * S), dim3(256), 0, st, z, HW, S, chunk, partial);
   else
     hipLaunchKernelGGL(gram_partial_k<false>, dim3(B * S), dim3(256), 0, st, z, HW, S, chunk, partial);
-  hipLaunchKernelGGL(gram_finalize_k, dim3(B), dim3(256), 0, st, partial, S, HW, eps, gram, v, offdiag, diag);
+  hipLaunchKernelGGL(gram_finalize_k<4>, dim3(B), dim3(256), 0, st, partial, S, HW, eps, gram, v, offdiag, diag, (unsigned*)nullptr);
   return wtpse_status();
 }
 
@@ -393,6 +465,6 @@ extern "C" int wtpse_mmd_fwd(const float* v, int domain_num, int per_domain, dou
   WTPSE_REQUIRE(v && rowval && dmmd_dv && domain_num >= 1 && per_domain >= 1);
   const int R = domain_num * per_domain;
   hipLaunchKernelGGL(mmd_rows_k, dim3(R), dim3(128), R * sizeof(double), (hipStream_t)stream, v, domain_num, per_domain,
-                     rowval, dmmd_dv);
+                     rowval, dmmd_dv, WtFinalArgs{nullptr, nullptr, 0, 0, 0.f, nullptr, nullptr});
   return wtpse_status();
 }

@@ -273,7 +273,7 @@ def wt_loss_fwd(z, domain_num, per_domain, margin=0.0, eps=1e-5, losses_out=None
     st.v = torch.empty((B, 120), dtype=torch.float32, device=dev)
     st.offdiag = torch.empty((B,), dtype=torch.float32, device=dev)
     st.diag = torch.empty((B,), dtype=torch.float32, device=dev)
-    rowval = torch.empty((max(R, 1),), dtype=torch.float64, device=dev)
+    rowval = torch.empty((max(R, 1) + 1,), dtype=torch.float64, device=dev)     # + the tail launch's ticket word
     st.dmmd_dv = torch.empty((max(R, 1), 120), dtype=torch.float32, device=dev)
     st.losses = losses_out if losses_out is not None else torch.empty((3,), dtype=torch.float32, device=dev)
     if gram_partial is not None:
