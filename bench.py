@@ -47,18 +47,20 @@ def parse():
     ap.add_argument("--workload", choices=["full", "seg"], default="full",
                     help="full = configs[2] (seg + shape nets + WT loss); seg = configs[1] (seg-net only)")
     ap.add_argument("--bn-sync", type=int, default=0, help="1: BatchNorm statistics over the global batch (parity mode)")
-    ap.add_argument("--launch", choices=["eager", "plan", "graph"], default="eager",
-                    help="eager (default): one ctypes call per launch; plan: the step is recorded once and replayed from native "
-                         "code (csrc/plan.hip; 2x less host time per step: what a small batch needs, e.g. the reference's own "
-                         "B=6 — at B=32 the GPU is the bottleneck either way and eager measures ~2 %% faster); graph: hipGraph "
-                         "replay (slower than eager on this runtime, profiles/r02_hipgraph_vs_eager.txt).  Exact data-parallel "
-                         "mode always runs eagerly")
+    ap.add_argument("--launch", choices=["eager", "plan", "graph"], default="plan",
+                    help="plan (default): the step is recorded once during set-up and replayed from native code (csrc/plan.hip): "
+                         "5 ms instead of 22 ms of host time per step at B=32 (same images/s within noise: 573 vs 577), 319 vs 261 "
+                         "images/s at the reference's own B=6 where eager launches are host-bound; eager: one ctypes call per "
+                         "launch; graph: hipGraph replay (slower than eager on this runtime, profiles/r02_hipgraph_vs_eager.txt).  "
+                         "Exact data-parallel mode always runs eagerly")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-full", action="store_true",
                     help="SURVEY.md 8d protocol in full: 3 warm-up + 10 timed iterations at B=6 and B=30 (minutes of CPU time)")
-    ap.add_argument("--roi-presteps", type=int, default=-1,
-                    help="untimed set-up steps that train the optic-disc net until its prediction (the ROI of calls C/D) is "
-                         "no longer empty; -1 = until 2-60 %% of the pixels are inside (at most 400), 0 = none")
+    ap.add_argument("--roi-presteps", type=int, default=70,
+                    help="untimed set-up steps that train the optic-disc net so that its prediction (the ROI of calls C/D) is no "
+                         "longer empty: a FIXED count (default 70: od_pred then covers ~21 %% of the pixels of the seed-1 batch; "
+                         "reported as `roi_presteps`), so that runs and profiles are comparable; -1 = adaptive (until 10-60 %% of "
+                         "the pixels are inside, at most 400), 0 = none")
     ap.add_argument("--no-kernel-roofline", action="store_true")
     ap.add_argument("--kernels-only", action="store_true",
                     help="run only the per-kernel roofline launches (used under rocprofv3 --pmc to measure HBM traffic)")
@@ -153,7 +155,32 @@ def kernel_rooflines(B, H, dev):
     out["x3_fwd"] = agg(fw, "conv_x3_k forward, %s: %s, BatchNorm+ReLU prologue on both inputs, bias + BatchNorm partials" % (x3, shape))
     out["x3_dgrad"] = agg(dg, "conv_x3_k data gradient, %s: %s, split output" % (x3, shape))
     out["x3_conv"] = agg(fw + dg, "conv_x3_k forward + data gradient, %s: %s" % (x3, shape))
-    out["x3_wgrad"] = agg(wg, "conv_wgrad_x3_k + slab fold, %s: %s, BatchNorm+ReLU prologue on both inputs" % (x3, shape))
+    out["x3_wgrad"] = agg(wg, "wgrad_r_k (register-resident operands, v_mfma_f32_16x16x32_bf16) + slab fold, %s: %s, "
+                          "BatchNorm+ReLU prologue on both inputs" % (x3, shape))
+    # the 16-channel 256x256 layers (inc.conv2/3, DeepWT, teacher inc): forward on the fp32-input MFMA (conv_fwd_k<3,0,5>),
+    # weight gradient on wgrad_r_k<1,1> — HBM-bound: 2 x 16 x H x W x 4 bytes per image either way
+    C16 = 16
+    x16 = torch.randn(B, C16, H, H, device=dev)
+    dy16 = torch.randn(B, C16, H, H, device=dev)
+    p16 = torch.rand(C16, 2, device=dev) + 0.5
+
+    class Holder16(E.HipNet):
+        def __init__(self):
+            super().__init__()
+            self.conv = E.ConvP(C16, C16, 3)
+            self._finish_init()
+    n16 = Holder16().to(dev)
+    n16.ensure_ready(repack=True)
+    a16 = E.Act(x16, p16, True)
+    nb16 = 2.0 * B * C16 * H * H * 4
+    ms = time_kernel(lambda: E._conv(n16.conv, a16, None, False, True))
+    out["c16_fwd"] = {"kernel": "conv_fwd_k<3,0,5> 16->16 3x3 @%dx%d B=%d (BatchNorm+ReLU prologue, bias, BatchNorm partials)" % (H, H, B),
+                      "ms": ms, "gbs": nb16 / ms / 1e6, "bytes_per_launch": nb16, "tflops": 2.0 * 16 * 16 * 9 * H * H * B / ms / 1e9}
+    n16.begin_backward()
+    ms = time_kernel(lambda: E._wgrad(n16.conv, dy16, a16, None, with_bias=True))
+    out["c16_wgrad"] = {"kernel": "wgrad_r_k<1,1> + slab fold 16->16 3x3 @%dx%d B=%d (prologue, with bias gradient)" % (H, H, B),
+                        "ms": ms, "gbs": nb16 / ms / 1e6, "bytes_per_launch": nb16, "tflops": 2.0 * 16 * 16 * 9 * H * H * B / ms / 1e9}
+    del x16, dy16, n16
     C, Hc = 64, H // 2
     x = torch.randn(B, C, Hc, Hc, device=dev)
     w = torch.randn(C, C, 3, 3, device=dev) * 0.05
@@ -214,6 +241,19 @@ def kernel_rooflines(B, H, dev):
     ms = time_kernel(wtb)
     out["wt_bwd"] = {"kernel": "wtpse_wt_loss_bwd (gram_bwd_k) [%d,16,%d,%d]" % (B, H, H), "ms": ms,
                      "gbs": 2 * nbytes / ms / 1e6, "bytes_per_launch": 2 * nbytes}
+    del z, dz, partial
+    # The literal 2-D DWT BASELINE.json's wording names: a stand-alone micro-benchmark, NOT part of WT-PSE, parity unpinned
+    # (csrc/dwt.hip).  Algorithmic bytes: every level reads and writes its region once.
+    from wtpse_hip import dwt
+    out["dwt"] = []
+    for shp, lv in (((B, 16, H, H), 3), ((max(B // 2, 1), 16, 2 * H, 2 * H), 4)):
+        xd = torch.randn(*shp, device=dev)
+        nb = 8.0 * xd.numel() * sum(0.25 ** l for l in range(lv))
+        for wv in ("haar", "db2"):
+            ms = time_kernel(lambda: dwt.dwt2(xd, wv, lv))
+            out["dwt"].append({"kernel": "wtpse_dwt2_fwd %s, %d levels, %s" % (wv, lv, list(shp)), "ms": ms, "gbs": nb / ms / 1e6,
+                               "bytes_per_launch": nb})
+        del xd
     return out
 
 
@@ -424,6 +464,7 @@ def main():
                        "bn_sync": bool(args.bn_sync), "step": "calls A-D + 4 backward + 4 Adam (Trainer.py:766-914)",
                        "launch": ("native launch plan" if ts.plan else "hipGraph replay") if ts.graph else "eager",
                        "roi": "od_pred covers %.3f of the pixels after %d untimed set-up steps" % (frac, presteps)},
+            "roi_presteps": presteps,
             "host_enqueue_ms_per_step": 1e3 * t_host / args.steps,
             "host_cpu_ms_per_step": 1e3 * timed.cpu / args.steps,
             "conv_tflops_end_to_end": ips * GFLOP_PER_IMAGE * (H * H / 65536.0) / 1e3 if full else None,
@@ -442,9 +483,16 @@ def main():
                 r = kr[k]
                 return {"bound": "mfma", "kernel": r["kernel"], "achieved": r["tflops"], "peak": MFMA_X3_PEAK_TF,
                         "unit": "TFLOP/s", "frac": r["tflops"] / MFMA_X3_PEAK_TF, "traffic": tr.get(traffic_key),
+                        "traffic_source": "committed profile profiles/pmc_traffic.json (rocprofv3 --pmc of `bench.py --kernels-only`), "
+                                          "not measured by this run",
+                        "dvfs_ceiling_note": "on random operands the chip holds 1.5-1.9 GHz under bf16 MFMA streams, not 2.4: a bare "
+                                             "LDS-fed MFMA loop reaches ~250 TFLOP/s x3-equivalent, a register-fed 16x16x32 loop ~320 "
+                                             "(profiles/r03_mfma_peak.txt, tools/probe/mfma_peak.hip)",
                         "frac_of_fp32_mfma_peak": r["tflops"] / MFMA_F32_PEAK_TF,
                         "peak_note": "bf16 dense MFMA peak (16 x 157.3) / 6 products per fp32 multiply; fp32-input MFMA peak 157.3",
                         "ms_per_launch": r["ms"], "flop_per_launch": r["flop_per_launch"], "launches": r.get("launches")}
+            if dom:
+                dom["source"] = "committed profile %s, not measured by this run" % dom["profile"]
             line["roofline"] = dict(mfma_line(lead, lead), dominant_in_profile=dom)
             for k in ("x3_fwd", "x3_dgrad", "x3_wgrad"):
                 line["roofline_" + k] = mfma_line(k, "x3_wgrad" if k == "x3_wgrad" else "x3_conv")
@@ -459,6 +507,16 @@ def main():
                                          "ms_per_launch": w["ms"], "bytes_per_launch": w["bytes_per_launch"]}
                 if "fused_in_step" in w:
                     line["roofline_" + k]["fused_in_step"] = w["fused_in_step"]
+            for k in ("c16_fwd", "c16_wgrad"):
+                w = kr[k]
+                line["roofline_" + k] = {"bound": "hbm", "kernel": w["kernel"], "achieved": w["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                         "frac": w["gbs"] / HBM_PEAK_GBS, "traffic": tr.get(k), "ms_per_launch": w["ms"],
+                                         "bytes_per_launch": w["bytes_per_launch"], "tflops": w["tflops"]}
+            line["roofline_dwt"] = [{"bound": "hbm", "kernel": w["kernel"], "achieved": w["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": w["gbs"] / HBM_PEAK_GBS, "traffic": tr.get("dwt_" + w["kernel"].split()[1].rstrip(",")),
+                                     "ms_per_launch": w["ms"], "bytes_per_launch": w["bytes_per_launch"],
+                                     "note": "stand-alone micro-benchmark: the reference has no wavelet transform — not part of WT-PSE, "
+                                             "parity unpinned (SURVEY.md 8f-4)"} for w in kr["dwt"]]
         if world == 1 and not args.no_cpu_baseline:
             log("cpu baseline")
             line["cpu_baseline"] = cpu_baseline(H, full, args.cpu_baseline_full)
