@@ -252,7 +252,7 @@ def kernel_rooflines(B, H, dev):
         for wv in ("haar", "db2"):
             ms = time_kernel(lambda: dwt.dwt2(xd, wv, lv))
             out["dwt"].append({"kernel": "wtpse_dwt2_fwd %s, %d levels, %s" % (wv, lv, list(shp)), "ms": ms, "gbs": nb / ms / 1e6,
-                               "bytes_per_launch": nb})
+                               "bytes_per_launch": nb, "min_bytes": 8.0 * xd.numel(), "gbs_min_bytes": 8.0 * xd.numel() / ms / 1e6})
         del xd
     return out
 
@@ -515,6 +515,10 @@ def main():
             line["roofline_dwt"] = [{"bound": "hbm", "kernel": w["kernel"], "achieved": w["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                      "frac": w["gbs"] / HBM_PEAK_GBS, "traffic": tr.get("dwt_" + w["kernel"].split()[1].rstrip(",")),
                                      "ms_per_launch": w["ms"], "bytes_per_launch": w["bytes_per_launch"],
+                                     "bytes_note": "bytes_per_launch: every level reads and writes its region once (round 2's accounting); "
+                                                   "the fused kernels keep the levels after the first in LDS, so the plane is read once and "
+                                                   "the coefficients written once: achieved_min_bytes = 2 x 4 B x elements / time",
+                                     "achieved_min_bytes": w["gbs_min_bytes"], "frac_min_bytes": w["gbs_min_bytes"] / HBM_PEAK_GBS,
                                      "note": "stand-alone micro-benchmark: the reference has no wavelet transform — not part of WT-PSE, "
                                              "parity unpinned (SURVEY.md 8f-4)"} for w in kr["dwt"]]
         if world == 1 and not args.no_cpu_baseline:

@@ -30,7 +30,11 @@ def test_specification_properties(wavelet):
 @pytest.mark.gpu
 @pytest.mark.parametrize("wavelet", ["haar", "db2"])
 @pytest.mark.parametrize("shape,levels", [((2, 3, 32, 64), 1), ((1, 2, 64, 32), 3), ((2, 2, 128, 256), 4), ((1, 1, 16, 16), 4),
-                                          ((1, 2, 48, 80), 2)])
+                                          ((1, 2, 48, 80), 2),
+                                          # square 256 / 512 planes: the streaming / fused analysis kernels (rows owned by a wave,
+                                          # the levels after the first in LDS)
+                                          ((2, 3, 256, 256), 1), ((3, 2, 256, 256), 3), ((1, 2, 256, 256), 7),
+                                          ((1, 2, 512, 512), 1), ((2, 1, 512, 512), 2), ((1, 3, 512, 512), 4)])
 def test_gpu_dwt_vs_specification(wavelet, shape, levels):
     from wtpse_hip import dwt
     g = torch.Generator().manual_seed(3)
