@@ -47,8 +47,9 @@ def parse():
     ap.add_argument("--workload", choices=["full", "seg"], default="full",
                     help="full = configs[2] (seg + shape nets + WT loss); seg = configs[1] (seg-net only)")
     ap.add_argument("--bn-sync", type=int, default=0, help="1: BatchNorm statistics over the global batch (parity mode)")
-    ap.add_argument("--launch", choices=["eager", "plan", "graph"], default="plan",
-                    help="plan (default): the step is recorded once during set-up and replayed from native code (csrc/plan.hip): "
+    ap.add_argument("--launch", choices=["eager", "plan", "graph"], default=None,
+                    help="default: plan on one GPU, eager with several (the gradient all-reduces then start inside the backward, "
+                         "overlapped with it: collectives cannot sit inside a recorded stretch).  plan: the step is recorded once during set-up and replayed from native code (csrc/plan.hip): "
                          "5 ms instead of 22 ms of host time per step at B=32 (same images/s within noise: 573 vs 577), 319 vs 261 "
                          "images/s at the reference's own B=6 where eager launches are host-bound; eager: one ctypes call per "
                          "launch; graph: hipGraph replay (slower than eager on this runtime, profiles/r02_hipgraph_vs_eager.txt).  "
@@ -350,6 +351,8 @@ def main():
                  "Philox stream and needs a per-GPU batch that is a multiple of the 3 source domains: --batch %d is not "
                  "(use e.g. --batch 30 or 33)" % args.batch)
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.launch is None:
+        args.launch = "plan" if world == 1 else "eager"
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)

@@ -42,6 +42,33 @@ def host_logic(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
+def host_buckets(rank, world, port, out_dir):
+    """CPU + gloo: the bucketed, overlapped gradient exchange (pieces announced out of order, gaps left for the final call)
+    equals the single all-reduce of the whole buffer."""
+    import torch
+    import torch.distributed as dist
+    from wtpse_hip.dp import DataParallel
+    _init(rank, world, port)
+    n = 10007
+    base = (torch.arange(n, dtype=torch.float32) % 97.0) * world                 # sums and means stay exact in fp32
+    mine = base * (rank + 1)
+    want = base * (world + 1) / 2.0
+    owner = object()
+    res = {}
+    for overlap in (True, False):
+        dp = DataParallel(world, rank, torch.device("cpu"), bn_sync=False, overlap=overlap)
+        g = mine.clone()
+        dp.bucket_ready(owner, g, 9000, n)            # the heads, first
+        dp.bucket_ready(owner, g, 3000, 7000)         # the decoder
+        dp.bucket_ready(owner, g, 7000, 7000)         # an empty range
+        assert (id(owner) in dp._pieces) == overlap
+        dp.allreduce_grads(owner, g)                  # [0, 3000) and [7000, 9000) are reduced here
+        res["overlap" if overlap else "single"] = bool(torch.equal(g, want))
+        assert id(owner) not in dp._pieces
+    torch.save(res, os.path.join(out_dir, "r%d.pt" % rank))
+    dist.destroy_process_group()
+
+
 def gpu_exact(rank, world, port, out_dir, B_g, pb_g, H):
     """GPU (all ranks share cuda:0, gloo transport): calls A and B in exact mode; dumps the averaged flat gradients."""
     import torch
@@ -167,6 +194,8 @@ if __name__ == "__main__":
     fn, rank, world, port, out_dir = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
     if fn == "host":
         host_logic(rank, world, port, out_dir)
+    elif fn == "buckets":
+        host_buckets(rank, world, port, out_dir)
     elif fn == "nccl":
         nccl_rccl(rank, world, port, out_dir, *[int(a) for a in sys.argv[6:9]])
     else:

@@ -47,3 +47,13 @@ def test_gloo_world2(tmp_path):
     for r in res:
         assert r["gather"] and r["mean"] and r["sum"], r
     assert sorted(res[0]["rows"] + res[1]["rows"]) == list(range(12))
+
+
+def test_gloo_bucketed_exchange_world2_and_3(tmp_path):
+    """The overlapped gradient exchange (ranges announced while the backward is still running, dp.bucket_ready) gives the same
+    averages as the single all-reduce, with 2 and with 3 ranks."""
+    for world in (2, 3):
+        d = tmp_path / ("w%d" % world)
+        d.mkdir()
+        for r in run_workers("buckets", world, d):
+            assert r == {"overlap": True, "single": True}, (world, r)

@@ -167,7 +167,9 @@ class ShapeVariationalDist_x(E.HipNet, E.UNetBody):
         g_kd, g_off, g_diag, g_dom = c(g_kd), c(g_off), c(g_diag), c(g_dom)
         dmu = ops.mse_bwd(t.mu_s, t.mu_t, g_kd, w_kd)
         dfmap = E.head_bwd(self.mu_prior, t.hmu, dmu, (0, 2, 4))
-        d_relu_z2 = E.unet_bwd(self, t.unet, dfmap)
+        # data-parallel overlap: up1 .. logvar_prior (registration order: the decoder and the two heads) are complete after the
+        # decoder's backward and go out beside the encoder's and DeepWT's
+        d_relu_z2 = E.unet_bwd(self, t.unet, dfmap, decoder_done=lambda: self.grads_ready(self.up1, self.logvar_prior))
         dz2 = ops.relu_mask(d_relu_z2, t.w2.z2)
         self._wt_loss_bwd(t.st2, dz2, g_off=g_off, g_diag=g_diag, g_dom=g_dom, w_off=w_off / 3.0, w_diag=2.0 * w_diag / 3.0,
                           w_dom=w_dom / 3.0)

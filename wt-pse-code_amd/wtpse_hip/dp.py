@@ -4,9 +4,13 @@ The reference is single-device (train.py:33); this is new functionality (SURVEY.
 mini-batch is domain-major [D0 x pb, D1 x pb, D2 x pb] (Trainer.py:45-55); rank g of G takes rows
 [d*pb + g*pb/G, d*pb + (g+1)*pb/G) of EVERY domain, so its local batch is domain-major too and sees all domains.
 
-Gradient exchange: ONE all-reduce (mean) of a network's flat gradient buffer per backward — 25.5 MB (WT_PSE) /
-12.8 MB (student) — instead of ~390 per-tensor reductions.  Convention: every rank differentiates its rank-local
-loss L_r with mean_r L_r = L_global, so the exchange is a plain average.
+Gradient exchange: all-reduces (mean) of contiguous RANGES of a network's flat gradient buffer — 25.5 MB (WT_PSE) /
+12.8 MB (student) in two to four pieces — instead of ~390 per-tensor reductions.  Convention: every rank differentiates
+its rank-local loss L_r with mean_r L_r = L_global, so the exchange is a plain average.
+Overlap ("Collective 1"): the backward schedules announce a range as soon as nothing will write it any
+more (`HipNet.grads_ready`: the 1x1 heads, the decoder, the teacher ... in the order the backward finishes them); its
+all-reduce is issued behind the streams that produced it and runs on RCCL's stream beside the rest of the backward;
+`allreduce_grads` — called where the single collective used to be — reduces what is left and joins the pieces.
 
 Two modes
   * `bn_sync=False` (throughput; standard DDP semantics): BatchNorm statistics, the MMD term and the OC pos_weight
@@ -43,8 +47,11 @@ def gathered_to_global_index(n_local, domains, world):
 
 
 class DataParallel:
-    def __init__(self, world, rank, device, bn_sync=False, group=None, domains=3):
+    def __init__(self, world, rank, device, bn_sync=False, group=None, domains=3, overlap=True):
         self.world, self.rank, self.device = int(world), int(rank), device
+        self.overlap = bool(overlap)
+        self._pieces = {}            # id(net) -> [(lo, hi, work, view)]: ranges whose all-reduce is in flight
+        self._issue = {}             # device -> stream the early all-reduces are issued from
         self.bn_sync = bool(bn_sync)
         self.exact = self.bn_sync
         self.group = group
@@ -65,9 +72,40 @@ class DataParallel:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
+    def bucket_ready(self, net, gflat, lo, hi, streams=()):
+        """gflat[lo:hi] is final once the work queued so far on `streams` has run: start its all-reduce now, behind them,
+        beside whatever the caller enqueues next.  (No-op without `overlap`.)"""
+        if not self.overlap or hi <= lo:
+            return
+        view = gflat[lo:hi]
+        if gflat.is_cuda:
+            cs = self._issue.get(gflat.device)
+            if cs is None:
+                cs = self._issue[gflat.device] = torch.cuda.Stream(device=gflat.device)
+            for st in streams:
+                cs.wait_stream(st)
+            with torch.cuda.stream(cs):        # RCCL's own stream picks the dependency up from the stream the call is made on
+                work = dist.all_reduce(view, op=dist.ReduceOp.AVG if self._avg_native else dist.ReduceOp.SUM, group=self.group,
+                                       async_op=True)
+        else:
+            work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._pieces.setdefault(id(net), []).append((lo, hi, work, view))
+
     def allreduce_grads(self, net, gflat):
-        """One collective per network per backward, on the flat gradient buffer."""
-        self.allreduce_mean_(gflat)
+        """Finish a network's gradient exchange: all-reduce the ranges no bucket_ready() covered (all of it without
+        overlap: one collective per backward) and make the current stream wait for the pieces in flight."""
+        pieces = self._pieces.pop(id(net), [])
+        pos, n = 0, gflat.numel()
+        for lo, hi, _, _ in sorted(pieces, key=lambda p: p[0]):
+            if lo > pos:
+                self.allreduce_mean_(gflat[pos:lo])
+            pos = max(pos, hi)
+        if pos < n:
+            self.allreduce_mean_(gflat[pos:n])
+        for _, _, work, view in pieces:
+            work.wait()                           # RCCL: the current stream waits for the collective; gloo: the host does
+            if not (gflat.is_cuda and self._avg_native):
+                view.mul_(1.0 / self.world)
 
     def broadcast_params(self, nets):
         for n in nets:

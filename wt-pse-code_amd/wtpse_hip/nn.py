@@ -320,6 +320,25 @@ class HipNet(nn.Module):
         off = self._offsets[i]
         return self._gtarget[off:off + p.numel()]
 
+    def grads_ready(self, first, last=None):
+        """Data-parallel overlap: the parameter gradients of the consecutive submodules `first` .. `last` (a contiguous range of
+        the flat buffer) are complete once the work queued so far on the current stream and on its weight-gradient side stream
+        has run — their all-reduce can start now, beside the rest of the backward (dp.py).  Without data parallelism, while a
+        launch plan is being recorded (collectives stay outside plans) or when gradients accumulate: nothing happens."""
+        dp = self._dp
+        if dp is None or not dp.overlap or self._gtarget is not self._gflat or ops.lib()._rec is not None:
+            return
+        last = first if last is None else last
+        pf, pl = next(first.parameters()), list(last.parameters())[-1]
+        lo = self._offsets[self._pindex[id(pf)]]
+        hi = self._offsets[self._pindex[id(pl)]] + pl.numel()
+        cur = torch.cuda.current_stream()
+        streams = [cur]
+        side = _SIDE.get((self._gflat.device, ops.stream_ptr()))
+        if side is not None:
+            streams.append(side)
+        dp.bucket_ready(self, self._gtarget, lo, hi, streams)
+
     def end_backward(self):
         joins = self.__dict__.get("_join")
         if joins:                                   # helper streams this backward put work on (weight gradients, prior chain)
@@ -720,13 +739,16 @@ def unet_fwd(net, x1, training, want_tape=True):
     return x, t
 
 
-def unet_bwd(net, t, dfeat, need_dx1=True):
-    """-> gradient wrt the activated x1 (None if not needed)."""
+def unet_bwd(net, t, dfeat, need_dx1=True, decoder_done=None):
+    """-> gradient wrt the activated x1 (None if not needed).  decoder_done(): called once up4 .. up1 have been queued (their
+    parameter gradients are then complete: the data-parallel exchange of that range starts beside the encoder's backward)."""
     # (the output of up3 / up2 / up1 / down4 feeds only the next ConvU: its gradient carries that layer's BatchNorm statistics)
     d, g1 = convu_bwd(net.up4, t.u4, dfeat, below_x=t.u3.c3)
     d, g2 = convu_bwd(net.up3, t.u3, d, below_x=t.u2.c3)
     d, g3 = convu_bwd(net.up2, t.u2, d, below_x=t.u1.c3)
     g5, g4 = convu_bwd(net.up1, t.u1, d, below_x=t.d4.c3)
+    if decoder_done is not None:
+        decoder_done()
     convd_bwd(net.down4, t.d4, g5, g4)
     convd_bwd(net.down3, t.d3, g4, g3)
     convd_bwd(net.down2, t.d2, g3, g2)

@@ -208,6 +208,9 @@ class TrainStep:
                     L.plan_destroy(plan)
 
     def __del__(self):
+        import sys
+        if sys.is_finalizing():       # the HIP runtime may already be gone: destroying events then aborts the process
+            return
         try:
             self.close()
         except Exception:
