@@ -239,6 +239,8 @@ def wt_pse_update(sd, hp, inputs, mask, two_stage_inputs=None, two_step=False, n
     att, _ = attention(sd, "attention_layer.", z_post)
     att_mask = (att > THRESH).float()
     fuse = hp["shape_attention_coeffient"] * emb + att * emb
+    if hp["cat_shape"]:                 # algorithms.py:1192,1253: outc takes feature_dim + 1 channels
+        fuse = torch.cat([fuse, z_post], 1)
     # quirk (algorithms.py:1259-1267): two terms summed, divided by len(list) == 3
     ins = 0
     dom = 0
@@ -265,6 +267,8 @@ def wt_pse_predict(sd, sd_shape, hp, inputs_all, two_step):
     z = student_forward(sd_shape, w[-1], False)
     att, pre_sig = attention(sd, "attention_layer.", z)
     fuse = hp["shape_attention_coeffient"] * emb + att * emb
+    if hp["cat_shape"]:                 # algorithms.py:1348
+        fuse = torch.cat([fuse, z], 1)
     return _conv(sd, "outc.0", fuse, 0), pre_sig
 
 

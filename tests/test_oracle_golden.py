@@ -300,6 +300,33 @@ def test_network_calls(golden_dir, ci):
     assert _check_grads(shape, g, p + "shp_g.") > 50
 
 
+@pytest.mark.parametrize("ci", [0, 1])
+def test_cat_shape(golden_dir, ci):
+    """hparams['cat_shape'] = True (algorithms.py:1192,1253,1348): outc over cat(fuse, z_posterior), 9 input channels."""
+    g = load(golden_dir, "catshape.npz")
+    B, pb, H, s_in, s_a = (int(v) for v in g["cases"][ci])
+    p = f"c{ci}_"
+    hp = dict(HP, cat_shape=True)
+    tm = main_template()
+    tm["outc.0.weight"] = torch.empty(1, 9, 1, 1)
+    main = O.as_leaves(filled_state(tm, SEED_W + 40))
+    shape = filled_state(shape_template(), SEED_W + 43)
+    img, od, _ = make_inputs(s_in, B, H, H)
+    with torch.no_grad():
+        pred, pre = O.wt_pse_predict(main, shape, hp, img, False)
+    close(pred.numpy(), g[p + "pred_logit"], rtol=1e-4, atol=1e-5, what="pred")
+    close(pre.numpy(), g[p + "pred_att"], rtol=1e-4, atol=1e-5, what="pre-sigmoid attention")
+    out, m1, _, ins, dom = O.wt_pse_update(main, hp, img, od, img, True, make_noise(s_a, (B, 1, H, H)), 3, pb)
+    loss = O.seg_loss_od(out, od) + ins + dom
+    loss.backward()
+    close(out.detach().numpy(), g[p + "upd_out"], rtol=1e-4, atol=1e-5, what="out")
+    close(ins.item(), g[p + "upd_ins"], rtol=2e-4, atol=1e-6)
+    close(dom.item(), g[p + "upd_dom"], rtol=1e-3, atol=3e-7)
+    close(loss.item(), g[p + "upd_loss"], rtol=2e-4, atol=1e-6)
+    close(main["outc.0.weight"].grad.numpy(), g[p + "upd_g_full.outc.0.weight"], rtol=2e-3, atol=1e-6, what="d outc.weight")
+    assert _check_grads(main, g, p + "upd_g.") > 100
+
+
 def test_seg_only(golden_dir):
     g = load(golden_dir, "network.npz")
     hp0 = dict(HP, whitening=False, shape_prior=False)

@@ -253,6 +253,43 @@ def test_network_calls_vs_golden(golden_dir, ci):
     assert all(q.grad is None for q in main.parameters())                   # teacher backward skipped
 
 
+@pytest.mark.parametrize("ci", [0, 1])
+def test_cat_shape_vs_golden(golden_dir, ci):
+    """hparams['cat_shape'] = True (algorithms.py:1192,1253,1348): `outc` over cat(fuse_embedding, z_posterior), against the
+    reference's own outputs (oracle/make_golden_catshape.py)."""
+    import algorithms
+    import shape_networks
+    g = np.load(os.path.join(golden_dir, "catshape.npz"))
+    B, pb, H, s_in, s_a = (int(v) for v in g["cases"][ci])
+    p = f"c{ci}_"
+    hp = dict(HP, cat_shape=True)
+    main = algorithms.WT_PSE(n_channels=3, n_classes=1, hparams=hp, device=DEV, two_step=False, per_domain_batch=pb,
+                             source_domain_num=3).to(DEV)
+    shape = shape_networks.ShapeVariationalDist_x(hp, DEV, n_classes=1, number_source_domain=3, batch_size=pb).to(DEV)
+    assert tuple(main.outc[0].weight.shape) == (1, 9, 1, 1)
+    fill_state_dict(main, SEED_W + 40)
+    fill_state_dict(shape, SEED_W + 43)
+    img, od, _ = (t.to(DEV) for t in make_inputs(s_in, B, H, H))
+    main.eval(); shape.eval()
+    with torch.no_grad():
+        logit, att = main.predict(shape, img)
+    close(logit, g[p + "pred_logit"], atol=TOL, what="pred_logit")
+    close(att, g[p + "pred_att"], atol=TOL, what="pred_att")
+    main.train()
+    main.zero_grad()
+    main.set_noise([make_noise(s_a, (B, 1, H, H))])
+    out, m1, _, ins, dom = main.update(img, od, two_stage_inputs=img, sp_mask=od, two_step=True)
+    loss = F.binary_cross_entropy(torch.sigmoid(out), od) + ins + dom
+    loss.backward()
+    close(out, g[p + "upd_out"], atol=TOL, what="upd_out")
+    close(ins, g[p + "upd_ins"], rtol=1e-4, atol=1e-6, what="ins")
+    close(dom, g[p + "upd_dom"], rtol=1e-3, atol=3e-7, what="dom")
+    close(loss, g[p + "upd_loss"], rtol=1e-4, atol=1e-5, what="loss")
+    ref = g[p + "upd_g_full.outc.0.weight"]
+    close(main.outc[0].weight.grad, ref, rtol=2e-3, atol=3e-4 * float(np.abs(ref).max()), what="d outc.weight")
+    check_grads_vs_checksums(main, g, p + "upd_g.", 100)
+
+
 def test_seg_only_vs_golden(golden_dir):
     g = np.load(os.path.join(golden_dir, "network.npz"))
     main, _, _, _ = build_nets(2, full=False)

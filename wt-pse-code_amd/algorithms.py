@@ -121,9 +121,6 @@ class WT_PSE(E.HipNet, E.UNetBody):
             raise NotImplementedError("shape_attention=False fails in the reference itself: update() returns "
                                       "z_posterior_attention_mask and predict() no_sigmoid_embeddings, which only the "
                                       "attention branch assigns (algorithms.py:1241-1272, 1340-1352: UnboundLocalError)")
-        if self.cat_shape:
-            raise NotImplementedError("cat_shape=True (outc over cat(fuse, z_posterior), algorithms.py:1192,1253,1348) is not "
-                                      "built: only the reference default cat_shape=False")
         n = 16
         # registration order == reference state_dict order (algorithms.py:1161-1204)
         if self.whitening:
@@ -133,7 +130,9 @@ class WT_PSE(E.HipNet, E.UNetBody):
         if hparams['shape_prior']:
             self.prior_dist = E.TeacherP(n)
         self.mu = E.Seq(_0=E.ConvP(2 * n, 2 * n, 1), _2=E.ConvP(2 * n, feature_dim, 1))
-        self.outc = E.Seq(_0=E.ConvP(feature_dim, n_classes, 1))
+        # cat_shape (algorithms.py:1190-1193,1253,1348): outc also sees z_posterior as one more input channel
+        fuse_dim = feature_dim + 1 if (hparams['shape_prior'] and self.cat_shape) else feature_dim
+        self.outc = E.Seq(_0=E.ConvP(fuse_dim, n_classes, 1))
         self.attention_layer = E.AttentionP()
         self.global_step = 0
         self._finish_init()
@@ -174,11 +173,14 @@ class WT_PSE(E.HipNet, E.UNetBody):
         z = learn_x_network._student_mu(E.Act(w.z2, None, True), learn_x_network.training, None)
         _, pre, _, fuse = ops.attn_fuse_fwd(z, self.attention_layer.layer1.weight.data_ptr(), emb,
                                             float(self.hparams['shape_attention_coeffient']), False, True, False)
-        out, _ = E._conv(self.outc[0], fuse)
+        out, _ = E._conv(self.outc[0], self._outc_input(fuse, z))
         return out, pre
 
-    def forward(self, x):
-        return self.predict(x)
+    def _outc_input(self, fuse, z):
+        """cat_shape: torch.cat([fuse_embedding, z_posterior], 1) (algorithms.py:1253,1348).  This non-default branch
+        materialises the 9-channel tensor (a device copy, no arithmetic): the two-pointer loader wants its first part in
+        whole 16-channel chunks."""
+        return torch.cat([fuse, z], 1) if self.cat_shape else fuse
 
     def compute_whitening_loss(self, z):
         """Reference algorithms.py:1277-1309 -> (instance_loss, domain_loss), connected to autograd through `z`
@@ -251,9 +253,10 @@ class WT_PSE(E.HipNet, E.UNetBody):
             scal.record_stream(main)
         att, _, att_mask, fuse = ops.attn_fuse_fwd(z_post, self.attention_layer.layer1.weight.data_ptr(), emb, coef,
                                                    True, False, True)
-        out, _ = E._conv(self.outc[0], fuse)
+        fuse_in = self._outc_input(fuse, z_post)
+        out, _ = E._conv(self.outc[0], fuse_in)
         if want_tape:
-            t.w, t.th, t.eps, t.z_post, t.att, t.emb, t.fuse, t.st1, t.st2, t.coef = w, th, eps, z_post, att, emb, fuse, st1, st2, coef
+            t.w, t.th, t.eps, t.z_post, t.att, t.emb, t.fuse, t.st1, t.st2, t.coef = w, th, eps, z_post, att, emb, fuse_in, st1, st2, coef
         return (out, att_mask, scal), t
 
     def _wt_loss(self, z, D, n, losses_out, gram=None):
@@ -280,10 +283,16 @@ class WT_PSE(E.HipNet, E.UNetBody):
         else:
             E._wgrad(outc, d_out, t.fuse)
             dfuse, _ = E._dgrad(outc, d_out)
+            dz_cat = None
+            if self.cat_shape:          # gradient of the concat: the first feature_dim channels belong to fuse, the last to z_posterior
+                dz_cat = dfuse[:, self.feature_dim:].contiguous()
+                dfuse = dfuse[:, :self.feature_dim].contiguous()
             al = self.attention_layer.layer1
             d_wb = self.gview(al.weight)
             self.gview(al.bias)
             demb, dz_post = ops.attn_fuse_bwd(dfuse, t.z_post, t.emb, t.att, al.weight.data_ptr(), t.coef, d_wb.data_ptr(), True)
+            if dz_cat is not None:
+                ops.axpy(dz_post, dz_cat)
             gi = d_ins.contiguous() if d_ins is not None else None
             gd = d_dom.contiguous() if d_dom is not None else None
             kw = dict(g_off=gi, g_diag=gi, g_dom=gd, w_off=w_ins / 3.0, w_diag=w_ins / 3.0, w_dom=w_dom / 3.0)
