@@ -59,6 +59,19 @@ int wtpse_conv_fwd_x3(const float* in0, int C0, const float* in1, int C1, const 
                       const float* pro0, const float* pro1, int pro_relu, float* out0, float* out1, int Csplit, float* stats,
                       int B, int H, int W, int Cout, int ksize, int relu_out, const float* mask_ref, void* stream);
 
+/* The 16-channel 3x3 layers (inc, DeepWT, the teacher's inc: algorithms.py:897-917,1091-1117,398-413) in the x3 arithmetic on
+ * v_mfma_f32_16x16x32_bf16 (csrc/conv.hip, MODE 3): Cout <= 16, C0 <= 16, one input.  wx16: the layer's register-resident weight
+ * fragments (forward or data-gradient direction) from wtpse_pack_conv16_x3, 7680 unsigned shorts per direction, 16-byte aligned.
+ * Options as wtpse_conv_fwd (bias, prologue, relu_out, stats [wtpse_conv_stats_blocks][Cout][2], mask_ref) plus gram_partial
+ * (as wtpse_conv_fwd_gram; Cout == 16, relu_out == 0) and — with bn_mean — the BatchNorm-backward epilogue of wtpse_dgrad_bnb
+ * over all output channels (mask_ref = that layer's raw conv output, stats = its partials). */
+int wtpse_conv16_x3(const float* in0, int C0, const unsigned short* wx16, const float* bias, const float* pro0, int pro_relu,
+                    float* out0, float* stats, float* gram_partial, const float* mask_ref, const float* bn_ss,
+                    const float* bn_mean, int bn_relu, int B, int H, int W, int Cout, int relu_out, void* stream);
+/* desc: n_desc x 8 ints {w_off, Cout, Cin, 9, fwd_off (-1: none), dgrad_off (-1: none), 0, 0}; w_off in floats, *_off in
+ * unsigned shorts (multiples of 8). */
+int wtpse_pack_conv16_x3(const float* params, const int* desc, int n_desc, unsigned short* packed, void* stream);
+
 /* A data gradient (= wtpse_conv_fwd / wtpse_conv_fwd_x3 on dY with the `wd` / x3 data-gradient layout: C = the conv's output
  * channels, Cout = its input channels) that also performs the FIRST HALF of the BatchNorm backward of the conv + BatchNorm
  * (+ReLU) layer the gradient flows into (autograd of algorithms.py:883-889,904-917): output channels [bn_c0, bn_c1) — all of

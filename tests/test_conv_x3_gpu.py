@@ -281,3 +281,107 @@ def test_dgrad_bnb(case):
     close(dy, dy2, rtol=1e-4, atol=2e-5 * sc, what="fused vs stand-alone dy")
     close(dg, dg2, rtol=1e-4, atol=1e-4 * float(dg2.abs().max()) + 1e-6, what="fused vs stand-alone dgamma")
     close(dbt, dbt2, rtol=1e-4, atol=1e-4 * float(dbt2.abs().max()) + 1e-6, what="fused vs stand-alone dbeta")
+
+
+# ---- the 16-channel 3x3 layers in the x3 arithmetic (csrc/conv.hip MODE 3) ---------------------------------------------
+def pack_x16(w):
+    """OIHW (<= 16 x <= 16 x 3 x 3) -> (buffer, forward offset, data-gradient offset) through wtpse_pack_conv16_x3."""
+    o = ops()
+    co, ci = w.shape[:2]
+    n = o.X16_SIZE
+    flat = w.reshape(-1).contiguous().to(DEV)
+    packed = torch.full((2 * n,), 0x7FC0, dtype=torch.int16, device=DEV)
+    desc = torch.tensor([0, co, ci, 9, 0, n, 0, 0], dtype=torch.int32, device=DEV)
+    o.lib().call("wtpse_pack_conv16_x3", flat.data_ptr(), desc.data_ptr(), 1, packed.data_ptr(), o.stream_ptr())
+    return packed, 0, n
+
+
+X16_CASES = [
+    # B, Cin, Cout, H, W
+    (2, 16, 16, 16, 16),
+    (3, 16, 16, 24, 40),      # ragged tiles
+    (2, 8, 16, 8, 8),         # image smaller than a tile, half the reduction channels
+    (2, 16, 5, 32, 64),       # few output channels
+    (1, 3, 16, 20, 12),       # 3-channel input
+    (2, 16, 16, 64, 128),     # several tiles per image in both directions
+]
+
+
+@pytest.mark.parametrize("case", X16_CASES)
+def test_conv16_x3_forward(case):
+    o = ops()
+    B, Ci, Co, H, W = case
+    x = rnd(B, Ci, H, W, seed=41)
+    w = rnd(Co, Ci, 3, 3, seed=42, scale=0.2)
+    b = rnd(Co, seed=43)
+    ref = F.conv2d(x, w, b, padding=1)
+    packed, xf, xd = pack_x16(w)
+    y, stats, gram = o.conv16_x3(x.to(DEV), packed.data_ptr() + 2 * xf, b.to(DEV), Co, want_stats=True, want_gram=(Co == 16))
+    close(y, ref, what="conv16 x3")
+    s = stats.double().sum(0).cpu()
+    close(s[:, 0], ref.double().sum((0, 2, 3)), rtol=1e-4, atol=1e-3, what="stat sum")
+    close(s[:, 1], (ref.double() ** 2).sum((0, 2, 3)), rtol=1e-4, atol=1e-3, what="stat sumsq")
+    if gram is not None:
+        gp, S = gram
+        G = gp.double().view(B, S, 16, 16).sum(1).cpu()
+        f = ref.double().reshape(B, 16, -1)
+        close(G, f @ f.transpose(1, 2), rtol=1e-4, atol=1e-3, what="gram")
+        # the same numbers as the fp32-MFMA kernel's Gram epilogue gives on this output
+        pk, wf, _ = pack(w)
+        y0, (gp0, S0) = o.conv_fwd_gram(x.to(DEV), pk.data_ptr() + 4 * wf, b.to(DEV))
+        assert S0 == S
+        close(gp.double().view(B, S, 256).sum(1), gp0.double().view(B, S, 256).sum(1), rtol=1e-4, atol=1e-3, what="gram vs fp32 path")
+    yr, _, _ = o.conv16_x3(x.to(DEV), packed.data_ptr() + 2 * xf, None, Co, relu_out=True)
+    close(yr, F.relu(ref - b.view(1, -1, 1, 1)), what="conv16 x3 relu nobias")
+    # prologue: per-channel affine + ReLU on load, zero padding AFTER the prologue
+    pro = torch.stack([rnd(Ci, seed=44) * 0.5 + 1.0, rnd(Ci, seed=45)], 1).contiguous()
+    act = F.relu(x * pro[:, 0].view(1, -1, 1, 1) + pro[:, 1].view(1, -1, 1, 1))
+    yp, _, _ = o.conv16_x3(x.to(DEV), packed.data_ptr() + 2 * xf, b.to(DEV), Co, pro.to(DEV), 1)
+    close(yp, F.conv2d(act, w, b, padding=1), what="conv16 x3 prologue")
+    yq, _, _ = o.conv16_x3(x.to(DEV), packed.data_ptr() + 2 * xf, None, Co, None, 1)          # ReLU-on-load only
+    close(yq, F.conv2d(F.relu(x), w, None, padding=1), what="conv16 x3 relu on load")
+    # data gradient direction + ReLU mask
+    du = rnd(B, Co, H, W, seed=46)
+    dref = F.conv_transpose2d(du, w, padding=1)
+    d, _, _ = o.conv16_x3(du.to(DEV), packed.data_ptr() + 2 * xd, None, Ci)
+    close(d, dref, what="dgrad16 x3")
+    mref = rnd(B, Ci, H, W, seed=47)
+    dm, _, _ = o.conv16_x3(du.to(DEV), packed.data_ptr() + 2 * xd, None, Ci, mask_ref=mref.to(DEV))
+    close(dm, dref * (mref > 0), what="dgrad16 x3 masked")
+    # accuracy against fp64, with the fp32-MFMA kernel as the yardstick
+    ref64 = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    pk, wf, _ = pack(w)
+    y32, _, _ = o.conv_fwd(x.to(DEV), None, pk.data_ptr() + 4 * wf, b.to(DEV), Co, 3)
+    e3 = float((y.cpu().double() - ref64).norm() / ref64.norm())
+    e32 = float((y32.cpu().double() - ref64).norm() / ref64.norm())
+    print("relative L2 error vs fp64: x3 %.2e, fp32 MFMA %.2e" % (e3, e32))
+    assert e3 <= 2.0 * e32 + 2e-8, (e3, e32)
+
+
+@pytest.mark.parametrize("case", [(2, 16, 16, 16, 32, True), (3, 16, 8, 24, 40, True), (2, 12, 16, 32, 32, False)])
+def test_conv16_x3_bnb(case):
+    """The BatchNorm-backward epilogue on the 16-channel path, against the same epilogue of the fp32-input kernel and against
+    the stand-alone BatchNorm backward."""
+    o = ops()
+    B, Cl, Cn, H, W, relu = case
+    yd = rnd(B, Cl, H, W, seed=51).to(DEV)                      # raw conv output of the layer below
+    w = rnd(Cn, Cl, 3, 3, seed=52, scale=0.2)
+    du = rnd(B, Cn, H, W, seed=53).to(DEV)
+    mean = yd.double().mean((0, 2, 3))
+    invstd = 1.0 / torch.sqrt(yd.double().var((0, 2, 3), unbiased=False) + 1e-5)
+    g_d = (rnd(Cl, seed=54) * 0.2 + 1).to(DEV)
+    b_d = (rnd(Cl, seed=55) * 0.2).to(DEV)
+    ss = torch.stack([g_d.double() * invstd, b_d.double() - mean * g_d.double() * invstd], 1).float().contiguous()
+    mean_f, invstd_f = mean.float().contiguous(), invstd.float().contiguous()
+    packed, _, xd = pack_x16(w)
+    g, stats, _ = o.conv16_x3(du, packed.data_ptr() + 2 * xd, None, Cl, bnb=(yd, ss, mean_f, relu))
+    dg, dbt = torch.empty(Cl, device=DEV), torch.empty(Cl, device=DEV)
+    dy = o.bn_bwd_from_stats(g, yd, stats, g_d, mean_f, invstd_f, dg, dbt)
+    pk, _, wd = pack(w)
+    dz, _, _ = o.conv_fwd(du, None, pk.data_ptr() + 4 * wd, None, Cl, 3)
+    dg2, dbt2 = torch.empty(Cl, device=DEV), torch.empty(Cl, device=DEV)
+    dy2 = o.bn_bwd(dz, yd, ss, relu, g_d, mean_f, invstd_f, dg2, dbt2)
+    sc = float(dy2.abs().max())
+    close(dy, dy2, rtol=1e-4, atol=2e-5 * sc, what="fused vs stand-alone dy")
+    close(dg, dg2, rtol=1e-4, atol=1e-4 * float(dg2.abs().max()) + 1e-6, what="dgamma")
+    close(dbt, dbt2, rtol=1e-4, atol=1e-4 * float(dbt2.abs().max()) + 1e-6, what="dbeta")

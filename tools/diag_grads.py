@@ -7,8 +7,9 @@ from oracle import wtpse_cpu as O
 from oracle.inputs import make_inputs, make_noise
 from test_parity_gpu import build_nets, HP, is_prebn_bias
 B, pb, H = (int(a) for a in sys.argv[1:4]) if len(sys.argv) > 3 else (3, 1, 32)
-img, od, oc = make_inputs(600, B, H, H)
-eps = make_noise(700, (B, 1, H, H))
+S0 = int(sys.argv[4]) if len(sys.argv) > 4 else 0          # seed offset: golden case ci uses 600+ci, 700+ci, ...
+img, od, oc = make_inputs(600 + S0, B, H, H)
+eps = make_noise(700 + S0, (B, 1, H, H))
 main, shape, _, _ = build_nets(pb)
 sd0 = {k: v.detach().cpu().clone() for k, v in main.state_dict().items()}
 main.train(); main.zero_grad(); main.set_noise([eps])
@@ -44,7 +45,7 @@ res = {}
 for dt in (torch.float32, torch.float64):
     mk = lambda s0: {k: (v.detach().clone().to(dt).requires_grad_(not O.is_buffer(k)) if v.is_floating_point() else v.clone()) for k, v in s0.items()}
     sdm, sds = mk(sd0), mk(sds0)
-    r = O.shape_update(sds, sdm, HP, img.to(dt), od.to(dt), img.to(dt), True, make_noise(800, (B, 1, H, H)).to(dt), make_noise(900, (B, 1, H, H)).to(dt), pb)
+    r = O.shape_update(sds, sdm, HP, img.to(dt), od.to(dt), img.to(dt), True, make_noise(800 + S0, (B, 1, H, H)).to(dt), make_noise(900 + S0, (B, 1, H, H)).to(dt), pb)
     (r[0] + r[1] + r[4]).backward()
     res[dt] = {k: sds[k].grad.double() for k in sds if not O.is_buffer(k) and sds[k].grad is not None}
     print(dt, "kd", float(kd.detach()), float(r[0].detach()), "ins", float(ins_t.detach()), float(r[1].detach()), "dom", float(dom_s.detach()), float(r[4].detach()))

@@ -58,3 +58,24 @@ __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned vof
 __device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t r, unsigned voffset, unsigned soffset, float v) {
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, (int)voffset, (int)soffset, 0);
 }
+
+// ---- split-bf16 ("x3") helpers shared by conv.hip's 16-channel path (conv_x3.hip / wgrad_r.hip carry their own copies)
+typedef __bf16 wt_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 wt_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned wt_pack_rne(float a, float b) {
+  wt_bf16x2 v = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(unsigned, v);
+}
+// (a, b) -> three dwords holding the bf16 pairs (term_i(a), term_i(b)), each term rounded to nearest even, remainders exact
+__device__ __forceinline__ void wt_split3_pair(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2) {
+  p0 = wt_pack_rne(a, b);
+  const float ra = a - __builtin_bit_cast(float, p0 << 16);
+  const float rb = b - __builtin_bit_cast(float, p0 & 0xFFFF0000u);
+  p1 = wt_pack_rne(ra, rb);
+  const float sa = ra - __builtin_bit_cast(float, p1 << 16);
+  const float sb = rb - __builtin_bit_cast(float, p1 & 0xFFFF0000u);
+  p2 = wt_pack_rne(sa, sb);
+}
+__device__ __forceinline__ f32x4 wt_mfma16x32(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(wt_bf16x8, a), __builtin_bit_cast(wt_bf16x8, b), c, 0, 0, 0);
+}

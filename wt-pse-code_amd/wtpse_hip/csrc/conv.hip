@@ -9,6 +9,11 @@
 // instruction writes runs of contiguous pixels of one channel plane.
 //   * Cout <= 16           : v_mfma_f32_16x16x4_f32, wave tile 16 cout x 64 pixels   (MODE 0)
 //   * Cout multiple of 32  : v_mfma_f32_32x32x2_f32, wave tile 32|64 cout x 64 pixels (MODE 1|2)
+//   * Cout, Cin <= 16, 3x3 : MODE 3 (round 3) — the same tile and epilogue as MODE 0, the products in the x3 arithmetic of
+//                            conv_x3.hip on v_mfma_f32_16x16x32_bf16: the whole 16-channel input tile is split once into bf16
+//                            triples in LDS, the 9 taps x 16 channels are five k = 32 steps (tap pairs), and the layer's 15
+//                            weight fragments live in registers for the whole workgroup.  2.4x fewer matrix cycles and 5x
+//                            fewer LDS reads than MODE 0: these layers (inc, DeepWT, the teacher's inc) are then bound by HBM.
 // A workgroup (4 waves) owns a TH x TW = 256-pixel spatial tile of one image and one cout block;
 // input channels are streamed through LDS in chunks (halo tile [KC][TH+2][TW+2] + weight slab
 // [KC*taps][CB]).  Several workgroups per CU overlap one another's load and MFMA phases.
@@ -29,7 +34,7 @@
 struct ConvArgs {
   const float* in0;
   const float* in1;
-  const float* wp;     // packed weights [CinP][taps][CoutP]
+  const float* wp;     // packed weights [CinP][taps][CoutP]; MODE 3: x3 fragments [5 k-steps][3 terms][64 lanes][8 bf16]
   const float* bias;   // [Cout] or null
   const float* pro0;   // [C0][2] (scale, shift) applied to in0 on load, or null
   const float* pro1;   // [C1][2] for in1, or null
@@ -89,7 +94,9 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
   // this phase costs about one MFMA slot (tools/probe/conv_stamps.py)
   constexpr int NPOS = (PE + 255) / 256;
   constexpr int S = PlaneStride<NPOS * 256>::value;
-  constexpr bool P16 = (MODE == 0);
+  constexpr bool XP = (MODE == 3);                 // 16-cout path in the x3 arithmetic (3x3, Cin <= 16)
+  constexpr bool P16 = (MODE == 0) || XP;
+  static_assert(!XP || KS == 3, "MODE 3 is the 3x3 path");
   constexpr int MT = P16 ? 1 : MODE;
   constexpr int MB = P16 ? 16 : 32;
   constexpr int CB = MB * MT;
@@ -100,7 +107,9 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
   constexpr int NACC = P16 ? 4 : 16;
   constexpr int CB4 = CB / 4;
   constexpr int NW = (KC * TAPS * CB4 + 255) / 256;   // 16-byte weight loads per thread and chunk
-  constexpr int XS_SZ = KC * S, WS_SZ = NW * 1024;     // weight slab [KC*TAPS][CB], padded to whole load rounds
+  constexpr int PEP = (PE + 7) & ~7;                     // MODE 3: 16-byte slots per (term, k-half) plane of the split tile
+  constexpr int XS_SZ = XP ? 6 * PEP * 4 : KC * S;
+  constexpr int WS_SZ = XP ? 0 : NW * 1024;            // weight slab [KC*TAPS][CB], padded to whole load rounds
   constexpr int GRAM_SZ = (P16 && KS == 3) ? 4 * 16 * 65 + 4 * 256 : 0;   // wave-private [16 ch][64 px (+1)] tiles + 4 partial Grams
   constexpr int RED_SZ = 4 * CB * 2 > GRAM_SZ ? 4 * CB * 2 : GRAM_SZ;
   constexpr int MAIN_SZ = (XS_SZ + WS_SZ) > RED_SZ ? (XS_SZ + WS_SZ) : RED_SZ;
@@ -135,6 +144,103 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
     off[nt] = (p >> TWL) * PITCH + (p & (TW - 1));
   }
 
+  typename AccT<P16>::type acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < NACC; ++r) acc[mt][nt][r] = 0.f;
+
+  if constexpr (XP) {
+    // ---- MODE 3: one 16-channel chunk, split once; weights in registers; 16x16x32 bf16 MFMAs, six per fp32 product
+    u32x4* Xq = reinterpret_cast<u32x4*>(smem);           // [term 3][k-half 2][PEP positions] 16-byte rows of 8 channels
+    const int g4 = lane >> 4;
+    // loader work items: (halo position, k-half) in whole-wave blocks (as conv_x3.hip)
+    constexpr int PB = (PE + 63) / 64, NIT = (2 * PB + 3) / 4;
+    const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(a.in0 + (size_t)b * a.C0 * HW, (unsigned)a.C0 * HW * 4u);
+    const bool any_pro = a.pro0 != nullptr || a.pro_relu != 0;
+    float xv[NIT][8];
+    int ipos[NIT], ihalf[NIT];
+    bool iin[NIT];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int blk = __builtin_amdgcn_readfirstlane(i * 4 + wave);
+      ihalf[i] = blk >= PB ? 1 : 0;
+      const int p = (blk - ihalf[i] * PB) * 64 + lane;
+      ipos[i] = (blk < 2 * PB && p < PE) ? p : -1;
+      const int r = p / PITCH, x = p - r * PITCH;
+      const int gy = ty * TH + r - PAD, gx = tx * TW + x - PAD;
+      iin[i] = ipos[i] >= 0 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      const unsigned vo = iin[i] ? (unsigned)(gy * a.W + gx) * 4u : BUF_OOB;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)     // channels past C0 are out of the buffer's range and read as zero (their weights are zero too)
+        xv[i][j] = buf_load(rs0, vo, (unsigned)min(ihalf[i] * 8 + j, a.C0) * (unsigned)HW * 4u);
+    }
+    // the layer's weight fragments: [k-step 5][term 3], one 16-byte row per lane (pre-split by pack_weights_x3p16_k)
+    const u32x4* wq = reinterpret_cast<const u32x4*>(a.wp);
+    u32x4 afr[5][3];
+#pragma unroll
+    for (int s5 = 0; s5 < 5; ++s5)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) afr[s5][t] = wq[(s5 * 3 + t) * 64 + lane];
+    if (any_pro) {   // zero padding applies AFTER the fused affine/ReLU, as in the reference graph
+      const bool relu = a.pro_relu & 1;
+#pragma unroll
+      for (int i = 0; i < NIT; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int cg = min(ihalf[i] * 8 + j, a.C0 - 1);
+          const float sc = a.pro0 ? a.pro0[2 * cg] : 1.f, sh = a.pro0 ? a.pro0[2 * cg + 1] : 0.f;
+          float v = fmaf(xv[i][j], sc, sh);
+          if (relu) v = fmaxf(v, 0.f);
+          xv[i][j] = (iin[i] && ihalf[i] * 8 + j < a.C0) ? v : 0.f;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      if (ipos[i] >= 0) {
+        u32x4 t0, t1, t2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          unsigned q0, q1, q2;
+          wt_split3_pair(xv[i][2 * j], xv[i][2 * j + 1], q0, q1, q2);
+          t0[j] = q0; t1[j] = q1; t2[j] = q2;
+        }
+        Xq[(0 * 2 + ihalf[i]) * PEP + ipos[i]] = t0;
+        Xq[(1 * 2 + ihalf[i]) * PEP + ipos[i]] = t1;
+        Xq[(2 * 2 + ihalf[i]) * PEP + ipos[i]] = t2;
+      }
+    }
+    __syncthreads();
+    // k-step s5 covers taps 2 s5 (lane groups 0, 1) and 2 s5 + 1 (groups 2, 3); the tenth "tap" has zero weights
+    int toff[5];
+#pragma unroll
+    for (int s5 = 0; s5 < 5; ++s5) {
+      const int t = min(2 * s5 + (g4 >> 1), TAPS - 1);
+      toff[s5] = (t / KS) * PITCH + (t % KS);
+    }
+    const int hsel = (g4 & 1) * PEP;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+      for (int s5 = 0; s5 < 5; ++s5) {
+        u32x4 bfr[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) bfr[t] = Xq[(t * 2) * PEP + hsel + off[nt] + toff[s5]];
+        f32x4 c = acc[0][nt];
+        // the six leading cross terms, smallest first (as conv_x3.hip)
+        c = wt_mfma16x32(afr[s5][0], bfr[2], c);
+        c = wt_mfma16x32(afr[s5][1], bfr[1], c);
+        c = wt_mfma16x32(afr[s5][2], bfr[0], c);
+        c = wt_mfma16x32(afr[s5][0], bfr[1], c);
+        c = wt_mfma16x32(afr[s5][1], bfr[0], c);
+        c = wt_mfma16x32(afr[s5][0], bfr[0], c);
+        acc[0][nt] = c;
+      }
+    }
+    __syncthreads();      // the epilogue reuses the tile's LDS (Gram staging, statistics)
+  } else {
   // halo-tile positions owned by this thread (fixed for the whole kernel): position tid + 256*i of a channel plane;
   // gpos = offset within a global channel plane (-1: zero padding / outside the image / past the tile)
   int gpos[NPOS];
@@ -145,14 +251,6 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
     int gy = ty * TH + r - PAD, gx = tx * TW + x - PAD;
     gpos[i] = (p < PE && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? gy * a.W + gx : -1;
   }
-
-  typename AccT<P16>::type acc[MT][NT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int r = 0; r < NACC; ++r) acc[mt][nt][r] = 0.f;
 
   const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(a.in0 + (size_t)b * a.C0 * HW, (unsigned)a.C0 * HW * 4u);
   const __amdgpu_buffer_rsrc_t rs1 = a.in1 ? make_rsrc(a.in1 + (size_t)b * a.C1 * HW, (unsigned)a.C1 * HW * 4u) : rs0;
@@ -256,6 +354,7 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
           for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mfma(av[t][mt], bv[t][nt], acc[mt][nt]);
     }
     STAMP(5 + 4 * (c0 / KC));
+  }
   }
   STAMP(60);
   if (a.bias) {
@@ -476,7 +575,7 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
 
 template <int KS, int MODE, bool DB, int EPI>
 static int launch_fwd(const ConvArgs& a, hipStream_t st) {
-  constexpr int CB = MODE == 0 ? 16 : 32 * MODE;
+  constexpr int CB = (MODE == 0 || MODE == 3) ? 16 : 32 * MODE;
   ConvArgs args = a;
   const bool narrow = a.W <= 16;  // 16x16 tiles for the deepest levels, 8x32 otherwise
   const int TW = narrow ? 16 : 32, TH = 256 / TW;
@@ -567,6 +666,69 @@ extern "C" int wtpse_dgrad_bnb(const float* dy, int C, const float* wpacked, flo
   WTPSE_REQUIRE(bn_y && bn_ss && bn_mean && stats);
   return conv_fwd_impl(dy, C, nullptr, 0, wpacked, nullptr, nullptr, nullptr, 0, out0, out1, Csplit, stats, B, H, W, Cout, ksize, 0,
                        bn_y, nullptr, stream, BnbArgs{bn_ss, bn_mean, bn_relu, bn_c0, bn_c1});
+}
+
+// ---- the 16-channel 3x3 layers in the x3 arithmetic (MODE 3): Cout <= 16, Cin <= 16, one input tensor.  wx16: the layer's
+// fragments from wtpse_pack_conv16_x3.  Everything optional: bias, prologue, ReLU, BatchNorm (sum, sum^2) partials `stats`,
+// Gram partials `gram_partial` (Cout == 16), ReLU mask `mask_ref`, or — with bn_mean — the BatchNorm-backward epilogue of
+// wtpse_dgrad_bnb over all output channels (mask_ref = that layer's raw conv output).
+extern "C" int wtpse_conv16_x3(const float* in0, int C0, const unsigned short* wx16, const float* bias, const float* pro0,
+                               int pro_relu, float* out0, float* stats, float* gram_partial, const float* mask_ref,
+                               const float* bn_ss, const float* bn_mean, int bn_relu, int B, int H, int W, int Cout, int relu_out,
+                               void* stream) {
+  WTPSE_REQUIRE(in0 && wx16 && out0 && B > 0 && H > 0 && W > 0 && C0 > 0 && C0 <= 16 && Cout > 0 && Cout <= 16);
+  WTPSE_REQUIRE(!(stats && relu_out) && !(gram_partial && (Cout != 16 || relu_out)));
+  WTPSE_REQUIRE((((uintptr_t)wx16) & 15) == 0);
+  const bool bnb = bn_mean != nullptr;
+  WTPSE_REQUIRE(bnb || !(stats && mask_ref));
+  WTPSE_REQUIRE(!bnb || (mask_ref && stats && bn_ss && !bias && !relu_out && !gram_partial));
+  ConvArgs a;
+  a.in0 = in0; a.in1 = nullptr; a.wp = reinterpret_cast<const float*>(wx16); a.bias = bias; a.pro0 = pro0; a.pro1 = nullptr;
+  a.out0 = out0; a.out1 = nullptr; a.stats = stats; a.mask = mask_ref; a.gram = gram_partial;
+  a.bn_ss = bn_ss; a.bn_mean = bn_mean; a.bn_relu = bn_relu; a.bn_c0 = 0; a.bn_c1 = bnb ? Cout : 0;
+  a.B = B; a.H = H; a.W = W; a.C0 = C0; a.C1 = 0; a.Cin = C0; a.CinP = 16;
+  a.Cout = Cout; a.CoutP = 16; a.Csplit = Cout; a.pro_relu = pro_relu; a.relu_out = relu_out;
+  a.tiles_x = a.tiles_y = 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (bnb) return launch_fwd<3, 3, false, 2>(a, st);
+  if (mask_ref) return launch_fwd<3, 3, false, 1>(a, st);
+  return launch_fwd<3, 3, false, 0>(a, st);
+}
+
+// Weight fragments of the 16-channel x3 path, all convs of a network in one launch.  desc: n_desc x 8 ints {w_off, Cout, Cin,
+// 9, fwd_off (-1: none), dgrad_off (-1: none), 0, 0}, w_off in floats into `params`, *_off in unsigned shorts into `packed`;
+// one direction = [5 k-steps][3 terms][64 lanes][8] bf16 = 7680 shorts:  lane = (row = lane & 15, g = lane >> 4),
+// tap = 2 s + (g >> 1), k = 8 (g & 1) + j;  forward: rows = Cout, k = Cin, w[row][k][tap];  data gradient: rows = Cin,
+// k = Cout, w[k][row][8 - tap];  zero beyond the layer's channels and for the tenth tap.
+__global__ __launch_bounds__(256) void pack_weights_x3p16_k(const float* __restrict__ params, const int* __restrict__ desc,
+                                                            unsigned short* __restrict__ packed) {
+  const int* d = desc + blockIdx.y * 8;
+  const int w_off = d[0], Co = d[1], Ci = d[2];
+  const float* w = params + w_off;
+  for (int dir = 0; dir < 2; ++dir) {
+    const int base = d[4 + dir];
+    if (base < 0) continue;
+    const int R = dir == 0 ? Co : Ci, K = dir == 0 ? Ci : Co;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < 5 * 64 * 8; e += gridDim.x * 256) {
+      const int j = e & 7, lane = (e >> 3) & 63, s5 = e >> 9;
+      const int row = lane & 15, g = lane >> 4;
+      const int tap = 2 * s5 + (g >> 1), k = 8 * (g & 1) + j;
+      float v = 0.f;
+      if (tap < 9 && row < R && k < K) v = dir == 0 ? w[(row * Ci + k) * 9 + tap] : w[(k * Ci + row) * 9 + (8 - tap)];
+      unsigned q0, q1, q2;
+      wt_split3_pair(v, 0.f, q0, q1, q2);
+      unsigned short* o = packed + base;
+      o[((s5 * 3 + 0) * 64 + lane) * 8 + j] = (unsigned short)(q0 & 0xFFFFu);
+      o[((s5 * 3 + 1) * 64 + lane) * 8 + j] = (unsigned short)(q1 & 0xFFFFu);
+      o[((s5 * 3 + 2) * 64 + lane) * 8 + j] = (unsigned short)(q2 & 0xFFFFu);
+    }
+  }
+}
+
+extern "C" int wtpse_pack_conv16_x3(const float* params, const int* desc, int n_desc, unsigned short* packed, void* stream) {
+  WTPSE_REQUIRE(params && desc && packed && n_desc > 0);
+  hipLaunchKernelGGL(pack_weights_x3p16_k, dim3(2, n_desc), dim3(256), 0, (hipStream_t)stream, params, desc, packed);
+  return wtpse_status();
 }
 
 // 3x3 convolution with exactly 16 output channels that also emits the per-tile partial Grams of its output

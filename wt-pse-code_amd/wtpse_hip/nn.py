@@ -34,6 +34,7 @@ class ConvP(nn.Module):
         nn.init.uniform_(self.bias, -bound, bound)
         self.wf_off = self.wd_off = -1
         self.xf_off = self.xd_off = -1      # offsets (unsigned shorts) into the root's x3-packed weights; -1: fp32-MFMA path
+        self.x16f_off = self.x16d_off = -1  # same, the 16-channel x3 layout (csrc/conv.hip MODE 3)
 
 
 class BNP(nn.Module):
@@ -173,6 +174,7 @@ class HipNet(nn.Module):
         object.__setattr__(self, "_packed", None)
         object.__setattr__(self, "_x3", None)
         object.__setattr__(self, "_xdesc", None)
+        object.__setattr__(self, "_x16desc", None)
         object.__setattr__(self, "_packed_version", -1)
         object.__setattr__(self, "_desc", None)
         object.__setattr__(self, "_touched", [])
@@ -209,6 +211,20 @@ class HipNet(nn.Module):
                 off += ops.x3_packed_size(c.cin, c.cout, c.k * c.k)
             if fwd or bwd:
                 self._x3_convs.append(c)
+        # the 16-channel 3x3 layers (inc, DeepWT, the last decoder conv): x3 arithmetic with register-resident weight fragments
+        # (csrc/conv.hip MODE 3); same buffer, own layout
+        self._x16_convs = []
+        for c in self._convs:
+            c.x16f_off = c.x16d_off = -1
+            if X16 and c.k == 3 and c.cin <= 16 and c.cout <= 16:
+                if c.cin >= X16_MIN_K:
+                    c.x16f_off = off
+                    off += ops.X16_SIZE
+                if c.cout >= X16_MIN_K:
+                    c.x16d_off = off
+                    off += ops.X16_SIZE
+                if c.x16f_off >= 0 or c.x16d_off >= 0:
+                    self._x16_convs.append(c)
         self._x3_size = off
 
     # ---- flat storage --------------------------------------------------------------------------------------
@@ -256,6 +272,10 @@ class HipNet(nn.Module):
         for c in self._x3_convs:
             xdesc += [self._offsets[self._pindex[id(c.weight)]], c.cout, c.cin, c.k * c.k, c.xf_off, c.xd_off, 0, 0]
         object.__setattr__(self, "_xdesc", torch.tensor(xdesc, dtype=torch.int32).to(dev) if xdesc else None)
+        xdesc = []
+        for c in self._x16_convs:
+            xdesc += [self._offsets[self._pindex[id(c.weight)]], c.cout, c.cin, 9, c.x16f_off, c.x16d_off, 0, 0]
+        object.__setattr__(self, "_x16desc", torch.tensor(xdesc, dtype=torch.int32).to(dev) if xdesc else None)
         object.__setattr__(self, "_flag", torch.zeros(1, dtype=torch.int32, device=dev))
         # position in this network's Philox stream.  It lives in device memory (advanced by a one-thread launch after each
         # draw) so that nothing that changes from step to step is passed to a kernel by value: a captured step (hipGraph)
@@ -277,6 +297,9 @@ class HipNet(nn.Module):
                            self._packed.data_ptr(), ops.stream_ptr())
             if self._xdesc is not None:
                 ops.lib().call("wtpse_pack_conv_weights_x3", self._flat.data_ptr(), self._xdesc.data_ptr(), len(self._x3_convs),
+                               self._x3.data_ptr(), ops.stream_ptr())
+            if self._x16desc is not None:
+                ops.lib().call("wtpse_pack_conv16_x3", self._flat.data_ptr(), self._x16desc.data_ptr(), len(self._x16_convs),
                                self._x3.data_ptr(), ops.stream_ptr())
             object.__setattr__(self, "_packed_version", 1)
 
@@ -427,6 +450,11 @@ def _relu_bits(a0, a1):
 X3 = os.environ.get("WTPSE_X3", "1") != "0"
 X3_WGRAD = os.environ.get("WTPSE_X3_WGRAD", "1") != "0"
 WGRAD_R = os.environ.get("WTPSE_WGRAD_R", "1") != "0"      # =0: the LDS-based weight-gradient kernels of rounds 1-2
+# 16-channel 3x3 layers (<= 16 in, <= 16 out) in the x3 arithmetic (csrc/conv.hip MODE 3); =0: fp32-input MFMA.  Layers whose
+# reduction has fewer than X16_MIN_K channels (the 1- and 3-channel inputs) are bound by their output write on either path and
+# stay on the fp32-input MFMA.
+X16 = os.environ.get("WTPSE_X16", "1") != "0" and X3
+X16_MIN_K = int(os.environ.get("WTPSE_X16_MIN_K", "8"))
 
 
 def x3_eligible(k_dim, rows, ksize):
@@ -438,6 +466,10 @@ def _conv(layer, a0, a1=None, relu_out=False, want_stats=False):
     root = layer._root
     a0 = as_act(a0)
     a1 = as_act(a1) if a1 is not None else None
+    if layer.x16f_off >= 0 and a1 is None:
+        y, stats, _ = ops.conv16_x3(a0.t, root.x3_ptr(layer.x16f_off), layer.bias, layer.cout, a0.pro, _relu_bits(a0, None),
+                                    relu_out, want_stats)
+        return y, stats
     if layer.xf_off >= 0:
         y, _, stats = ops.conv_fwd_x3(a0.t, a1.t if a1 is not None else None, root.x3_ptr(layer.xf_off), layer.bias, layer.cout,
                                       layer.k, a0.pro, _relu_bits(a0, a1), relu_out, want_stats, None, None,
@@ -473,6 +505,10 @@ def _dgrad(layer, dy, split=None, mask_ref=None, below0=None, below1=None):
     below = below0 if below0 is not None else below1
     if (BN_FUSED_STATS and below is not None and mask_ref is None and below.mean is not None
             and not (root._dp is not None and root._dp.bn_sync) and (below1 is None or split is not None)):
+        if layer.x16d_off >= 0 and split is None:
+            d0, stats, _ = ops.conv16_x3(dy, root.x3_ptr(layer.x16d_off), None, layer.cin,
+                                         bnb=(below.y, below.ss, below.mean, below.relu))
+            return PreBN(d0, stats), None
         x3 = layer.xd_off >= 0
         wptr = root.x3_ptr(layer.xd_off) if x3 else root.packed_ptr(layer.wd_off)
         d0, d1, stats = ops.dgrad_bnb(dy, wptr, x3, layer.cin, layer.k, below.y, below.ss, below.mean, below.relu, split,
@@ -480,6 +516,8 @@ def _dgrad(layer, dy, split=None, mask_ref=None, below0=None, below1=None):
         if below0 is not None:
             return PreBN(d0, stats), d1
         return d0, PreBN(d1, stats)
+    if layer.x16d_off >= 0 and split is None:
+        return ops.conv16_x3(dy, root.x3_ptr(layer.x16d_off), None, layer.cin, mask_ref=mask_ref)[0], None
     if layer.xd_off >= 0:
         return ops.conv_fwd_x3(dy, None, root.x3_ptr(layer.xd_off), None, layer.cin, layer.k, None, 0, False, False, split,
                                mask_ref)[:2]
@@ -824,6 +862,10 @@ WT_FUSED_GRAM = os.environ.get("WTPSE_WT_FUSED_GRAM", "1") != "0"
 def _conv_gram(layer, a0):
     """3x3, 16 output channels, no BatchNorm: -> (z, (partial Grams, S))."""
     a0 = as_act(a0)
+    if layer.x16f_off >= 0:
+        y, _, g = ops.conv16_x3(a0.t, layer._root.x3_ptr(layer.x16f_off), layer.bias, 16, a0.pro, _relu_bits(a0, None), False,
+                                want_gram=True)
+        return y, g
     return ops.conv_fwd_gram(a0.t, layer._root.packed_ptr(layer.wf_off), layer.bias, a0.pro, _relu_bits(a0, None), False)
 
 

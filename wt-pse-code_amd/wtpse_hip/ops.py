@@ -80,6 +80,32 @@ def conv_fwd_gram(in0, wpacked_ptr, bias, pro0=None, pro_relu=0, relu_out=False)
     return out, (partial, nblk // B)
 
 
+X16_SIZE = 5 * 3 * 64 * 8       # unsigned shorts of one direction of one conv in the 16-channel x3 layout
+
+
+def conv16_x3(in0, wx16_ptr, bias, cout, pro0=None, pro_relu=0, relu_out=False, want_stats=False, want_gram=False, mask_ref=None,
+              bnb=None):
+    """3x3 conv with at most 16 input and 16 output channels in the x3 arithmetic (csrc/conv.hip MODE 3; include/wtpse_hip.h,
+    wtpse_conv16_x3).  bnb = (bn_y, bn_ss, bn_mean, bn_relu): the BatchNorm-backward epilogue of dgrad_bnb.
+    -> (out, stats or None, (gram partial, tiles per image) or None)."""
+    _chk(in0, "in0"); _chk(pro0, "pro0"); _chk(mask_ref, "mask_ref")
+    B, C0, H, W = in0.shape
+    L = lib()
+    out = torch.empty((B, cout, H, W), dtype=torch.float32, device=in0.device)
+    nblk = L.query("wtpse_conv_stats_blocks", B, H, W)
+    stats = torch.empty((nblk, cout, 2), dtype=torch.float32, device=in0.device) if (want_stats or bnb is not None) else None
+    gram = torch.empty((nblk, 256), dtype=torch.float32, device=in0.device) if want_gram else None
+    bn_ss = bn_mean = None
+    bn_relu = 0
+    if bnb is not None:
+        mask_ref, bn_ss, bn_mean, bn_relu = bnb
+        _chk(mask_ref, "bn_y"); _chk(bn_ss, "bn_ss"); _chk(bn_mean, "bn_mean")
+        assert mask_ref.shape == out.shape
+    L.call("wtpse_conv16_x3", ptr(in0), C0, wx16_ptr, ptr(bias), ptr(pro0), int(pro_relu), ptr(out), ptr(stats), ptr(gram),
+           ptr(mask_ref), ptr(bn_ss), ptr(bn_mean), int(bool(bn_relu)), B, H, W, cout, int(relu_out), stream_ptr())
+    return out, stats, ((gram, nblk // B) if want_gram else None)
+
+
 def x3_packed_size(rows, k, taps):
     """unsigned shorts of one direction of one conv in the x3 layout (include/wtpse_hip.h)."""
     return ((k + 15) & ~15) * ((rows + 31) & ~31) * taps * 3
