@@ -158,8 +158,9 @@ def kernel_rooflines(B, H, dev):
     out["x3_conv"] = agg(fw + dg, "conv_x3_k forward + data gradient, %s: %s" % (x3, shape))
     out["x3_wgrad"] = agg(wg, "wgrad_r_k (register-resident operands, v_mfma_f32_16x16x32_bf16) + slab fold, %s: %s, "
                           "BatchNorm+ReLU prologue on both inputs" % (x3, shape))
-    # the 16-channel 256x256 layers (inc.conv2/3, DeepWT, teacher inc): forward on the fp32-input MFMA (conv_fwd_k<3,0,5>),
-    # weight gradient on wgrad_r_k<1,1> — HBM-bound: 2 x 16 x H x W x 4 bytes per image either way
+    # the 16-channel 256x256 layers (inc.conv2/3, DeepWT, teacher inc): forward / data gradient in the x3 arithmetic on
+    # v_mfma_f32_16x16x32_bf16 with register-resident weight fragments (conv_fwd_k<3,3,5>; WTPSE_X16=0: the fp32-input MFMA
+    # conv_fwd_k<3,0,5>), weight gradient on wgrad_r_k<1,1> — HBM-bound: 2 x 16 x H x W x 4 bytes per image either way
     C16 = 16
     x16 = torch.randn(B, C16, H, H, device=dev)
     dy16 = torch.randn(B, C16, H, H, device=dev)
@@ -175,13 +176,12 @@ def kernel_rooflines(B, H, dev):
     a16 = E.Act(x16, p16, True)
     nb16 = 2.0 * B * C16 * H * H * 4
     ms = time_kernel(lambda: E._conv(n16.conv, a16, None, False, True))
-    out["c16_fwd"] = {"kernel": "conv_fwd_k<3,0,5> 16->16 3x3 @%dx%d B=%d (BatchNorm+ReLU prologue, bias, BatchNorm partials)" % (H, H, B),
+    out["c16_fwd"] = {"kernel": "conv_fwd_k<3,%d,5> 16->16 3x3 @%dx%d B=%d (BatchNorm+ReLU prologue, bias, BatchNorm partials)" % (3 if E.X16 else 0, H, H, B),
                       "ms": ms, "gbs": nb16 / ms / 1e6, "bytes_per_launch": nb16, "tflops": 2.0 * 16 * 16 * 9 * H * H * B / ms / 1e9}
     n16.begin_backward()
     ms = time_kernel(lambda: E._wgrad(n16.conv, dy16, a16, None, with_bias=True))
     out["c16_wgrad"] = {"kernel": "wgrad_r_k<1,1> + slab fold 16->16 3x3 @%dx%d B=%d (prologue, with bias gradient)" % (H, H, B),
                         "ms": ms, "gbs": nb16 / ms / 1e6, "bytes_per_launch": nb16, "tflops": 2.0 * 16 * 16 * 9 * H * H * B / ms / 1e9}
-    del x16, dy16, n16
     C, Hc = 64, H // 2
     x = torch.randn(B, C, Hc, Hc, device=dev)
     w = torch.randn(C, C, 3, 3, device=dev) * 0.05
@@ -217,18 +217,13 @@ def kernel_rooflines(B, H, dev):
                      "gbs": nbytes / ms / 1e6, "bytes_per_launch": nbytes}
     # in a training step the Gram partials come from the epilogue of the DeepWT conv that writes z (wtpse_conv_fwd_gram):
     # the loss then costs the extra epilogue time plus the tail on the partials, and never reads z
-    h = torch.randn(B, 16, H, H, device=dev)
-    w16 = torch.randn(16, 16, 3, 3, device=dev) * 0.1
-    pk = torch.empty(16 * 9 * 16 * 2, device=dev)
-    d16 = torch.tensor([0, 16, 16, 9, 0, 16 * 9 * 16, 0, 0], dtype=torch.int32, device=dev)
-    L.call("wtpse_pack_conv_weights", w16.data_ptr(), d16.data_ptr(), 1, pk.data_ptr(), ops.stream_ptr())
-    b16 = torch.zeros(16, device=dev)
-    t_plain = time_kernel(lambda: ops.conv_fwd(h, None, pk.data_ptr(), b16, 16, 3))
-    t_gram = time_kernel(lambda: ops.conv_fwd_gram(h, pk.data_ptr(), b16))
-    zz, gp = ops.conv_fwd_gram(h, pk.data_ptr(), b16)
+    t_plain = time_kernel(lambda: E._conv(n16.conv, x16))
+    t_gram = time_kernel(lambda: E._conv_gram(n16.conv, x16))
+    zz, gp = E._conv_gram(n16.conv, x16)
     t_tail = time_kernel(lambda: ops.wt_loss_fwd(zz, 3, pb, 0.0, gram_partial=gp))
+    del x16, dy16, n16
     out["wt_fwd"]["fused_in_step"] = {
-        "what": "Gram partials in the epilogue of the conv that writes z (conv_fwd_k 16->16 3x3) + wtpse_wt_loss_fwd_partials",
+        "what": "Gram partials in the epilogue of the conv that writes z (16->16 3x3, the kernel of c16_fwd) + wtpse_wt_loss_fwd_partials",
         "conv_ms": t_plain, "conv_with_gram_epilogue_ms": t_gram, "tail_on_partials_ms": t_tail,
         "loss_cost_ms": (t_gram - t_plain) + t_tail, "hbm_bytes_avoided_per_call": nbytes,
         "equivalent_gbs": nbytes / ((t_gram - t_plain) + t_tail) / 1e6}

@@ -49,7 +49,9 @@ int wtpse_conv_fwd_gram(const float* in0, int C0, const float* wpacked, const fl
 
 /* The same convolution on the BF16 matrix cores at fp32 accuracy (csrc/conv_x3.hip): every fp32 operand is split into three
  * bf16 terms and the product formed from the six leading cross terms with fp32 accumulation (6 bf16 MFMAs instead of 8 fp32
- * MFMAs per 32x32x16 block).  Same contract as wtpse_conv_fwd; requires Cout > 16.  `wpacked`: the weights pre-split by
+ * MFMAs per 32x32x16 block).  Same contract as wtpse_conv_fwd; requires Cout > 16 and ceil16(C0 + C1) <= 256 (<= 512 when
+ * the launch uses 64-channel row blocks: Cout % 64 == 0 and at least 512 of them) — the per-channel prologue coefficients are
+ * staged in LDS; anything else fails with WTPSE_ERR_ARG.  `wpacked`: the weights pre-split by
  * wtpse_pack_conv_weights_x3 — desc as for wtpse_pack_conv_weights with offsets {xf_off, xd_off} in unsigned shorts; per
  * conv and direction ceil16(K) * ceil32(rows) * taps * 3 unsigned shorts (forward: rows = Cout, K = Cin; data gradient:
  * rows = Cin, K = Cout), layout [K chunk 16][row block 32][tap][term 3][k half 2][row 32][8 k]. */

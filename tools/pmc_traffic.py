@@ -19,11 +19,11 @@ import sys
 # The x3 kernels run on four layer shapes each in `bench.py --kernels-only` (conv3 of up1..up4, forward and data gradient
 # share one kernel name): their entry is the mean over all those launches, to be compared with the mean algorithmic bytes.
 # Round 3: the weight gradient is wgrad_r_k (16-byte loads per lane: the x2 calibration applies), the 16-channel layers and the
-# DWT micro-benchmark kernels are listed too (dwt2_fwd_k: 8-byte loads per lane — uncalibrated, raw value reported).
+# DWT micro-benchmark kernels are listed too (dwt2_stream_k: 4-/8-byte loads per lane — uncalibrated, raw value reported).
 KERNELS = {"x3_conv": ("conv_x3_k<3", 1.0), "x3_wgrad": ("wgrad_r_k<2, 2", 2.0), "conv": ("conv_fwd_k<3, 2, 5", 1.0),
-           "c16_fwd": ("conv_fwd_k<3, 0, 5", 1.0), "c16_wgrad": ("wgrad_r_k<1, 1", 2.0),
+           "c16_fwd": ("conv_fwd_k<3, 3, 5", 1.0), "c16_wgrad": ("wgrad_r_k<1, 1", 2.0),
            "wt_fwd": ("gram_partial_k", 2.0), "wt_bwd": ("gram_bwd_k", 2.0),
-           "dwt_haar": ("dwt2_fwd_k<0>", 1.0), "dwt_db2": ("dwt2_fwd_k<1>", 1.0)}
+           "dwt_haar": ("dwt2_stream_k<0", 1.0), "dwt_db2": ("dwt2_stream_k<1", 1.0)}
 
 
 def per_launch(path, counter, pattern):

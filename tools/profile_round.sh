@@ -15,6 +15,9 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_w" -o w -- $B --kern
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OUT/pmc_a" -o a -- $B --kernels-only > "$OUT/pmc_a.log" 2>&1 &&
 python3 tools/pmc_traffic.py "$OUT/pmc_f/f_counter_collection.csv" "$OUT/pmc_w/w_counter_collection.csv" > "$OUT/pmc_traffic.log" 2>&1 &&
 python3 tools/microbench_x3.py > "$OUT/microbench_x3.log" 2>&1 &&
+python3 tools/microbench_wgrad.py 32 > "$OUT/microbench_wgrad.log" 2>&1 &&
+python3 tools/microbench_c16.py 32 > "$OUT/microbench_c16.log" 2>&1 &&
+python3 tools/bench_dwt.py > "$OUT/microbench_dwt.log" 2>&1 &&
 python3 tools/microbench.py --only wt > "$OUT/microbench_rest.log" 2>&1 &&
 python3 tools/microbench.py --only head >> "$OUT/microbench_rest.log" 2>&1 &&
 python3 tools/microbench.py --only bn >> "$OUT/microbench_rest.log" 2>&1 &&

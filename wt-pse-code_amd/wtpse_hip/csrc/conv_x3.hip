@@ -17,6 +17,7 @@
 //     Ws[tap 3][term 3][k-half 2][cout CB][8 cin]     one kernel row of the weights (pre-split by the pack kernel)
 #include <stdlib.h>
 #include "common.h"
+#include <utility>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -57,6 +58,15 @@ struct ConvX3Args {
   int pro_relu, relu_out;
   int tiles_x, tiles_y;
 };
+
+template <class F, int... I>
+__device__ __forceinline__ void x3_static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void x3_static_for(F&& f) {
+  x3_static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
 
 __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
@@ -273,7 +283,9 @@ __global__ __launch_bounds__(256, 2) void conv_x3_k(ConvX3Args a) {
   constexpr int NW = (WS_U4 + 255) / 256;          // 16-byte weight loads per thread and kernel row
   constexpr int RED_F = 4 * CB * 2;
   constexpr int MAIN_U4 = (XS_U4 + 2 * WS_U4) > (RED_F + 3) / 4 ? (XS_U4 + 2 * WS_U4) : (RED_F + 3) / 4;
+  constexpr int PRO_MAX = MT == 1 ? 256 : 512;                     // input channels (virtual concat, padded) a prologue is staged for
   __shared__ u32x4v smem[MAIN_U4 + CB / 4 + (EPI == 2 ? CB : 0)];
+  __shared__ float2 pro_s[PRO_MAX];                // (scale, shift) applied on load; (1, 0) without a prologue, (0, 0) padding
   u32x4v* Xs = smem;
   u32x4v* Ws = smem + XS_U4;
   float* bias_s = reinterpret_cast<float*>(smem + MAIN_U4);
@@ -295,6 +307,14 @@ __global__ __launch_bounds__(256, 2) void conv_x3_k(ConvX3Args a) {
     q[0] = (bn && a.bn_relu) ? a.bn_ss[2 * (c - a.bn_c0)] : 0.f;
     q[CB] = (bn && a.bn_relu) ? a.bn_ss[2 * (c - a.bn_c0) + 1] : 1.f;
     q[2 * CB] = bn ? a.bn_mean[c - a.bn_c0] : 0.f;
+  }
+
+  for (int c = tid; c < a.CinP; c += 256) {
+    const bool first = c < a.C0;
+    const float* pro = first ? a.pro0 : a.pro1;
+    const int cl = first ? c : c - a.C0;
+    const bool live = c < a.C0 + a.C1;
+    pro_s[c] = !live ? make_float2(0.f, 0.f) : (pro ? make_float2(pro[2 * cl], pro[2 * cl + 1]) : make_float2(1.f, 0.f));
   }
 
   int off[NT];                                    // halo position of this lane's pixel (tap 0,0 corner)
@@ -337,7 +357,6 @@ __global__ __launch_bounds__(256, 2) void conv_x3_k(ConvX3Args a) {
   const int ncb32 = a.CoutP / 32;
   const __amdgpu_buffer_rsrc_t rsw = make_rsrc(a.wx, (unsigned)(a.CinP / 16) * ncb32 * TAPS * 6u * 32u * 16u);
   // (per-lane offset + scalar offset: a lane is out of range when voffset >= num_records - soffset, see common.h)
-  const bool any_pro = a.pro0 != nullptr || a.pro1 != nullptr || a.pro_relu != 0;
 
   // Software pipeline over "rows" (one kernel row of one 16-channel chunk = KS taps = KS*MT*NT*6 MFMAs per wave): the global
   // loads of the next row's weights — and, on a chunk's last row, of the next chunk's input tile — are issued before the
@@ -359,41 +378,46 @@ __global__ __launch_bounds__(256, 2) void conv_x3_k(ConvX3Args a) {
       for (int i = 0; i < NIT; ++i) xv[i][j] = buf_load(rs, voff[i], soff);
     }
   };
-  auto stash_x = [&](int c0) {
-    if (any_pro) {   // zero padding applies AFTER the fused affine/ReLU, as in the reference graph
-      const bool first = c0 < a.C0;
-      const int cbase = first ? c0 : c0 - a.C0;
-      const int cmax = (first ? a.C0 : a.C1) - 1;
-      const bool relu = first ? (a.pro_relu & 1) : (a.pro_relu & 2);
-      const float* pro = first ? a.pro0 : a.pro1;
-#pragma unroll
-      for (int i = 0; i < NIT; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int cg = min(cbase + ihalf[i] * 8 + j, cmax);
-          const float sc = pro ? pro[2 * cg] : 1.f, sh = pro ? pro[2 * cg + 1] : 0.f;
-          float v = fmaf(xv[i][j], sc, sh);
-          if (relu) v = fmaxf(v, 0.f);
-          xv[i][j] = iin[i] ? v : 0.f;
-        }
+  // Conversion of a loaded chunk — prologue (affine, ReLU; the zero padding applies AFTER it, as in the reference graph), split
+  // into three bf16 terms — one channel pair of one item at a time, so that for 3x3 kernels the pieces can sit between the MFMA
+  // groups of the chunk's last kernel row (they used to run behind the chunk's barrier, ~1600 cycles per chunk during which
+  // the wave issued no MFMA: 9 % of the forward kernel with a prologue, 6 % without).  Branch-free: the coefficients come from
+  // LDS ((1, 0) without a prologue), the ReLU is a select on a uniform flag.
+  u32x4v tq[NIT][3];
+  const bool any_pro = a.pro0 != nullptr || a.pro1 != nullptr || a.pro_relu != 0;
+  auto convert_pair = [&](int c0, int i, int j, bool pro) __attribute__((always_inline)) {
+    float v0 = xv[i][2 * j], v1 = xv[i][2 * j + 1];
+    if (pro) {        // `true` between the MFMA groups (no branch there), any_pro behind a barrier
+      const bool relu = (c0 < a.C0) ? (a.pro_relu & 1) : (a.pro_relu & 2);
+      const int cg = min(c0 + ihalf[i] * 8 + 2 * j, PRO_MAX - 2);
+      const float2 p0 = pro_s[cg], p1 = pro_s[cg + 1];
+      v0 = fmaf(v0, p0.x, p0.y);
+      v1 = fmaf(v1, p1.x, p1.y);
+      v0 = relu ? fmaxf(v0, 0.f) : v0;
+      v1 = relu ? fmaxf(v1, 0.f) : v1;
+      v0 = iin[i] ? v0 : 0.f;
+      v1 = iin[i] ? v1 : 0.f;
     }
+    unsigned q0, q1, q2;
+    split3_pair(v0, v1, q0, q1, q2);
+    tq[i][0][j] = q0;
+    tq[i][1][j] = q1;
+    tq[i][2][j] = q2;
+  };
+  auto store_x = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
       if (ipos[i] >= 0) {
-        u32x4v t0, t1, t2;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          unsigned q0, q1, q2;
-          split3_pair(xv[i][2 * j], xv[i][2 * j + 1], q0, q1, q2);
-          t0[j] = q0;
-          t1[j] = q1;
-          t2[j] = q2;
-        }
-        Xs[(0 * 2 + ihalf[i]) * PEP + ipos[i]] = t0;
-        Xs[(1 * 2 + ihalf[i]) * PEP + ipos[i]] = t1;
-        Xs[(2 * 2 + ihalf[i]) * PEP + ipos[i]] = t2;
+        Xs[(0 * 2 + ihalf[i]) * PEP + ipos[i]] = tq[i][0];
+        Xs[(1 * 2 + ihalf[i]) * PEP + ipos[i]] = tq[i][1];
+        Xs[(2 * 2 + ihalf[i]) * PEP + ipos[i]] = tq[i][2];
       }
     }
+  };
+  auto stash_x = [&](int c0) __attribute__((always_inline)) {
+    // (compile-time indices: as two `#pragma unroll` loops the 3x3 MT 1 variant indexed xv / tq dynamically, through scratch)
+    x3_static_for<NIT * 4>([&](auto pc) __attribute__((always_inline)) { convert_pair(c0, decltype(pc)::value >> 2, decltype(pc)::value & 3, any_pro); });
+    store_x();
   };
   // one kernel row of weights: LDS slot s = ((tl*6 + q) * CB + co), tl = tap within the row, q = term*2 + half
   unsigned wslot[NW];
@@ -421,18 +445,39 @@ __global__ __launch_bounds__(256, 2) void conv_x3_k(ConvX3Args a) {
   XSTAMPV(1, (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32));
   issue_x(0);
   issue_w(0, 0);
+  __syncthreads();                    // pro_s
   stash_x(0);
   stash_w(0);
   __syncthreads();
   XSTAMP(2);
   int buf = 0;
+  // 3x3: the next chunk's tile is loaded at the start of the middle kernel row (in flight behind that row's MFMAs) and converted
+  // piecewise between the MFMA groups of the last row; after the chunk's barrier only the LDS stores remain.  1x1 (one row
+  // per chunk): loaded in front of the row, converted behind the barrier.  The loads and the conversion also run on the last
+  // chunk (out of range: zeros) — no branch inside the MFMA stream.
+  constexpr bool PIPE = KS == 3 && MT == 2;     // MT 1: the 36 extra registers cost the third wave per SIMD (measured 210 -> 248 us)
+  constexpr int NPIECE = NIT * 4;
   for (int chunk = 0; chunk < nchunks; ++chunk) {
 #pragma unroll
     for (int ky = 0; ky < KS; ++ky) {
       const bool last_row = ky == KS - 1;
       const bool more = !last_row || chunk + 1 < nchunks;
       if (more) issue_w(last_row ? chunk + 1 : chunk, last_row ? 0 : ky + 1);
-      if (last_row && more) issue_x((chunk + 1) * KC);
+      if (PIPE ? ky == KS - 2 : (last_row && more)) issue_x((chunk + 1) * KC);
+      const int c0n = (chunk + 1) * KC;
+      int piece = 0;
+      auto convert_piece = [&]() __attribute__((always_inline)) {      // one channel pair behind each of the first NPIECE MFMA groups of the last row
+        if constexpr (PIPE) if (last_row && piece < NPIECE) {
+          convert_pair(c0n, piece >> 2, piece & 3, true);
+          // 4 MFMAs (128 cycles of the pipe) : ~20 VALU — one MFMA, then a fifth of the piece
+#pragma unroll
+          for (int q = 0; q < MT * NT; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, (24 + MT * NT - 1) / (MT * NT), 0);
+          }
+        }
+        ++piece;
+      };
       // keep the loads in front of the MFMAs (left alone, the scheduler sinks them to their first use behind the row,
       // where their latency is exposed)
       __builtin_amdgcn_sched_barrier(0);
@@ -468,20 +513,26 @@ __global__ __launch_bounds__(256, 2) void conv_x3_k(ConvX3Args a) {
           __builtin_amdgcn_sched_barrier(0);
           mm(tl, 0, 2);
           if (nx) { rd_b(tl + 1, 2); rd_a(tl + 1, 0); }
+          convert_piece();
           __builtin_amdgcn_sched_barrier(0);
           mm(tl, 1, 1);
           if (nx) rd_a(tl + 1, 1);
+          convert_piece();
           __builtin_amdgcn_sched_barrier(0);
           mm(tl, 2, 0);
           if (nx) rd_a(tl + 1, 2);
+          convert_piece();
           __builtin_amdgcn_sched_barrier(0);
           mm(tl, 0, 1);
           if (nx) rd_b(tl + 1, 1);
+          convert_piece();
           __builtin_amdgcn_sched_barrier(0);
           mm(tl, 1, 0);
+          convert_piece();
           __builtin_amdgcn_sched_barrier(0);
           mm(tl, 0, 0);
           if (nx) rd_b(tl + 1, 0);
+          convert_piece();
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -490,7 +541,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_k(ConvX3Args a) {
       if (last_row && more) {
         __syncthreads();                // every wave is done with this chunk's input tile
         if (chunk < 7) XSTAMP(3 + 7 * chunk + 5);
-        stash_x((chunk + 1) * KC);
+        if (PIPE) store_x(); else stash_x((chunk + 1) * KC);
       }
       if (chunk < 7 && last_row) XSTAMP(3 + 7 * chunk + 6);
       __syncthreads();
@@ -610,6 +661,7 @@ static int conv_x3_impl(const float* in0, int C0, const float* in1, int C1, cons
   WTPSE_REQUIRE(!bnb || (mask_ref && stats && bn_ss && !bias && !relu_out && bn_c0 >= 0 && bn_c0 < bn_c1 && bn_c1 <= Cout &&
                          bn_c0 % 16 == 0 && (bn_c1 % 16 == 0 || bn_c1 == Cout)));
   WTPSE_REQUIRE(C1 == 0 || C0 % 16 == 0);
+
   ConvX3Args a;
   a.in0 = in0; a.in1 = in1; a.wx = wpacked; a.bias = bias; a.pro0 = pro0; a.pro1 = pro1; a.out0 = out0; a.out1 = out1;
   a.stats = stats; a.mask = mask_ref;
@@ -619,6 +671,7 @@ static int conv_x3_impl(const float* in0, int C0, const float* in1, int C1, cons
   a.tiles_x = a.tiles_y = 0;
   hipStream_t st = (hipStream_t)stream;
   const bool mt2 = x3_mt2(B, H, W, a.CoutP);
+  WTPSE_REQUIRE(a.CinP <= (mt2 ? 512 : 256));            // prologue coefficients staged in LDS (conv_x3_k: PRO_MAX)
 #define X3(KS, M) (bnb ? launch_x3<KS, M, 2>(a, st) : mask_ref ? launch_x3<KS, M, 1>(a, st) : launch_x3<KS, M, 0>(a, st))
   if (ksize == 3) return mt2 ? X3(3, 2) : X3(3, 1);
   return mt2 ? X3(1, 2) : X3(1, 1);

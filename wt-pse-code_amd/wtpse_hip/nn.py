@@ -459,7 +459,7 @@ X16_MIN_K = int(os.environ.get("WTPSE_X16_MIN_K", "8"))
 
 def x3_eligible(k_dim, rows, ksize):
     """rows = output channels of the launch (Cout forward, Cin for a data gradient), k_dim = its reduction channels."""
-    return X3 and rows > 16 and k_dim >= 16 and (ksize == 3 or k_dim >= 64)
+    return X3 and rows > 16 and 16 <= k_dim <= 256 and (ksize == 3 or k_dim >= 64)     # 256: wtpse_conv_fwd_x3 (include/wtpse_hip.h)
 
 
 def _conv(layer, a0, a1=None, relu_out=False, want_stats=False):
