@@ -89,6 +89,22 @@ int wtpse_dgrad_x3_bnb(const float* dy, int C, const unsigned short* wpacked, fl
                        const float* bn_y, const float* bn_ss, const float* bn_mean, int bn_relu, int bn_c0, int bn_c1, float* stats,
                        int B, int H, int W, int Cout, int ksize, void* stream);
 
+/* The same launches, which then ALSO finish the statistics: groups of 64 workgroups fold their partials as their last member
+ * arrives, the last group of an output-channel block folds the group sums (fixed order: bitwise reproducible, nobody waits) and
+ * writes coef [Cbn][3] = (k1, k2, k3) and dgamma / dbeta (+)= (accumulate) of the BatchNorm'd channels — what
+ * wtpse_bn_bwd_from_stats does in its first launch.  wtpse_bn_bwd_apply_coef is then the whole rest of the BatchNorm backward.
+ * layout: 0 = wtpse_dgrad_bnb (fp32 `wd`), 1 = wtpse_dgrad_x3_bnb, 2 = wtpse_conv16_x3's fragments (Csplit == Cout, all channels).
+ * gamma / invstd: of the BatchNorm'd channels.  partial2: wtpse_bnb_tail_partial2(nblk, Cout) doubles of scratch; tickets:
+ * wtpse_bnb_tail_tickets(nblk, Cout) unsigneds, ZERO on entry and zero again when the launch has finished (nblk = rows of stats);
+ * two launches that may overlap must not share them. */
+int wtpse_bnb_tail_partial2(int nblk, int Cout);
+int wtpse_bnb_tail_tickets(int nblk, int Cout);
+int wtpse_dgrad_bnb_coef(const float* dy, int C, const void* wpacked, int layout, float* out0, float* out1, int Csplit,
+                         const float* bn_y, const float* bn_ss, const float* bn_mean, int bn_relu, int bn_c0, int bn_c1,
+                         float* stats, const float* gamma, const float* invstd, float* coef, float* dgamma, float* dbeta,
+                         int accumulate, double* partial2, unsigned* tickets, int B, int H, int W, int Cout, int ksize,
+                         void* stream);
+
 /* dW[Cout][C0+C1][k][k] (+)= sum dY * X, dbias (+)= sum dY (dbias/dbias_slab NULL: skip).  slab: [ksplit][Cout*Cin*k*k],
  * dbias_slab: [ksplit][Cout], ksplit = wtpse_wgrad_ksplit(...).  x inputs take the same prologue as the forward. */
 int wtpse_conv_wgrad(const float* dy, const float* x0, int C0, const float* x1, int C1, const float* pro0,
@@ -153,6 +169,9 @@ int wtpse_bn_bwd_apply(const float* dz, const float* y, const float* scale_shift
 int wtpse_bn_bwd_from_stats(const float* g, const float* y, const float* stats_partial, int nblk, const float* gamma,
                             const float* save_mean, const float* save_invstd, float* coef, float* dgamma, float* dbeta,
                             int accumulate, float* dy, int B, int C, int HW, void* stream);
+
+/* dy = k1 * g + k2 * y + k3 with coef [C][3] from wtpse_dgrad_bnb_coef. */
+int wtpse_bn_bwd_apply_coef(const float* g, const float* y, const float* coef, float* dy, int B, int C, int HW, void* stream);
 
 /* ---- WT (whitening) loss: compute_whitening_loss + compute_MMD (algorithms.py:1277-1309,59-121;
  *      shape_networks.py:561-594,240-309) ------------------------------------------------------------------------ */

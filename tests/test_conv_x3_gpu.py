@@ -258,10 +258,23 @@ def test_dgrad_bnb(case):
         packed, _, wd = pack(w)
         wptr = packed.data_ptr() + 4 * wd
     split = None if not Co else (Co if bn_second else Cl)
-    g0, g1, stats = o.dgrad_bnb(du.to(DEV), wptr, x3, Cl + Co, k, yd, ss, mean_f, relu, split, bn_second)
+    g0, g1, stats, _ = o.dgrad_bnb(du.to(DEV), wptr, x3, Cl + Co, k, yd, ss, mean_f, relu, split, bn_second)
     g = g1 if (Co and bn_second) else g0
     dg, dbt = torch.empty(Cl, device=DEV), torch.empty(Cl, device=DEV)
     dy = o.bn_bwd_from_stats(g, yd, stats, g_d, mean_f, invstd_f, dg, dbt)
+    # the same launch folding its partials itself (last-arriver tickets): same masked gradient bit for bit, coefficients and
+    # dgamma / dbeta equal to the stand-alone fold up to the order of the fp64 sums
+    dg_t, dbt_t = torch.full((Cl,), 7.0, device=DEV), torch.full((Cl,), 7.0, device=DEV)
+    h0, h1, stats_t, coef = o.dgrad_bnb(du.to(DEV), wptr, x3, Cl + Co, k, yd, ss, mean_f, relu, split, bn_second,
+                                        tail=(g_d, invstd_f.to(DEV), dg_t, dbt_t))
+    h = h1 if (Co and bn_second) else h0
+    assert torch.equal(h, g) and torch.equal(stats_t, stats)
+    dy_t = o.bn_bwd_apply_coef(h, yd, coef)
+    close(dg_t, dg, rtol=1e-6, atol=1e-6 * float(dg.abs().max()) + 1e-9, what="tail dgamma")
+    close(dbt_t, dbt, rtol=1e-6, atol=1e-6 * float(dbt.abs().max()) + 1e-9, what="tail dbeta")
+    close(dy_t, dy, rtol=1e-5, atol=1e-6 * float(dy.abs().max()), what="tail dy")
+    torch.cuda.synchronize()
+    assert all(int(t[0].abs().sum()) == 0 for t in o._TICKETS.values()), "tickets must be left at zero"
     kz = lambda t: torch.where(on_kink.to(t.device), torch.zeros_like(t), t)
     assert int(on_kink.sum()) <= max(2, on_kink.numel() // 100000)
     sc = float(y.grad.abs().max())

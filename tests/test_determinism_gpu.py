@@ -106,14 +106,31 @@ def test_dgrad_bnb_repeatable(x3, C, H, W, k):
     else:
         packed, _, wd = pack(w)
         wptr = packed.data_ptr() + 4 * wd
-    g0, _, st0 = o.dgrad_bnb(du, wptr, x3, C, k, y, ss, mean, True)
+    g0, _, st0, _ = o.dgrad_bnb(du, wptr, x3, C, k, y, ss, mean, True)
     g0, st0 = g0.clone(), st0.clone()
     for it in range(150):
         junk = torch.empty((1 << 22) + 4096 * it, device=DEV).fill_(float(it))
-        g, _, st = o.dgrad_bnb(du, wptr, x3, C, k, y, ss, mean, True)
+        g, _, st, _ = o.dgrad_bnb(du, wptr, x3, C, k, y, ss, mean, True)
         assert torch.equal(g, g0), "launch %d: %d masked-gradient elements differ" % (it, int((g != g0).sum()))
         assert torch.equal(st, st0), "launch %d: partials differ" % it
         del junk
+    # the launch that folds its own partials (last-arriver tickets, csrc/common.h: bnb_tail): whoever arrives last, the
+    # coefficients and dgamma / dbeta are the same bits, and the tickets are back at zero
+    gamma = (rnd(C, seed=47) * 0.2 + 1.0).to(DEV)
+    invstd = (rnd(C, seed=48).abs() + 0.5).to(DEV)
+    ref = None
+    for it in range(100):
+        junk = torch.empty((1 << 22) + 4096 * it, device=DEV).fill_(float(it))
+        dg, db = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+        g, _, st, coef = o.dgrad_bnb(du, wptr, x3, C, k, y, ss, mean, True, tail=(gamma, invstd, dg, db))
+        cur = (coef.clone(), dg.clone(), db.clone())
+        if ref is None:
+            ref = cur
+            assert torch.equal(g, g0) and torch.equal(st, st0)
+        for a, b, what in zip(cur, ref, ("coef", "dgamma", "dbeta")):
+            assert torch.equal(a, b), "launch %d: %s differs" % (it, what)
+        del junk
+    assert all(int(t[0].abs().sum()) == 0 for t in o._TICKETS.values()), "tickets must be left at zero"
 
 
 @pytest.mark.gpu

@@ -50,7 +50,7 @@ def main():
              lambda: ops.conv_fwd(x, None, pk.data_ptr() + 4 * wd, None, 16, 3, mask_ref=yref),
              lambda: ops.conv16_x3(x, px.data_ptr() + 2 * n, None, 16, mask_ref=yref), byts * 1.5),
             ("data gradient + BatchNorm-backward epilogue",
-             lambda: ops.dgrad_bnb(x, pk.data_ptr() + 4 * wd, False, 16, 3, yref, ss, mean, True),
+             lambda: ops.dgrad_bnb(x, pk.data_ptr() + 4 * wd, 0, 16, 3, yref, ss, mean, True),
              lambda: ops.conv16_x3(x, px.data_ptr() + 2 * n, None, 16, bnb=(yref, ss, mean, True)), byts * 1.5),
         ]
         print("16 -> 16, 3x3, %dx%d, B=%d  (%.0f MB in+out, %.2f GFLOP)" % (H, H, b, byts / 1e6, flops / 1e9))

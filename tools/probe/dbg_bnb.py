@@ -19,7 +19,7 @@ g_d, b_d = gamma.detach().float().to(DEV), beta.detach().float().to(DEV)
 ss = torch.stack([g_d.double()*invstd, b_d.double()-mean*g_d.double()*invstd],1).float().contiguous()
 mean_f, invstd_f = mean.float().contiguous(), invstd.float().contiguous()
 packed,_,xd = pack_x3(w); wptr = packed.data_ptr()+2*xd
-g0,g1,stats = o.dgrad_bnb(du.to(DEV), wptr, True, Cl, k, yd, ss, mean_f, relu, None, False)
+g0,g1,stats,_ = o.dgrad_bnb(du.to(DEV), wptr, True, Cl, k, yd, ss, mean_f, relu, None, False)
 dg, dbt = torch.empty(Cl, device=DEV), torch.empty(Cl, device=DEV)
 dy = o.bn_bwd_from_stats(g0, yd, stats, g_d, mean_f, invstd_f, dg, dbt)
 d0,_,_ = o.conv_fwd_x3(du.to(DEV), None, wptr, None, Cl, k)
@@ -43,7 +43,7 @@ for it in range(300):
     junk.uniform_(-5, 5)          # dirty the allocator's free blocks between iterations
     del junk
     junk = torch.empty((1 << 26) + it * 1024, device=DEV); junk.fill_(float(it))
-    g0_, _, st_ = o.dgrad_bnb(du.to(DEV), wptr, True, Cl, k, yd, ss, mean_f, relu, None, False)
+    g0_, _, st_, _ = o.dgrad_bnb(du.to(DEV), wptr, True, Cl, k, yd, ss, mean_f, relu, None, False)
     dy_ = o.bn_bwd_from_stats(g0_, yd, st_, g_d, mean_f, invstd_f, dg, dbt)
     d0_, _, _ = o.conv_fwd_x3(du.to(DEV), None, wptr, None, Cl, k)
     dy2_ = o.bn_bwd(d0_, yd, ss, relu, g_d, mean_f, invstd_f, dg2, dbt2)

@@ -421,3 +421,18 @@ extern "C" int wtpse_bn_bwd_from_stats(const float* g, const float* y, const flo
                        ceil_div(HW, 256), dy);
   return wtpse_status();
 }
+
+// dy = k1 * g + k2 * y + k3 with the coefficients a data gradient's tail left in `coef` (wtpse_dgrad_bnb_coef): the whole
+// BatchNorm backward that remains once the reductions and their fold happened in the producing launch.
+extern "C" int wtpse_bn_bwd_apply_coef(const float* g, const float* y, const float* coef, float* dy, int B, int C, int HW,
+                                       void* stream) {
+  WTPSE_REQUIRE(g && y && coef && dy && B > 0 && C > 0 && HW > 0);
+  hipStream_t st = (hipStream_t)stream;
+  if (vec_ok(HW, g, y, dy))
+    hipLaunchKernelGGL(bn_bwd_apply_k<true>, dim3(ceil_div(HW, 1024) * B * C), dim3(256), 0, st, g, y, coef, 0, coef, C, HW,
+                       ceil_div(HW, 1024), dy);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_k<false>, dim3(ceil_div(HW, 256) * B * C), dim3(256), 0, st, g, y, coef, 0, coef, C, HW,
+                       ceil_div(HW, 256), dy);
+  return wtpse_status();
+}

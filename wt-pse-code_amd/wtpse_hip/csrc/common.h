@@ -79,3 +79,131 @@ __device__ __forceinline__ void wt_split3_pair(float a, float b, unsigned& p0, u
 __device__ __forceinline__ f32x4 wt_mfma16x32(u32x4 a, u32x4 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(wt_bf16x8, a), __builtin_bit_cast(wt_bf16x8, b), c, 0, 0, 0);
 }
+
+// ---- BatchNorm-backward coefficients from the epilogue of the data gradient that produced the statistics (conv.hip, conv_x3.hip:
+// EPI 2).  Every workgroup has written its (sum g, sum g (y - mean)) partials to stats[tile][Cbn][2]; instead of a separate
+// finalize launch (a 16..256-workgroup kernel that sat between two big launches of a dependency chain, 142 times per step, and
+// waited 50 us on average for a free CU beside the weight gradient on the other stream), the partials are folded by whoever
+// arrives last: groups of 64 consecutive tiles take a ticket, the last arriver of a group folds the group in index order
+// (fp64) into partial2, then the groups of one output-channel block take a second ticket and the last of them folds the
+// group sums — again in index order, so the result does not depend on who arrives when — and writes (k1, k2, k3), dgamma,
+// dbeta exactly as bn_bwd_finalize_k does.  Nobody waits for anybody: no spinning.  Tickets are zero on entry and are left zero.
+struct BnbTail {
+  double* partial2;        // [ngroups][ctot][2]
+  unsigned* tickets;       // [t2_off + blocks along y]; null: no tail (stats only)
+  const float* gamma;      // of the BatchNorm'd channels (index c - bn_c0), as invstd / mean
+  const float* invstd;
+  float* coef;             // [Cbn][3]
+  float* dgamma;
+  float* dbeta;
+  double count;
+  int accumulate, ngroups, ntiles, ctot, t2_off;
+};
+
+// Hand-off between workgroups without cache-wide fences (MI355X_MICROARCH.md, inter-workgroup visibility): the producer
+// publishes with agent-scope (write-through) stores and drains them (s_waitcnt vmcnt(0)) before it takes its ticket with a
+// relaxed agent-scope atomic; the consumer reads with agent-scope loads.  (An agent-scope release fence writes back the whole
+// L2 of the XCD: thousands of those beside a kernel that is writing its output are not an option.)
+__device__ __forceinline__ void pub_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void pub_store(double* p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float pub_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double pub_load(const double* p) {
+  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                                                            __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void pub_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// The caller has written this workgroup's partials with pub_store().
+template <int CB>
+__device__ __forceinline__ void bnb_tail(const BnbTail& tl, const float* stats, const float* __restrict__ bn_mean,
+                                         int bn_c0, int bn_c1, int cout0, int tile, int y, int tid, double* sh, int* flag_s) {
+  static_assert(CB * 2 <= 256, "one thread per (channel, sum)");
+  if (tl.tickets == nullptr) return;
+  if (cout0 >= bn_c1 || cout0 + CB <= bn_c0) return;          // no BatchNorm'd channel in this block (uniform)
+  const int Cbn = bn_c1 - bn_c0;
+  pub_drain();
+  __syncthreads();
+  const int grp = tile >> 6, g0 = grp << 6;
+  const int gsize = min(64, tl.ntiles - g0);
+  if (tid == 0) {
+    const unsigned old = __hip_atomic_fetch_add(tl.tickets + (size_t)y * tl.ngroups + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *flag_s = old == (unsigned)(gsize - 1);
+  }
+  __syncthreads();
+  if (!*flag_s) return;
+  const int crel = tid >> 1, k = tid & 1, c = cout0 + crel;
+  const bool mine = tid < CB * 2 && c >= bn_c0 && c < bn_c1;
+  {
+    double s = 0.0;
+    if (mine) {
+      const float* p = stats + ((size_t)g0 * Cbn + (c - bn_c0)) * 2 + k;
+      int i = 0;
+      for (; i + 8 <= gsize; i += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = pub_load(p + (size_t)(i + u) * Cbn * 2);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += (double)v[u];
+      }
+      for (; i < gsize; ++i) s += (double)pub_load(p + (size_t)i * Cbn * 2);
+      pub_store(tl.partial2 + ((size_t)grp * tl.ctot + c) * 2 + k, s);
+    }
+    if (tid == 0) __hip_atomic_store(tl.tickets + (size_t)y * tl.ngroups + grp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  pub_drain();
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned old = __hip_atomic_fetch_add(tl.tickets + tl.t2_off + y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *flag_s = old == (unsigned)(tl.ngroups - 1);
+  }
+  __syncthreads();
+  if (!*flag_s) return;
+  double s = 0.0;
+  if (mine) {
+    const double* p = tl.partial2 + (size_t)c * 2 + k;
+    int i = 0;
+    for (; i + 8 <= tl.ngroups; i += 8) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = pub_load(p + (size_t)(i + u) * tl.ctot * 2);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; i < tl.ngroups; ++i) s += pub_load(p + (size_t)i * tl.ctot * 2);
+  }
+  if (tid < CB * 2) sh[tid] = s;
+  if (tid == 0) __hip_atomic_store(tl.tickets + tl.t2_off + y, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (mine && k == 0) {
+    const int cb = c - bn_c0;
+    const double is = (double)tl.invstd[cb], ga = (double)tl.gamma[cb];
+    const double s1 = sh[tid], s2 = sh[tid + 1] * is;          // the partials hold sum g (y - mean): not yet / std
+    tl.dbeta[cb] = tl.accumulate ? tl.dbeta[cb] + (float)s1 : (float)s1;
+    tl.dgamma[cb] = tl.accumulate ? tl.dgamma[cb] + (float)s2 : (float)s2;
+    const double k1 = ga * is;
+    const double k2 = -ga * is * is * s2 / tl.count;
+    const double k3 = -k1 * s1 / tl.count - k2 * (double)bn_mean[cb];
+    tl.coef[3 * cb] = (float)k1;
+    tl.coef[3 * cb + 1] = (float)k2;
+    tl.coef[3 * cb + 2] = (float)k3;
+  }
+}
+
+// Host side: the caller-provided part of a tail (null tickets: none) completed with the launch's geometry.  partial2 must hold
+// wtpse_bnb_tail_partial2(nblk, Cout) doubles, tickets wtpse_bnb_tail_tickets(nblk, Cout) zeroed unsigneds (include/wtpse_hip.h).
+static inline int bnb_tail_groups(int ntiles) { return (ntiles + 63) / 64; }
+static inline int bnb_tail_ctot(int Cout) { return (Cout + 63) & ~63; }
+static inline int bnb_tail_t2off(int ntiles, int Cout) { return ((Cout + 15) / 16) * bnb_tail_groups(ntiles); }
+static inline BnbTail bnb_tail_none() {
+  BnbTail t;
+  t.partial2 = nullptr; t.tickets = nullptr; t.gamma = nullptr; t.invstd = nullptr; t.coef = nullptr; t.dgamma = nullptr; t.dbeta = nullptr;
+  t.count = 1.0; t.accumulate = 0; t.ngroups = 0; t.ntiles = 0; t.ctot = 0; t.t2_off = 0;
+  return t;
+}
+static inline void bnb_tail_geometry(BnbTail& t, int ntiles, int Cout, double count) {
+  t.ntiles = ntiles; t.ngroups = bnb_tail_groups(ntiles); t.ctot = bnb_tail_ctot(Cout); t.t2_off = bnb_tail_t2off(ntiles, Cout);
+  t.count = count;
+}

@@ -49,6 +49,7 @@ struct ConvArgs {
   const float* bn_ss;
   const float* bn_mean;
   int bn_c0, bn_c1, bn_relu;
+  BnbTail tail;        // EPI == 2: the BatchNorm-backward coefficients from the last workgroups (common.h), or tickets == null
   int B, H, W;
   int C0, C1, Cin, CinP;
   int Cout, CoutP, Csplit;
@@ -564,11 +565,14 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
       const float s = red[tid] + red[CB * 2 + tid] + red[2 * CB * 2 + tid] + red[3 * CB * 2 + tid];
       if (BNB) {
         const int c = cout0 + crel;
-        if (c >= a.bn_c0 && c < a.bn_c1) a.stats[((size_t)blockIdx.x * Cbn + c - a.bn_c0) * 2 + (tid & 1)] = s;
+        if (c >= a.bn_c0 && c < a.bn_c1) pub_store(a.stats + ((size_t)blockIdx.x * Cbn + c - a.bn_c0) * 2 + (tid & 1), s);
       } else if (cout0 + crel < a.Cout) {
         a.stats[((size_t)blockIdx.x * a.Cout + cout0 + crel) * 2 + (tid & 1)] = s;
       }
     }
+    if constexpr (BNB)
+      bnb_tail<CB>(a.tail, a.stats, a.bn_mean, a.bn_c0, a.bn_c1, cout0, (int)blockIdx.x, (int)blockIdx.y, tid,
+                   reinterpret_cast<double*>(red), reinterpret_cast<int*>(red + 4 * CB));
   }
   STAMP(61);
 }
@@ -582,6 +586,7 @@ static int launch_fwd(const ConvArgs& a, hipStream_t st) {
   args.tiles_x = ceil_div(a.W, TW);
   args.tiles_y = ceil_div(a.H, TH);
   dim3 grid((unsigned)(a.B * args.tiles_x * args.tiles_y), (unsigned)ceil_div(a.CoutP, CB));
+  if (args.tail.tickets) bnb_tail_geometry(args.tail, (int)grid.x, a.Cout, (double)a.B * a.H * a.W);
   if (narrow)
     hipLaunchKernelGGL((conv_fwd_k<KS, MODE, 4, DB, EPI>), grid, dim3(256), 0, st, args);
   else
@@ -608,7 +613,7 @@ struct BnbArgs {   // EPI 2 parameters of conv_fwd_impl (all null / 0: none)
 static int conv_fwd_impl(const float* in0, int C0, const float* in1, int C1, const float* wpacked, const float* bias,
                          const float* pro0, const float* pro1, int pro_relu, float* out0, float* out1, int Csplit, float* stats,
                          int B, int H, int W, int Cout, int ksize, int relu_out, const float* mask_ref, float* gram,
-                         void* stream, BnbArgs bn = BnbArgs{nullptr, nullptr, 0, 0, 0}) {
+                         void* stream, BnbArgs bn = BnbArgs{nullptr, nullptr, 0, 0, 0}, BnbTail tail = bnb_tail_none()) {
   WTPSE_REQUIRE(in0 && wpacked && out0 && B > 0 && H > 0 && W > 0 && C0 > 0 && C1 >= 0 && Cout > 0);
   WTPSE_REQUIRE(ksize == 1 || ksize == 3);
   WTPSE_REQUIRE((C1 == 0) == (in1 == nullptr));
@@ -621,7 +626,9 @@ static int conv_fwd_impl(const float* in0, int C0, const float* in1, int C1, con
   WTPSE_REQUIRE(!bnb || (mask_ref && stats && bn.ss && !bias && !relu_out && !gram && bn.c0 >= 0 && bn.c0 < bn.c1 && bn.c1 <= Cout &&
                          bn.c0 % 16 == 0 && (bn.c1 % 16 == 0 || bn.c1 == Cout)));
   WTPSE_REQUIRE(C1 == 0 || C0 % 16 == 0);   // a channel chunk must not straddle the two inputs
+  WTPSE_REQUIRE(!tail.tickets || (bnb && tail.partial2 && tail.gamma && tail.invstd && tail.coef && tail.dgamma && tail.dbeta));
   ConvArgs a;
+  a.tail = tail;
   a.bn_ss = bn.ss; a.bn_mean = bn.mean; a.bn_relu = bn.relu; a.bn_c0 = bnb ? bn.c0 : 0; a.bn_c1 = bnb ? bn.c1 : 0;
   a.in0 = in0; a.in1 = in1; a.wp = wpacked; a.bias = bias; a.pro0 = pro0; a.pro1 = pro1; a.out0 = out0; a.out1 = out1; a.stats = stats; a.mask = mask_ref; a.gram = gram;
   a.B = B; a.H = H; a.W = W; a.C0 = C0; a.C1 = C1; a.Cin = C0 + C1; a.CinP = (a.Cin + 3) & ~3;
@@ -672,17 +679,19 @@ extern "C" int wtpse_dgrad_bnb(const float* dy, int C, const float* wpacked, flo
 // fragments from wtpse_pack_conv16_x3.  Everything optional: bias, prologue, ReLU, BatchNorm (sum, sum^2) partials `stats`,
 // Gram partials `gram_partial` (Cout == 16), ReLU mask `mask_ref`, or — with bn_mean — the BatchNorm-backward epilogue of
 // wtpse_dgrad_bnb over all output channels (mask_ref = that layer's raw conv output).
-extern "C" int wtpse_conv16_x3(const float* in0, int C0, const unsigned short* wx16, const float* bias, const float* pro0,
-                               int pro_relu, float* out0, float* stats, float* gram_partial, const float* mask_ref,
-                               const float* bn_ss, const float* bn_mean, int bn_relu, int B, int H, int W, int Cout, int relu_out,
-                               void* stream) {
+static int conv16_x3_impl(const float* in0, int C0, const unsigned short* wx16, const float* bias, const float* pro0,
+                          int pro_relu, float* out0, float* stats, float* gram_partial, const float* mask_ref,
+                          const float* bn_ss, const float* bn_mean, int bn_relu, int B, int H, int W, int Cout, int relu_out,
+                          void* stream, BnbTail tail = bnb_tail_none()) {
   WTPSE_REQUIRE(in0 && wx16 && out0 && B > 0 && H > 0 && W > 0 && C0 > 0 && C0 <= 16 && Cout > 0 && Cout <= 16);
   WTPSE_REQUIRE(!(stats && relu_out) && !(gram_partial && (Cout != 16 || relu_out)));
   WTPSE_REQUIRE((((uintptr_t)wx16) & 15) == 0);
   const bool bnb = bn_mean != nullptr;
   WTPSE_REQUIRE(bnb || !(stats && mask_ref));
   WTPSE_REQUIRE(!bnb || (mask_ref && stats && bn_ss && !bias && !relu_out && !gram_partial));
+  WTPSE_REQUIRE(!tail.tickets || (bnb && tail.partial2 && tail.gamma && tail.invstd && tail.coef && tail.dgamma && tail.dbeta));
   ConvArgs a;
+  a.tail = tail;
   a.in0 = in0; a.in1 = nullptr; a.wp = reinterpret_cast<const float*>(wx16); a.bias = bias; a.pro0 = pro0; a.pro1 = nullptr;
   a.out0 = out0; a.out1 = nullptr; a.stats = stats; a.mask = mask_ref; a.gram = gram_partial;
   a.bn_ss = bn_ss; a.bn_mean = bn_mean; a.bn_relu = bn_relu; a.bn_c0 = 0; a.bn_c1 = bnb ? Cout : 0;
@@ -693,6 +702,47 @@ extern "C" int wtpse_conv16_x3(const float* in0, int C0, const unsigned short* w
   if (bnb) return launch_fwd<3, 3, false, 2>(a, st);
   if (mask_ref) return launch_fwd<3, 3, false, 1>(a, st);
   return launch_fwd<3, 3, false, 0>(a, st);
+}
+
+extern "C" int wtpse_conv16_x3(const float* in0, int C0, const unsigned short* wx16, const float* bias, const float* pro0,
+                               int pro_relu, float* out0, float* stats, float* gram_partial, const float* mask_ref,
+                               const float* bn_ss, const float* bn_mean, int bn_relu, int B, int H, int W, int Cout, int relu_out,
+                               void* stream) {
+  return conv16_x3_impl(in0, C0, wx16, bias, pro0, pro_relu, out0, stats, gram_partial, mask_ref, bn_ss, bn_mean, bn_relu, B, H, W,
+                        Cout, relu_out, stream);
+}
+
+// ---- wtpse_dgrad_bnb / wtpse_dgrad_x3_bnb / wtpse_conv16_x3(bn_mean) whose launch ALSO finishes the statistics: the last
+// workgroups fold the partials (common.h: bnb_tail) and leave (k1, k2, k3) in `coef`, dgamma / dbeta (+)= in place, so that the
+// BatchNorm backward is this launch + wtpse_bn_bwd_apply_coef.  layout: 0 fp32 (`wd`), 1 x3, 2 the 16-channel x3 fragments.
+extern "C" int wtpse_dgrad_x3_bnb_tail(const float* dy, int C, const unsigned short* wpacked, float* out0, float* out1, int Csplit,
+                                       const float* bn_y, const float* bn_ss, const float* bn_mean, int bn_relu, int bn_c0,
+                                       int bn_c1, float* stats, const BnbTail* tail, int B, int H, int W, int Cout, int ksize,
+                                       void* stream);
+
+extern "C" int wtpse_bnb_tail_partial2(int nblk, int Cout) { return bnb_tail_groups(nblk) * bnb_tail_ctot(Cout) * 2; }
+extern "C" int wtpse_bnb_tail_tickets(int nblk, int Cout) { return bnb_tail_t2off(nblk, Cout) + (Cout + 15) / 16; }
+
+extern "C" int wtpse_dgrad_bnb_coef(const float* dy, int C, const void* wpacked, int layout, float* out0, float* out1, int Csplit,
+                                    const float* bn_y, const float* bn_ss, const float* bn_mean, int bn_relu, int bn_c0, int bn_c1,
+                                    float* stats, const float* gamma, const float* invstd, float* coef, float* dgamma,
+                                    float* dbeta, int accumulate, double* partial2, unsigned* tickets, int B, int H, int W,
+                                    int Cout, int ksize, void* stream) {
+  WTPSE_REQUIRE(bn_y && bn_ss && bn_mean && stats && gamma && invstd && coef && dgamma && dbeta && partial2 && tickets);
+  WTPSE_REQUIRE(layout >= 0 && layout <= 2);
+  BnbTail t = bnb_tail_none();
+  t.partial2 = partial2; t.tickets = tickets; t.gamma = gamma; t.invstd = invstd; t.coef = coef; t.dgamma = dgamma; t.dbeta = dbeta;
+  t.accumulate = accumulate;
+  if (layout == 1)
+    return wtpse_dgrad_x3_bnb_tail(dy, C, static_cast<const unsigned short*>(wpacked), out0, out1, Csplit, bn_y, bn_ss, bn_mean,
+                                   bn_relu, bn_c0, bn_c1, stats, &t, B, H, W, Cout, ksize, stream);
+  if (layout == 2) {
+    WTPSE_REQUIRE(ksize == 3 && !out1 && Csplit == Cout && bn_c0 == 0 && bn_c1 == Cout);
+    return conv16_x3_impl(dy, C, static_cast<const unsigned short*>(wpacked), nullptr, nullptr, 0, out0, stats, nullptr, bn_y, bn_ss,
+                          bn_mean, bn_relu, B, H, W, Cout, 0, stream, t);
+  }
+  return conv_fwd_impl(dy, C, nullptr, 0, static_cast<const float*>(wpacked), nullptr, nullptr, nullptr, 0, out0, out1, Csplit, stats,
+                       B, H, W, Cout, ksize, 0, bn_y, nullptr, stream, BnbArgs{bn_ss, bn_mean, bn_relu, bn_c0, bn_c1}, t);
 }
 
 // Weight fragments of the 16-channel x3 path, all convs of a network in one launch.  desc: n_desc x 8 ints {w_off, Cout, Cin,

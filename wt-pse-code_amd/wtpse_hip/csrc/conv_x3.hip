@@ -52,6 +52,7 @@ struct ConvX3Args {
   const float* bn_ss;         // [bn_c1 - bn_c0][2]
   const float* bn_mean;       // [bn_c1 - bn_c0]
   int bn_c0, bn_c1, bn_relu;
+  BnbTail tail;               // EPI == 2: the BatchNorm-backward coefficients from the last workgroups (common.h), or tickets == null
   int B, H, W;
   int C0, C1, Cin, CinP;      // CinP: multiple of 16
   int Cout, CoutP, Csplit;    // CoutP: multiple of 32
@@ -258,11 +259,14 @@ __device__ __forceinline__ void x3_epilogue(const ConvX3Args& a, f32x16 (&acc)[M
       const float s = red[tid] + red[CB * 2 + tid] + red[2 * CB * 2 + tid] + red[3 * CB * 2 + tid];
       if (BNB) {
         const int c = cout0 + crel;
-        if (live && c >= a.bn_c0 && c < a.bn_c1) a.stats[((size_t)stats_row * Cbn + c - a.bn_c0) * 2 + (tid & 1)] = s;
+        if (live && c >= a.bn_c0 && c < a.bn_c1) pub_store(a.stats + ((size_t)stats_row * Cbn + c - a.bn_c0) * 2 + (tid & 1), s);
       } else if (live && cout0 + crel < a.Cout) {
         a.stats[((size_t)stats_row * a.Cout + cout0 + crel) * 2 + (tid & 1)] = s;
       }
     }
+    if constexpr (BNB)
+      bnb_tail<CB>(a.tail, a.stats, a.bn_mean, a.bn_c0, a.bn_c1, cout0, stats_row, (int)blockIdx.y, tid,
+                   reinterpret_cast<double*>(red), reinterpret_cast<int*>(red + 4 * CB));
   }
 }
 
@@ -615,6 +619,7 @@ static int launch_x3(const ConvX3Args& a, hipStream_t st) {
   args.tiles_x = ceil_div(a.W, TW);
   args.tiles_y = ceil_div(a.H, TH);
   dim3 grid((unsigned)(a.B * args.tiles_x * args.tiles_y), (unsigned)ceil_div(a.CoutP, 32 * MT));
+  if (args.tail.tickets) bnb_tail_geometry(args.tail, (int)grid.x, a.Cout, (double)a.B * a.H * a.W);
   if (small) {
     if constexpr (MT == 1) hipLaunchKernelGGL((conv_x3_k<KS, 1, 4, EPI, 1>), grid, dim3(256), 0, st, args);
   } else if (narrow)
@@ -648,7 +653,7 @@ static int conv_x3_impl(const float* in0, int C0, const float* in1, int C1, cons
                         const float* bias, const float* pro0, const float* pro1, int pro_relu, float* out0, float* out1,
                         int Csplit, float* stats, int B, int H, int W, int Cout, int ksize, int relu_out,
                         const float* mask_ref, const float* bn_ss, const float* bn_mean, int bn_relu, int bn_c0, int bn_c1,
-                        void* stream) {
+                        void* stream, BnbTail tail = bnb_tail_none()) {
   WTPSE_REQUIRE(in0 && wpacked && out0 && B > 0 && H > 0 && W > 0 && C0 > 0 && C1 >= 0 && Cout > 0);
   WTPSE_REQUIRE(ksize == 1 || ksize == 3);
   WTPSE_REQUIRE((C1 == 0) == (in1 == nullptr));
@@ -666,6 +671,8 @@ static int conv_x3_impl(const float* in0, int C0, const float* in1, int C1, cons
   a.in0 = in0; a.in1 = in1; a.wx = wpacked; a.bias = bias; a.pro0 = pro0; a.pro1 = pro1; a.out0 = out0; a.out1 = out1;
   a.stats = stats; a.mask = mask_ref;
   a.bn_ss = bn_ss; a.bn_mean = bn_mean; a.bn_relu = bn_relu; a.bn_c0 = bnb ? bn_c0 : 0; a.bn_c1 = bnb ? bn_c1 : 0;
+  WTPSE_REQUIRE(!tail.tickets || (bnb && tail.partial2 && tail.gamma && tail.invstd && tail.coef && tail.dgamma && tail.dbeta));
+  a.tail = tail;
   a.B = B; a.H = H; a.W = W; a.C0 = C0; a.C1 = C1; a.Cin = C0 + C1; a.CinP = (a.Cin + 15) & ~15;
   a.Cout = Cout; a.CoutP = (Cout + 31) & ~31; a.Csplit = Csplit; a.pro_relu = pro_relu; a.relu_out = relu_out;
   a.tiles_x = a.tiles_y = 0;
@@ -695,6 +702,16 @@ extern "C" int wtpse_dgrad_x3_bnb(const float* dy, int C, const unsigned short* 
   WTPSE_REQUIRE(bn_y && bn_ss && bn_mean && stats);
   return conv_x3_impl(dy, C, nullptr, 0, wpacked, nullptr, nullptr, nullptr, 0, out0, out1, Csplit, stats, B, H, W, Cout, ksize, 0,
                       bn_y, bn_ss, bn_mean, bn_relu, bn_c0, bn_c1, stream);
+}
+
+// wtpse_dgrad_bnb_coef (conv.hip), x3 layout
+extern "C" int wtpse_dgrad_x3_bnb_tail(const float* dy, int C, const unsigned short* wpacked, float* out0, float* out1, int Csplit,
+                                       const float* bn_y, const float* bn_ss, const float* bn_mean, int bn_relu, int bn_c0,
+                                       int bn_c1, float* stats, const BnbTail* tail, int B, int H, int W, int Cout, int ksize,
+                                       void* stream) {
+  WTPSE_REQUIRE(bn_y && bn_ss && bn_mean && stats && tail);
+  return conv_x3_impl(dy, C, nullptr, 0, wpacked, nullptr, nullptr, nullptr, 0, out0, out1, Csplit, stats, B, H, W, Cout, ksize, 0,
+                      bn_y, bn_ss, bn_mean, bn_relu, bn_c0, bn_c1, stream, *tail);
 }
 
 // ================================================================================================

@@ -277,6 +277,7 @@ class HipNet(nn.Module):
             xdesc += [self._offsets[self._pindex[id(c.weight)]], c.cout, c.cin, 9, c.x16f_off, c.x16d_off, 0, 0]
         object.__setattr__(self, "_x16desc", torch.tensor(xdesc, dtype=torch.int32).to(dev) if xdesc else None)
         object.__setattr__(self, "_flag", torch.zeros(1, dtype=torch.int32, device=dev))
+        ops._tickets(0, dev)          # the ticket ring of the self-folding data gradients: created outside any stream capture
         # position in this network's Philox stream.  It lives in device memory (advanced by a one-thread launch after each
         # draw) so that nothing that changes from step to step is passed to a kernel by value: a captured step (hipGraph)
         # then draws fresh noise on every replay, and eager and captured runs see the same stream.
@@ -486,15 +487,18 @@ class PreBN:
     already masked with that layer's ReLU (`g`), with the two reductions of the BatchNorm backward as per-workgroup partials
     (`stats`): convbn_bwd / upbn_bwd finish the BatchNorm backward with one elementwise pass (ops.bn_bwd_from_stats) instead
     of reduce + apply (5 -> 3 HBM passes over the layer's map)."""
-    __slots__ = ("g", "stats")
+    __slots__ = ("g", "stats", "coef")
 
-    def __init__(self, g, stats):
-        self.g, self.stats = g, stats
+    def __init__(self, g, stats, coef=None):
+        self.g, self.stats, self.coef = g, stats, coef      # coef: the launch also folded the partials (BN_TAIL)
 
 
 # BatchNorm-backward reductions in the epilogue of the producing data gradient (csrc/conv_x3.hip, conv.hip: EPI 2).
 # WTPSE_BN_FUSED_STATS=0: the stand-alone reduce pass everywhere.
 BN_FUSED_STATS = os.environ.get("WTPSE_BN_FUSED_STATS", "1") != "0"
+# ... and the fold of those partials into the BatchNorm-backward coefficients by the same launch's last workgroups
+# (csrc/common.h: bnb_tail).  WTPSE_BN_TAIL=0: the stand-alone fold (bn_bwd_finalize_k) in front of the apply pass.
+BN_TAIL = os.environ.get("WTPSE_BN_TAIL", "1") != "0"
 
 
 def _dgrad(layer, dy, split=None, mask_ref=None, below0=None, below1=None):
@@ -505,17 +509,19 @@ def _dgrad(layer, dy, split=None, mask_ref=None, below0=None, below1=None):
     below = below0 if below0 is not None else below1
     if (BN_FUSED_STATS and below is not None and mask_ref is None and below.mean is not None
             and not (root._dp is not None and root._dp.bn_sync) and (below1 is None or split is not None)):
+        bn = below.bn
+        tail = (bn.weight, below.invstd, root.gview(bn.weight), root.gview(bn.bias)) if BN_TAIL else None
         if layer.x16d_off >= 0 and split is None:
-            d0, stats, _ = ops.conv16_x3(dy, root.x3_ptr(layer.x16d_off), None, layer.cin,
-                                         bnb=(below.y, below.ss, below.mean, below.relu))
-            return PreBN(d0, stats), None
-        x3 = layer.xd_off >= 0
-        wptr = root.x3_ptr(layer.xd_off) if x3 else root.packed_ptr(layer.wd_off)
-        d0, d1, stats = ops.dgrad_bnb(dy, wptr, x3, layer.cin, layer.k, below.y, below.ss, below.mean, below.relu, split,
-                                      below1 is not None and below0 is None)
+            layout, wptr = 2, root.x3_ptr(layer.x16d_off)
+        elif layer.xd_off >= 0:
+            layout, wptr = 1, root.x3_ptr(layer.xd_off)
+        else:
+            layout, wptr = 0, root.packed_ptr(layer.wd_off)
+        d0, d1, stats, coef = ops.dgrad_bnb(dy, wptr, layout, layer.cin, layer.k, below.y, below.ss, below.mean, below.relu, split,
+                                            below1 is not None and below0 is None, tail)
         if below0 is not None:
-            return PreBN(d0, stats), d1
-        return d0, PreBN(d1, stats)
+            return PreBN(d0, stats, coef), d1
+        return d0, PreBN(d1, stats, coef)
     if layer.x16d_off >= 0 and split is None:
         return ops.conv16_x3(dy, root.x3_ptr(layer.x16d_off), None, layer.cin, mask_ref=mask_ref)[0], None
     if layer.xd_off >= 0:
@@ -587,6 +593,10 @@ def _wgrad_side(layer, dy, a0, a1=None):
     for t in (dy, a0.t, a0.pro) + ((as_act(a1).t, as_act(a1).pro) if a1 is not None else ()):
         if t is not None:
             t.record_stream(side)       # the caching allocator must not hand these out again before the side stream is done
+    # (Under stream capture the allocator keeps record_stream'ed blocks out of circulation until the capture ends.  Holding the
+    # tensors instead until the main stream has waited for the weight gradient that reads them — lagged by 2-3 layers, marks in
+    # the launch plan — was built and measured in round 3: plan 577 / 571 images/s against 588 with record_stream, eager
+    # unchanged; it is not where the replayed step loses its 1 % against the eager one.)
     note_join(root, side)
 
 
@@ -636,12 +646,15 @@ def convbn_fwd(conv, bn, a0, a1, relu, training, want_tape=True):
         return z, None
     t = Tape()
     t.a0, t.a1, t.y, t.ss, t.mean, t.invstd, t.relu = a0, a1, y, ss, mean, invstd, relu
+    t.bn = bn
     return z, t
 
 
 def _bn_bwd(bn, t, dz, root):
     """BatchNorm (+ReLU) backward of a convbn / upbn tape: dz = gradient wrt the activated output, plain or PreBN."""
     if isinstance(dz, PreBN):
+        if dz.coef is not None:
+            return ops.bn_bwd_apply_coef(dz.g, t.y, dz.coef)
         return ops.bn_bwd_from_stats(dz.g, t.y, dz.stats, bn.weight, t.mean, t.invstd, root.gview(bn.weight), root.gview(bn.bias))
     if root._dp is not None and root._dp.bn_sync:
         return root._dp.bn_bwd_synced(dz, t, bn, root)
@@ -720,6 +733,7 @@ def upbn_fwd(conv, bn, a0, training, want_tape=True):
         return out, None
     t = Tape()
     t.a0, t.a1, t.y, t.ss, t.mean, t.invstd, t.relu = a0, None, y, ss, mean, invstd, True
+    t.bn = bn
     return out, t
 
 

@@ -135,12 +135,38 @@ def conv_fwd_x3(in0, in1, wpacked_ptr, bias, cout, ksize, pro0=None, pro_relu=0,
     return out0, out1, stats
 
 
-def dgrad_bnb(dy, wpacked_ptr, x3, cout, ksize, bn_y, bn_ss, bn_mean, bn_relu, split=None, bn_second=False):
-    """Data gradient (`wpacked_ptr`: the layer's data-gradient weights, x3 layout if `x3`) whose epilogue masks the result with
-    the ReLU of the conv + BatchNorm layer it flows into and forms that layer's BatchNorm-backward reductions
-    (include/wtpse_hip.h, wtpse_dgrad_bnb).  With a split the BatchNorm'd tensor is out0, or out1 if `bn_second`.
-    -> (out0, out1 or None, stats [nblk, Cbn, 2])."""
+_TICKETS = {}
+_TICKET_RING = 1 << 21      # unsigneds: ~900 launches of the largest layer before a slice comes round again
+
+
+def _tickets(n, device):
+    """n zeroed unsigneds for a launch that leaves them zeroed (include/wtpse_hip.h: wtpse_dgrad_bnb_coef).  Slices of one ring per
+    device: a slice is handed out again only after ~900 further launches, long after its launch has finished; launches recorded in
+    a launch plan keep theirs."""
+    st = _TICKETS.get(device)
+    if st is None:
+        if torch.cuda.is_current_stream_capturing():
+            # the zero fill would be captured instead of executed (and the ring would live in the capture's private pool)
+            raise RuntimeError("the ticket ring must exist before a step is captured: HipNet.ensure_ready() creates it")
+        st = _TICKETS[device] = [torch.zeros(_TICKET_RING, dtype=torch.int32, device=device), 0]
+        torch.cuda.current_stream(device).synchronize()
+    n = (n + 63) & ~63
+    if st[1] + n > _TICKET_RING:
+        st[1] = 0
+    off = st[1]
+    st[1] += n
+    return st[0].data_ptr() + 4 * off
+
+
+def dgrad_bnb(dy, wpacked_ptr, layout, cout, ksize, bn_y, bn_ss, bn_mean, bn_relu, split=None, bn_second=False, tail=None):
+    """Data gradient (`wpacked_ptr`: the layer's data-gradient weights; layout 0 fp32, 1 x3, 2 the 16-channel x3 fragments) whose
+    epilogue masks the result with the ReLU of the conv + BatchNorm layer it flows into and forms that layer's BatchNorm-backward
+    reductions (include/wtpse_hip.h, wtpse_dgrad_bnb).  With a split the BatchNorm'd tensor is out0, or out1 if `bn_second`.
+    tail = (gamma, invstd, dgamma, dbeta) of that BatchNorm: the launch also folds the partials and leaves the coefficients
+    (wtpse_dgrad_bnb_coef).
+    -> (out0, out1 or None, stats [nblk, Cbn, 2], coef [Cbn, 3] or None)."""
     _chk(dy, "dy"); _chk(bn_y, "bn_y"); _chk(bn_ss, "bn_ss"); _chk(bn_mean, "bn_mean")
+    layout = int(layout)
     B, C, H, W = dy.shape
     L = lib()
     if split is None:
@@ -153,11 +179,24 @@ def dgrad_bnb(dy, wpacked_ptr, x3, cout, ksize, bn_y, bn_ss, bn_mean, bn_relu, s
         out0 = torch.empty((B, csplit, H, W), dtype=torch.float32, device=dy.device)
         out1 = torch.empty((B, cout - csplit, H, W), dtype=torch.float32, device=dy.device)
     assert bn_y.shape == (B, c1 - c0, H, W), (bn_y.shape, (B, c1 - c0, H, W))
-    nblk = L.query("wtpse_conv_x3_stats_blocks", B, H, W, cout) if x3 else L.query("wtpse_conv_stats_blocks", B, H, W)
+    nblk = L.query("wtpse_conv_x3_stats_blocks", B, H, W, cout) if layout == 1 else L.query("wtpse_conv_stats_blocks", B, H, W)
     stats = torch.empty((nblk, c1 - c0, 2), dtype=torch.float32, device=dy.device)
-    L.call("wtpse_dgrad_x3_bnb" if x3 else "wtpse_dgrad_bnb", ptr(dy), C, wpacked_ptr, ptr(out0), ptr(out1), csplit, ptr(bn_y),
-           ptr(bn_ss), ptr(bn_mean), int(bool(bn_relu)), c0, c1, ptr(stats), B, H, W, cout, ksize, stream_ptr())
-    return out0, out1, stats
+    if tail is not None:
+        gamma, invstd, dgamma, dbeta = tail
+        coef = torch.empty((c1 - c0, 3), dtype=torch.float32, device=dy.device)
+        partial2 = torch.empty(L.query("wtpse_bnb_tail_partial2", nblk, cout), dtype=torch.float64, device=dy.device)
+        tickets = _tickets(L.query("wtpse_bnb_tail_tickets", nblk, cout), dy.device)
+        L.call("wtpse_dgrad_bnb_coef", ptr(dy), C, wpacked_ptr, layout, ptr(out0), ptr(out1), csplit, ptr(bn_y), ptr(bn_ss),
+               ptr(bn_mean), int(bool(bn_relu)), c0, c1, ptr(stats), ptr(gamma), ptr(invstd), ptr(coef), ptr(dgamma), ptr(dbeta), 0,
+               ptr(partial2), tickets, B, H, W, cout, ksize, stream_ptr())
+        return out0, out1, stats, coef
+    if layout == 2:
+        L.call("wtpse_conv16_x3", ptr(dy), C, wpacked_ptr, 0, 0, 0, ptr(out0), ptr(stats), 0, ptr(bn_y), ptr(bn_ss), ptr(bn_mean),
+               int(bool(bn_relu)), B, H, W, cout, 0, stream_ptr())
+    else:
+        L.call("wtpse_dgrad_x3_bnb" if layout == 1 else "wtpse_dgrad_bnb", ptr(dy), C, wpacked_ptr, ptr(out0), ptr(out1), csplit,
+               ptr(bn_y), ptr(bn_ss), ptr(bn_mean), int(bool(bn_relu)), c0, c1, ptr(stats), B, H, W, cout, ksize, stream_ptr())
+    return out0, out1, stats, None
 
 
 def conv_wgrad(dy, x0, x1, ksize, dw, dbias, pro0=None, pro_relu=0, accumulate=False, pro1=None):
@@ -281,6 +320,15 @@ def bn_bwd_from_stats(g, y, stats, gamma, mean, invstd, dgamma, dbeta, accumulat
 # ----------------------------------------------------------------------------------------------- WT loss
 class WtLossState:
     __slots__ = ("z", "gram", "offdiag", "diag", "dmmd_dv", "losses", "v", "B", "HW", "D", "n", "margin")
+
+
+def bn_bwd_apply_coef(g, y, coef):
+    """dy = k1 g + k2 y + k3 with the coefficients a dgrad_bnb(..., tail=) launch left."""
+    _chk(g, "g"); _chk(y, "y")
+    B, C, H, W = y.shape
+    dy = torch.empty_like(y)
+    lib().call("wtpse_bn_bwd_apply_coef", ptr(g), ptr(y), ptr(coef), ptr(dy), B, C, H * W, stream_ptr())
+    return dy
 
 
 def wt_loss_fwd(z, domain_num, per_domain, margin=0.0, eps=1e-5, losses_out=None, gram_partial=None):

@@ -170,6 +170,11 @@ class TrainStep:
                         net = next(gen)
                     except StopIteration as stop:
                         res, done = stop.value, True
+                    except BaseException:
+                        # leaving a broken capture can crash the runtime before Python reports anything: say why first
+                        import traceback
+                        traceback.print_exc()
+                        raise
             finally:
                 if self.plan:
                     plan = L.plan_end()
