@@ -89,6 +89,17 @@ int wtpse_dgrad_x3_bnb(const float* dy, int C, const unsigned short* wpacked, fl
                        const float* bn_y, const float* bn_ss, const float* bn_mean, int bn_relu, int bn_c0, int bn_c1, float* stats,
                        int B, int H, int W, int Cout, int ksize, void* stream);
 
+/* A forward convolution in front of a train-mode BatchNorm (algorithms.py:883-889: conv -> bn) whose launch forms the
+ * (sum, sum^2) partials of its output in `stats` AND finishes them — wtpse_bn_finalize's work, done by the workgroups that arrive
+ * last (two levels of tickets, fixed fold order: bitwise reproducible; see wtpse_dgrad_bnb_coef below for partial2 / tickets,
+ * sized with the same two queries).  layout: 0 = wtpse_conv_fwd (fp32 `wf`), 1 = wtpse_conv_fwd_x3, 2 = wtpse_conv16_x3's
+ * fragments (one input).  No split, mask or ReLU output: the BatchNorm follows. */
+int wtpse_conv_fwd_bnf(const float* in0, int C0, const float* in1, int C1, const void* wpacked, int layout, const float* bias,
+                       const float* pro0, const float* pro1, int pro_relu, float* out0, float* stats, const float* gamma,
+                       const float* beta, float* running_mean, float* running_var, long long* num_batches, float momentum, float eps,
+                       float* scale_shift, float* save_mean, float* save_invstd, double* partial2, unsigned* tickets, int B, int H,
+                       int W, int Cout, int ksize, void* stream);
+
 /* The same launches, which then ALSO finish the statistics: groups of 64 workgroups fold their partials as their last member
  * arrives, the last group of an output-channel block folds the group sums (fixed order: bitwise reproducible, nobody waits) and
  * writes coef [Cbn][3] = (k1, k2, k3) and dgamma / dbeta (+)= (accumulate) of the BatchNorm'd channels — what

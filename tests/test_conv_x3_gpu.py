@@ -398,3 +398,62 @@ def test_conv16_x3_bnb(case):
     close(dy, dy2, rtol=1e-4, atol=2e-5 * sc, what="fused vs stand-alone dy")
     close(dg, dg2, rtol=1e-4, atol=1e-4 * float(dg2.abs().max()) + 1e-6, what="dgamma")
     close(dbt, dbt2, rtol=1e-4, atol=1e-4 * float(dbt2.abs().max()) + 1e-6, what="dbeta")
+
+
+@pytest.mark.parametrize("case", [
+    # layout, B, C0, C1, Cout, H, W, k
+    (1, 20, 32, 32, 64, 32, 64, 3),     # x3, 64-channel row blocks, 160 tiles -> 3 ticket groups
+    (1, 2, 16, 0, 32, 16, 16, 3),       # x3, one group
+    (1, 3, 64, 0, 96, 8, 16, 1),        # x3 1x1, three 32-channel blocks
+    (0, 3, 3, 0, 16, 24, 40, 3),        # fp32 16-channel path
+    (0, 4, 8, 0, 40, 16, 32, 1),        # fp32 ragged channels
+    (2, 20, 16, 0, 16, 64, 64, 3),      # 16-channel x3 fragments, 320 tiles -> 5 groups
+])
+def test_conv_fwd_bnf(case):
+    """A convolution that finishes its own BatchNorm statistics (last-arriver tickets) against conv + wtpse_bn_finalize: same output
+    bit for bit, same scale/shift, mean, invstd and running statistics up to the order of the fp64 sums; repeatable; tickets
+    back at zero."""
+    o = ops()
+    layout, B, C0, C1, Co, H, W, k = case
+    x0 = rnd(B, C0, H, W, seed=61).to(DEV)
+    x1 = rnd(B, C1, H, W, seed=62).to(DEV) if C1 else None
+    w = rnd(Co, C0 + C1, k, k, seed=63, scale=0.2)
+    bias = rnd(Co, seed=64).to(DEV)
+    pro0 = torch.stack([rnd(C0, seed=65) * 0.5 + 1.0, rnd(C0, seed=66)], 1).contiguous().to(DEV)
+    pro1 = torch.stack([rnd(C1, seed=67) * 0.5 + 1.0, rnd(C1, seed=68)], 1).contiguous().to(DEV) if C1 else None
+    gamma, beta = (rnd(Co, seed=69) * 0.2 + 1).to(DEV), (rnd(Co, seed=70) * 0.2).to(DEV)
+    if layout == 1:
+        packed, xf, _ = pack_x3(w)
+        wptr = packed.data_ptr() + 2 * xf
+        y_ref, _, stats = o.conv_fwd_x3(x0, x1, wptr, bias, Co, k, pro0, 3, want_stats=True, pro1=pro1)
+    elif layout == 2:
+        packed, xf, _ = pack_x16(w)
+        wptr = packed.data_ptr() + 2 * xf
+        y_ref, stats, _ = o.conv16_x3(x0, wptr, bias, Co, pro0, 1, want_stats=True)
+    else:
+        packed, wf, _ = pack(w)
+        wptr = packed.data_ptr() + 4 * wf
+        y_ref, _, stats = o.conv_fwd(x0, x1, wptr, bias, Co, k, pro0, 3, want_stats=True, pro1=pro1)
+    rm0, rv0 = rnd(Co, seed=71).to(DEV), (rnd(Co, seed=72).abs() + 0.5).to(DEV)
+    rm, rv, nbt = rm0.clone(), rv0.clone(), torch.zeros(1, dtype=torch.int64, device=DEV)
+    ss_ref, mean_ref, invstd_ref = o.bn_finalize(stats, B * H * W, gamma, beta, rm, rv, nbt)
+    got = None
+    for it in range(20):
+        rm2, rv2, nbt2 = rm0.clone(), rv0.clone(), torch.zeros(1, dtype=torch.int64, device=DEV)
+        y, ss, mean, invstd = o.conv_fwd_bnf(x0, x1, wptr, layout, bias, Co, k, pro0, 3 if layout != 2 else 1, pro1, gamma, beta,
+                                             rm2, rv2, nbt2)
+        cur = (y, ss, mean, invstd, rm2, rv2)
+        if got is None:
+            got = tuple(t.clone() for t in cur)
+            assert torch.equal(y, y_ref)
+            close(ss, ss_ref, rtol=2e-6, atol=2e-6, what="scale/shift")
+            close(mean, mean_ref, rtol=2e-6, atol=1e-7, what="mean")
+            close(invstd, invstd_ref, rtol=2e-6, atol=1e-7, what="invstd")
+            close(rm2, rm, rtol=2e-6, atol=1e-7, what="running mean")
+            close(rv2, rv, rtol=2e-6, atol=1e-7, what="running var")
+            assert int(nbt2) == 1
+        else:
+            for a, b in zip(cur, got):
+                assert torch.equal(a, b), "launch %d differs" % it
+    torch.cuda.synchronize()
+    assert all(int(t[0].abs().sum()) == 0 for t in o._TICKETS.values()), "tickets must be left at zero"

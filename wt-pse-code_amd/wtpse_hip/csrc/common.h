@@ -116,68 +116,81 @@ __device__ __forceinline__ double pub_load(const double* p) {
 }
 __device__ __forceinline__ void pub_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-// The caller has written this workgroup's partials with pub_store().
+// The two-level fold.  The caller has written this workgroup's partials stats[tile][Cst][2] (channels [c_lo, c_hi) of the
+// launch's output, Cst = c_hi - c_lo) with pub_store().  -> true in the ONE workgroup of output-channel block `y` that arrives
+// last; there sh[2 * crel + k] holds the fp64 totals of the block's channels (threads tid < 2 CB: crel = tid >> 1, k = tid & 1).
 template <int CB>
-__device__ __forceinline__ void bnb_tail(const BnbTail& tl, const float* stats, const float* __restrict__ bn_mean,
-                                         int bn_c0, int bn_c1, int cout0, int tile, int y, int tid, double* sh, int* flag_s) {
+__device__ __forceinline__ bool tail_fold(double* partial2, unsigned* tickets, int ngroups, int ntiles, int ctot, int t2_off,
+                                          const float* stats, int c_lo, int c_hi, int cout0, int tile, int y, int tid, double* sh,
+                                          int* flag_s) {
   static_assert(CB * 2 <= 256, "one thread per (channel, sum)");
-  if (tl.tickets == nullptr) return;
-  if (cout0 >= bn_c1 || cout0 + CB <= bn_c0) return;          // no BatchNorm'd channel in this block (uniform)
-  const int Cbn = bn_c1 - bn_c0;
+  const int Cst = c_hi - c_lo;
   pub_drain();
   __syncthreads();
   const int grp = tile >> 6, g0 = grp << 6;
-  const int gsize = min(64, tl.ntiles - g0);
+  const int gsize = min(64, ntiles - g0);
   if (tid == 0) {
-    const unsigned old = __hip_atomic_fetch_add(tl.tickets + (size_t)y * tl.ngroups + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned old = __hip_atomic_fetch_add(tickets + (size_t)y * ngroups + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     *flag_s = old == (unsigned)(gsize - 1);
   }
   __syncthreads();
-  if (!*flag_s) return;
+  if (!*flag_s) return false;
   const int crel = tid >> 1, k = tid & 1, c = cout0 + crel;
-  const bool mine = tid < CB * 2 && c >= bn_c0 && c < bn_c1;
+  const bool mine = tid < CB * 2 && c >= c_lo && c < c_hi;
   {
     double s = 0.0;
     if (mine) {
-      const float* p = stats + ((size_t)g0 * Cbn + (c - bn_c0)) * 2 + k;
+      const float* p = stats + ((size_t)g0 * Cst + (c - c_lo)) * 2 + k;
       int i = 0;
       for (; i + 8 <= gsize; i += 8) {
         float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = pub_load(p + (size_t)(i + u) * Cbn * 2);
+        for (int u = 0; u < 8; ++u) v[u] = pub_load(p + (size_t)(i + u) * Cst * 2);
 #pragma unroll
         for (int u = 0; u < 8; ++u) s += (double)v[u];
       }
-      for (; i < gsize; ++i) s += (double)pub_load(p + (size_t)i * Cbn * 2);
-      pub_store(tl.partial2 + ((size_t)grp * tl.ctot + c) * 2 + k, s);
+      for (; i < gsize; ++i) s += (double)pub_load(p + (size_t)i * Cst * 2);
+      pub_store(partial2 + ((size_t)grp * ctot + c) * 2 + k, s);
     }
-    if (tid == 0) __hip_atomic_store(tl.tickets + (size_t)y * tl.ngroups + grp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_store(tickets + (size_t)y * ngroups + grp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   pub_drain();
   __syncthreads();
   if (tid == 0) {
-    const unsigned old = __hip_atomic_fetch_add(tl.tickets + tl.t2_off + y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    *flag_s = old == (unsigned)(tl.ngroups - 1);
+    const unsigned old = __hip_atomic_fetch_add(tickets + t2_off + y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *flag_s = old == (unsigned)(ngroups - 1);
   }
   __syncthreads();
-  if (!*flag_s) return;
+  if (!*flag_s) return false;
   double s = 0.0;
   if (mine) {
-    const double* p = tl.partial2 + (size_t)c * 2 + k;
+    const double* p = partial2 + (size_t)c * 2 + k;
     int i = 0;
-    for (; i + 8 <= tl.ngroups; i += 8) {
+    for (; i + 8 <= ngroups; i += 8) {
       double v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = pub_load(p + (size_t)(i + u) * tl.ctot * 2);
+      for (int u = 0; u < 8; ++u) v[u] = pub_load(p + (size_t)(i + u) * ctot * 2);
 #pragma unroll
       for (int u = 0; u < 8; ++u) s += v[u];
     }
-    for (; i < tl.ngroups; ++i) s += pub_load(p + (size_t)i * tl.ctot * 2);
+    for (; i < ngroups; ++i) s += pub_load(p + (size_t)i * ctot * 2);
   }
   if (tid < CB * 2) sh[tid] = s;
-  if (tid == 0) __hip_atomic_store(tl.tickets + tl.t2_off + y, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0) __hip_atomic_store(tickets + t2_off + y, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
-  if (mine && k == 0) {
+  return true;
+}
+
+template <int CB>
+__device__ __forceinline__ void bnb_tail(const BnbTail& tl, const float* stats, const float* __restrict__ bn_mean,
+                                         int bn_c0, int bn_c1, int cout0, int tile, int y, int tid, double* sh, int* flag_s) {
+  if (tl.tickets == nullptr) return;
+  if (cout0 >= bn_c1 || cout0 + CB <= bn_c0) return;          // no BatchNorm'd channel in this block (uniform)
+  if (!tail_fold<CB>(tl.partial2, tl.tickets, tl.ngroups, tl.ntiles, tl.ctot, tl.t2_off, stats, bn_c0, bn_c1, cout0, tile, y, tid,
+                     sh, flag_s))
+    return;
+  const int c = cout0 + (tid >> 1);
+  if (tid < CB * 2 && (tid & 1) == 0 && c >= bn_c0 && c < bn_c1) {
     const int cb = c - bn_c0;
     const double is = (double)tl.invstd[cb], ga = (double)tl.gamma[cb];
     const double s1 = sh[tid], s2 = sh[tid + 1] * is;          // the partials hold sum g (y - mean): not yet / std
@@ -189,6 +202,51 @@ __device__ __forceinline__ void bnb_tail(const BnbTail& tl, const float* stats, 
     tl.coef[3 * cb] = (float)k1;
     tl.coef[3 * cb + 1] = (float)k2;
     tl.coef[3 * cb + 2] = (float)k3;
+  }
+}
+
+// ---- the same for the FORWARD statistics: the convolution that forms the BatchNorm (sum, sum^2) partials of its output
+// (stats[tile][Cout][2]) also finishes them — scale/shift, saved mean / invstd, running statistics: what bn_finalize_k does
+// (reference: nn.BatchNorm2d in train mode, algorithms.py:883-889) — 198 dependent launches of ~6 us per step otherwise.
+struct BnfTail {
+  double* partial2;        // [ngroups][ctot][2]
+  unsigned* tickets;       // null: no tail
+  const float* gamma;
+  const float* beta;
+  float* rmean;            // running statistics, or null
+  float* rvar;
+  long long* nbt;          // num_batches_tracked, or null
+  float* scale_shift;      // [Cout][2]
+  float* save_mean;
+  float* save_invstd;
+  double count;
+  float momentum, eps;
+  int ngroups, ntiles, ctot, t2_off;
+};
+
+template <int CB>
+__device__ __forceinline__ void bnf_tail(const BnfTail& tl, const float* stats, int Cout, int cout0, int tile, int y, int tid,
+                                         double* sh, int* flag_s) {
+  if (tl.tickets == nullptr) return;
+  if (!tail_fold<CB>(tl.partial2, tl.tickets, tl.ngroups, tl.ntiles, tl.ctot, tl.t2_off, stats, 0, Cout, cout0, tile, y, tid, sh,
+                     flag_s))
+    return;
+  const int c = cout0 + (tid >> 1);
+  if (tid < CB * 2 && (tid & 1) == 0 && c < Cout) {
+    const double mean = sh[tid] / tl.count;
+    double var = sh[tid + 1] / tl.count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double invstd = 1.0 / sqrt(var + (double)tl.eps);
+    tl.scale_shift[2 * c] = (float)(tl.gamma[c] * invstd);
+    tl.scale_shift[2 * c + 1] = (float)(tl.beta[c] - mean * tl.gamma[c] * invstd);
+    tl.save_mean[c] = (float)mean;
+    tl.save_invstd[c] = (float)invstd;
+    if (tl.rmean) {
+      const double unbiased = tl.count > 1.0 ? var * tl.count / (tl.count - 1.0) : var;
+      tl.rmean[c] = (float)((1.0 - tl.momentum) * tl.rmean[c] + tl.momentum * mean);
+      tl.rvar[c] = (float)((1.0 - tl.momentum) * tl.rvar[c] + tl.momentum * unbiased);
+    }
+    if (tl.nbt && c == 0) *tl.nbt += 1;
   }
 }
 
@@ -204,6 +262,17 @@ static inline BnbTail bnb_tail_none() {
   return t;
 }
 static inline void bnb_tail_geometry(BnbTail& t, int ntiles, int Cout, double count) {
+  t.ntiles = ntiles; t.ngroups = bnb_tail_groups(ntiles); t.ctot = bnb_tail_ctot(Cout); t.t2_off = bnb_tail_t2off(ntiles, Cout);
+  t.count = count;
+}
+static inline BnfTail bnf_tail_none() {
+  BnfTail t;
+  t.partial2 = nullptr; t.tickets = nullptr; t.gamma = nullptr; t.beta = nullptr; t.rmean = nullptr; t.rvar = nullptr; t.nbt = nullptr;
+  t.scale_shift = nullptr; t.save_mean = nullptr; t.save_invstd = nullptr; t.count = 1.0; t.momentum = 0.f; t.eps = 0.f;
+  t.ngroups = 0; t.ntiles = 0; t.ctot = 0; t.t2_off = 0;
+  return t;
+}
+static inline void bnf_tail_geometry(BnfTail& t, int ntiles, int Cout, double count) {
   t.ntiles = ntiles; t.ngroups = bnb_tail_groups(ntiles); t.ctot = bnb_tail_ctot(Cout); t.t2_off = bnb_tail_t2off(ntiles, Cout);
   t.count = count;
 }

@@ -50,6 +50,7 @@ struct ConvArgs {
   const float* bn_mean;
   int bn_c0, bn_c1, bn_relu;
   BnbTail tail;        // EPI == 2: the BatchNorm-backward coefficients from the last workgroups (common.h), or tickets == null
+  BnfTail ftail;       // forward statistics: BatchNorm finalize by the last workgroups (common.h), or tickets == null
   int B, H, W;
   int C0, C1, Cin, CinP;
   int Cout, CoutP, Csplit;
@@ -567,12 +568,15 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
         const int c = cout0 + crel;
         if (c >= a.bn_c0 && c < a.bn_c1) pub_store(a.stats + ((size_t)blockIdx.x * Cbn + c - a.bn_c0) * 2 + (tid & 1), s);
       } else if (cout0 + crel < a.Cout) {
-        a.stats[((size_t)blockIdx.x * a.Cout + cout0 + crel) * 2 + (tid & 1)] = s;
+        pub_store(a.stats + ((size_t)blockIdx.x * a.Cout + cout0 + crel) * 2 + (tid & 1), s);
       }
     }
     if constexpr (BNB)
       bnb_tail<CB>(a.tail, a.stats, a.bn_mean, a.bn_c0, a.bn_c1, cout0, (int)blockIdx.x, (int)blockIdx.y, tid,
                    reinterpret_cast<double*>(red), reinterpret_cast<int*>(red + 4 * CB));
+    else
+      bnf_tail<CB>(a.ftail, a.stats, a.Cout, cout0, (int)blockIdx.x, (int)blockIdx.y, tid, reinterpret_cast<double*>(red),
+                   reinterpret_cast<int*>(red + 4 * CB));
   }
   STAMP(61);
 }
@@ -587,6 +591,7 @@ static int launch_fwd(const ConvArgs& a, hipStream_t st) {
   args.tiles_y = ceil_div(a.H, TH);
   dim3 grid((unsigned)(a.B * args.tiles_x * args.tiles_y), (unsigned)ceil_div(a.CoutP, CB));
   if (args.tail.tickets) bnb_tail_geometry(args.tail, (int)grid.x, a.Cout, (double)a.B * a.H * a.W);
+  if (args.ftail.tickets) bnf_tail_geometry(args.ftail, (int)grid.x, a.Cout, (double)a.B * a.H * a.W);
   if (narrow)
     hipLaunchKernelGGL((conv_fwd_k<KS, MODE, 4, DB, EPI>), grid, dim3(256), 0, st, args);
   else
@@ -613,7 +618,8 @@ struct BnbArgs {   // EPI 2 parameters of conv_fwd_impl (all null / 0: none)
 static int conv_fwd_impl(const float* in0, int C0, const float* in1, int C1, const float* wpacked, const float* bias,
                          const float* pro0, const float* pro1, int pro_relu, float* out0, float* out1, int Csplit, float* stats,
                          int B, int H, int W, int Cout, int ksize, int relu_out, const float* mask_ref, float* gram,
-                         void* stream, BnbArgs bn = BnbArgs{nullptr, nullptr, 0, 0, 0}, BnbTail tail = bnb_tail_none()) {
+                         void* stream, BnbArgs bn = BnbArgs{nullptr, nullptr, 0, 0, 0}, BnbTail tail = bnb_tail_none(),
+                         BnfTail ftail = bnf_tail_none()) {
   WTPSE_REQUIRE(in0 && wpacked && out0 && B > 0 && H > 0 && W > 0 && C0 > 0 && C1 >= 0 && Cout > 0);
   WTPSE_REQUIRE(ksize == 1 || ksize == 3);
   WTPSE_REQUIRE((C1 == 0) == (in1 == nullptr));
@@ -627,8 +633,11 @@ static int conv_fwd_impl(const float* in0, int C0, const float* in1, int C1, con
                          bn.c0 % 16 == 0 && (bn.c1 % 16 == 0 || bn.c1 == Cout)));
   WTPSE_REQUIRE(C1 == 0 || C0 % 16 == 0);   // a channel chunk must not straddle the two inputs
   WTPSE_REQUIRE(!tail.tickets || (bnb && tail.partial2 && tail.gamma && tail.invstd && tail.coef && tail.dgamma && tail.dbeta));
+  WTPSE_REQUIRE(!ftail.tickets || (!bnb && stats && !gram && ftail.partial2 && ftail.gamma && ftail.beta && ftail.scale_shift &&
+                                   ftail.save_mean && ftail.save_invstd && (ftail.rmean == nullptr) == (ftail.rvar == nullptr)));
   ConvArgs a;
   a.tail = tail;
+  a.ftail = ftail;
   a.bn_ss = bn.ss; a.bn_mean = bn.mean; a.bn_relu = bn.relu; a.bn_c0 = bnb ? bn.c0 : 0; a.bn_c1 = bnb ? bn.c1 : 0;
   a.in0 = in0; a.in1 = in1; a.wp = wpacked; a.bias = bias; a.pro0 = pro0; a.pro1 = pro1; a.out0 = out0; a.out1 = out1; a.stats = stats; a.mask = mask_ref; a.gram = gram;
   a.B = B; a.H = H; a.W = W; a.C0 = C0; a.C1 = C1; a.Cin = C0 + C1; a.CinP = (a.Cin + 3) & ~3;
@@ -682,7 +691,7 @@ extern "C" int wtpse_dgrad_bnb(const float* dy, int C, const float* wpacked, flo
 static int conv16_x3_impl(const float* in0, int C0, const unsigned short* wx16, const float* bias, const float* pro0,
                           int pro_relu, float* out0, float* stats, float* gram_partial, const float* mask_ref,
                           const float* bn_ss, const float* bn_mean, int bn_relu, int B, int H, int W, int Cout, int relu_out,
-                          void* stream, BnbTail tail = bnb_tail_none()) {
+                          void* stream, BnbTail tail = bnb_tail_none(), BnfTail ftail = bnf_tail_none()) {
   WTPSE_REQUIRE(in0 && wx16 && out0 && B > 0 && H > 0 && W > 0 && C0 > 0 && C0 <= 16 && Cout > 0 && Cout <= 16);
   WTPSE_REQUIRE(!(stats && relu_out) && !(gram_partial && (Cout != 16 || relu_out)));
   WTPSE_REQUIRE((((uintptr_t)wx16) & 15) == 0);
@@ -690,8 +699,11 @@ static int conv16_x3_impl(const float* in0, int C0, const unsigned short* wx16, 
   WTPSE_REQUIRE(bnb || !(stats && mask_ref));
   WTPSE_REQUIRE(!bnb || (mask_ref && stats && bn_ss && !bias && !relu_out && !gram_partial));
   WTPSE_REQUIRE(!tail.tickets || (bnb && tail.partial2 && tail.gamma && tail.invstd && tail.coef && tail.dgamma && tail.dbeta));
+  WTPSE_REQUIRE(!ftail.tickets || (!bnb && stats && !gram_partial && ftail.partial2 && ftail.gamma && ftail.beta && ftail.scale_shift &&
+                                   ftail.save_mean && ftail.save_invstd && (ftail.rmean == nullptr) == (ftail.rvar == nullptr)));
   ConvArgs a;
   a.tail = tail;
+  a.ftail = ftail;
   a.in0 = in0; a.in1 = nullptr; a.wp = reinterpret_cast<const float*>(wx16); a.bias = bias; a.pro0 = pro0; a.pro1 = nullptr;
   a.out0 = out0; a.out1 = nullptr; a.stats = stats; a.mask = mask_ref; a.gram = gram_partial;
   a.bn_ss = bn_ss; a.bn_mean = bn_mean; a.bn_relu = bn_relu; a.bn_c0 = 0; a.bn_c1 = bnb ? Cout : 0;
@@ -719,6 +731,36 @@ extern "C" int wtpse_dgrad_x3_bnb_tail(const float* dy, int C, const unsigned sh
                                        const float* bn_y, const float* bn_ss, const float* bn_mean, int bn_relu, int bn_c0,
                                        int bn_c1, float* stats, const BnbTail* tail, int B, int H, int W, int Cout, int ksize,
                                        void* stream);
+
+extern "C" int wtpse_conv_fwd_x3_ftail(const float* in0, int C0, const float* in1, int C1, const unsigned short* wpacked,
+                                       const float* bias, const float* pro0, const float* pro1, int pro_relu, float* out0,
+                                       float* stats, const BnfTail* ftail, int B, int H, int W, int Cout, int ksize, void* stream);
+
+// ---- a forward convolution in front of a train-mode BatchNorm whose launch ALSO finishes the statistics (common.h: bnf_tail):
+// wtpse_conv_fwd / wtpse_conv_fwd_x3 / wtpse_conv16_x3 with `stats` + wtpse_bn_finalize in one launch.  layout as below.
+extern "C" int wtpse_conv_fwd_bnf(const float* in0, int C0, const float* in1, int C1, const void* wpacked, int layout,
+                                  const float* bias, const float* pro0, const float* pro1, int pro_relu, float* out0, float* stats,
+                                  const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                  long long* num_batches, float momentum, float eps, float* scale_shift, float* save_mean,
+                                  float* save_invstd, double* partial2, unsigned* tickets, int B, int H, int W, int Cout, int ksize,
+                                  void* stream) {
+  WTPSE_REQUIRE(stats && gamma && beta && scale_shift && save_mean && save_invstd && partial2 && tickets);
+  WTPSE_REQUIRE(layout >= 0 && layout <= 2);
+  BnfTail t = bnf_tail_none();
+  t.partial2 = partial2; t.tickets = tickets; t.gamma = gamma; t.beta = beta; t.rmean = running_mean; t.rvar = running_var;
+  t.nbt = num_batches; t.momentum = momentum; t.eps = eps; t.scale_shift = scale_shift; t.save_mean = save_mean;
+  t.save_invstd = save_invstd;
+  if (layout == 1)
+    return wtpse_conv_fwd_x3_ftail(in0, C0, in1, C1, static_cast<const unsigned short*>(wpacked), bias, pro0, pro1, pro_relu, out0,
+                                   stats, &t, B, H, W, Cout, ksize, stream);
+  if (layout == 2) {
+    WTPSE_REQUIRE(ksize == 3 && !in1 && C1 == 0 && !pro1);
+    return conv16_x3_impl(in0, C0, static_cast<const unsigned short*>(wpacked), bias, pro0, pro_relu, out0, stats, nullptr, nullptr,
+                          nullptr, nullptr, 0, B, H, W, Cout, 0, stream, bnb_tail_none(), t);
+  }
+  return conv_fwd_impl(in0, C0, in1, C1, static_cast<const float*>(wpacked), bias, pro0, pro1, pro_relu, out0, nullptr, Cout, stats,
+                       B, H, W, Cout, ksize, 0, nullptr, nullptr, stream, BnbArgs{nullptr, nullptr, 0, 0, 0}, bnb_tail_none(), t);
+}
 
 extern "C" int wtpse_bnb_tail_partial2(int nblk, int Cout) { return bnb_tail_groups(nblk) * bnb_tail_ctot(Cout) * 2; }
 extern "C" int wtpse_bnb_tail_tickets(int nblk, int Cout) { return bnb_tail_t2off(nblk, Cout) + (Cout + 15) / 16; }

@@ -53,6 +53,7 @@ struct ConvX3Args {
   const float* bn_mean;       // [bn_c1 - bn_c0]
   int bn_c0, bn_c1, bn_relu;
   BnbTail tail;               // EPI == 2: the BatchNorm-backward coefficients from the last workgroups (common.h), or tickets == null
+  BnfTail ftail;              // forward statistics: BatchNorm finalize by the last workgroups (common.h), or tickets == null
   int B, H, W;
   int C0, C1, Cin, CinP;      // CinP: multiple of 16
   int Cout, CoutP, Csplit;    // CoutP: multiple of 32
@@ -261,12 +262,15 @@ __device__ __forceinline__ void x3_epilogue(const ConvX3Args& a, f32x16 (&acc)[M
         const int c = cout0 + crel;
         if (live && c >= a.bn_c0 && c < a.bn_c1) pub_store(a.stats + ((size_t)stats_row * Cbn + c - a.bn_c0) * 2 + (tid & 1), s);
       } else if (live && cout0 + crel < a.Cout) {
-        a.stats[((size_t)stats_row * a.Cout + cout0 + crel) * 2 + (tid & 1)] = s;
+        pub_store(a.stats + ((size_t)stats_row * a.Cout + cout0 + crel) * 2 + (tid & 1), s);
       }
     }
     if constexpr (BNB)
       bnb_tail<CB>(a.tail, a.stats, a.bn_mean, a.bn_c0, a.bn_c1, cout0, stats_row, (int)blockIdx.y, tid,
                    reinterpret_cast<double*>(red), reinterpret_cast<int*>(red + 4 * CB));
+    else
+      bnf_tail<CB>(a.ftail, a.stats, a.Cout, cout0, stats_row, (int)blockIdx.y, tid, reinterpret_cast<double*>(red),
+                   reinterpret_cast<int*>(red + 4 * CB));
   }
 }
 
@@ -620,6 +624,7 @@ static int launch_x3(const ConvX3Args& a, hipStream_t st) {
   args.tiles_y = ceil_div(a.H, TH);
   dim3 grid((unsigned)(a.B * args.tiles_x * args.tiles_y), (unsigned)ceil_div(a.CoutP, 32 * MT));
   if (args.tail.tickets) bnb_tail_geometry(args.tail, (int)grid.x, a.Cout, (double)a.B * a.H * a.W);
+  if (args.ftail.tickets) bnf_tail_geometry(args.ftail, (int)grid.x, a.Cout, (double)a.B * a.H * a.W);
   if (small) {
     if constexpr (MT == 1) hipLaunchKernelGGL((conv_x3_k<KS, 1, 4, EPI, 1>), grid, dim3(256), 0, st, args);
   } else if (narrow)
@@ -653,7 +658,7 @@ static int conv_x3_impl(const float* in0, int C0, const float* in1, int C1, cons
                         const float* bias, const float* pro0, const float* pro1, int pro_relu, float* out0, float* out1,
                         int Csplit, float* stats, int B, int H, int W, int Cout, int ksize, int relu_out,
                         const float* mask_ref, const float* bn_ss, const float* bn_mean, int bn_relu, int bn_c0, int bn_c1,
-                        void* stream, BnbTail tail = bnb_tail_none()) {
+                        void* stream, BnbTail tail = bnb_tail_none(), BnfTail ftail = bnf_tail_none()) {
   WTPSE_REQUIRE(in0 && wpacked && out0 && B > 0 && H > 0 && W > 0 && C0 > 0 && C1 >= 0 && Cout > 0);
   WTPSE_REQUIRE(ksize == 1 || ksize == 3);
   WTPSE_REQUIRE((C1 == 0) == (in1 == nullptr));
@@ -673,6 +678,9 @@ static int conv_x3_impl(const float* in0, int C0, const float* in1, int C1, cons
   a.bn_ss = bn_ss; a.bn_mean = bn_mean; a.bn_relu = bn_relu; a.bn_c0 = bnb ? bn_c0 : 0; a.bn_c1 = bnb ? bn_c1 : 0;
   WTPSE_REQUIRE(!tail.tickets || (bnb && tail.partial2 && tail.gamma && tail.invstd && tail.coef && tail.dgamma && tail.dbeta));
   a.tail = tail;
+  WTPSE_REQUIRE(!ftail.tickets || (!bnb && stats && ftail.partial2 && ftail.gamma && ftail.beta && ftail.scale_shift && ftail.save_mean &&
+                                   ftail.save_invstd && (ftail.rmean == nullptr) == (ftail.rvar == nullptr)));
+  a.ftail = ftail;
   a.B = B; a.H = H; a.W = W; a.C0 = C0; a.C1 = C1; a.Cin = C0 + C1; a.CinP = (a.Cin + 15) & ~15;
   a.Cout = Cout; a.CoutP = (Cout + 31) & ~31; a.Csplit = Csplit; a.pro_relu = pro_relu; a.relu_out = relu_out;
   a.tiles_x = a.tiles_y = 0;
@@ -702,6 +710,15 @@ extern "C" int wtpse_dgrad_x3_bnb(const float* dy, int C, const unsigned short* 
   WTPSE_REQUIRE(bn_y && bn_ss && bn_mean && stats);
   return conv_x3_impl(dy, C, nullptr, 0, wpacked, nullptr, nullptr, nullptr, 0, out0, out1, Csplit, stats, B, H, W, Cout, ksize, 0,
                       bn_y, bn_ss, bn_mean, bn_relu, bn_c0, bn_c1, stream);
+}
+
+// wtpse_conv_fwd_bnf (conv.hip), x3 layout
+extern "C" int wtpse_conv_fwd_x3_ftail(const float* in0, int C0, const float* in1, int C1, const unsigned short* wpacked,
+                                       const float* bias, const float* pro0, const float* pro1, int pro_relu, float* out0,
+                                       float* stats, const BnfTail* ftail, int B, int H, int W, int Cout, int ksize, void* stream) {
+  WTPSE_REQUIRE(ftail && stats);
+  return conv_x3_impl(in0, C0, in1, C1, wpacked, bias, pro0, pro1, pro_relu, out0, nullptr, Cout, stats, B, H, W, Cout, ksize, 0,
+                      nullptr, nullptr, nullptr, 0, 0, 0, stream, bnb_tail_none(), *ftail);
 }
 
 // wtpse_dgrad_bnb_coef (conv.hip), x3 layout

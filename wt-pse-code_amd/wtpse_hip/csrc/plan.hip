@@ -26,7 +26,7 @@ struct Cmd {
   void* stream;
   void* other;
   hipEvent_t ev;
-  PlanArg args[32];
+  PlanArg args[40];
 };
 struct Plan {
   std::vector<Cmd> cmds;
@@ -51,7 +51,7 @@ extern "C" int wtpse_plan_size(void* plan) { return plan ? (int)static_cast<Plan
 
 extern "C" int wtpse_plan_add_call(void* plan, int fn, const void* args, int nargs, void* stream) {
   Plan* p = static_cast<Plan*>(plan);
-  WTPSE_REQUIRE(p && fn >= 0 && fn < PLAN_NFN && nargs >= 0 && nargs <= 32 && (args || nargs == 0));
+  WTPSE_REQUIRE(p && fn >= 0 && fn < PLAN_NFN && nargs >= 0 && nargs <= 40 && (args || nargs == 0));
   Cmd c;
   c.fn = fn; c.nargs = nargs; c.stream = stream; c.other = nullptr; c.ev = nullptr;
   const PlanArg* a = static_cast<const PlanArg*>(args);

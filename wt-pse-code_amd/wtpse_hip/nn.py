@@ -628,7 +628,18 @@ def convbn_fwd(conv, bn, a0, a1, relu, training, want_tape=True):
     root = conv._root
     a0 = as_act(a0)
     a1 = as_act(a1) if a1 is not None else None
-    if training:
+    if training and BN_TAIL and not (root._dp is not None and root._dp.bn_sync):
+        # the convolution finishes its own statistics (csrc/common.h: bnf_tail): no finalize launch
+        if conv.x16f_off >= 0 and a1 is None:
+            layout, wptr = 2, root.x3_ptr(conv.x16f_off)
+        elif conv.xf_off >= 0:
+            layout, wptr = 1, root.x3_ptr(conv.xf_off)
+        else:
+            layout, wptr = 0, root.packed_ptr(conv.wf_off)
+        y, ss, mean, invstd = ops.conv_fwd_bnf(a0.t, a1.t if a1 is not None else None, wptr, layout, conv.bias, conv.cout, conv.k,
+                                               a0.pro, _relu_bits(a0, a1), a1.pro if a1 is not None else None, bn.weight, bn.bias,
+                                               bn.running_mean, bn.running_var, bn.num_batches_tracked)
+    elif training:
         y, stats = _conv(conv, a0, a1, False, True)
         B, _, H, W = y.shape
         if root._dp is not None and root._dp.bn_sync:

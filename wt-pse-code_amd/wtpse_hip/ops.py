@@ -266,6 +266,30 @@ def conv_wgrad_r_bn(g, bn_y, coef, x0, x1, dw, pro0=None, pro_relu=0, accumulate
 
 
 # ----------------------------------------------------------------------------------------------- batch norm
+def conv_fwd_bnf(in0, in1, wpacked_ptr, layout, bias, cout, ksize, pro0, pro_relu, pro1, gamma, beta, rmean, rvar, nbt,
+                 momentum=0.1, eps=1e-5):
+    """Forward convolution in front of a train-mode BatchNorm, statistics finished by the same launch (include/wtpse_hip.h,
+    wtpse_conv_fwd_bnf).  layout 0 fp32, 1 x3, 2 the 16-channel x3 fragments.  -> (y, ss [C,2], mean, invstd)."""
+    _chk(in0, "in0"); _chk(in1, "in1"); _chk(pro0, "pro0"); _chk(pro1, "pro1")
+    layout = int(layout)
+    B, C0, H, W = in0.shape
+    C1 = 0 if in1 is None else in1.shape[1]
+    L = lib()
+    dev = in0.device
+    out = torch.empty((B, cout, H, W), dtype=torch.float32, device=dev)
+    nblk = L.query("wtpse_conv_x3_stats_blocks", B, H, W, cout) if layout == 1 else L.query("wtpse_conv_stats_blocks", B, H, W)
+    stats = torch.empty((nblk, cout, 2), dtype=torch.float32, device=dev)
+    ss = torch.empty((cout, 2), dtype=torch.float32, device=dev)
+    mean = torch.empty((cout,), dtype=torch.float32, device=dev)
+    invstd = torch.empty((cout,), dtype=torch.float32, device=dev)
+    partial2 = torch.empty(L.query("wtpse_bnb_tail_partial2", nblk, cout), dtype=torch.float64, device=dev)
+    tickets = _tickets(L.query("wtpse_bnb_tail_tickets", nblk, cout), dev)
+    L.call("wtpse_conv_fwd_bnf", ptr(in0), C0, ptr(in1), C1, wpacked_ptr, layout, ptr(bias), ptr(pro0), ptr(pro1), int(pro_relu),
+           ptr(out), ptr(stats), ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), ptr(nbt), float(momentum), float(eps), ptr(ss),
+           ptr(mean), ptr(invstd), ptr(partial2), tickets, B, H, W, cout, ksize, stream_ptr())
+    return out, ss, mean, invstd
+
+
 def bn_finalize(stats, count, gamma, beta, rmean, rvar, nbt, momentum=0.1, eps=1e-5):
     nblk, C, _ = stats.shape
     dev = stats.device

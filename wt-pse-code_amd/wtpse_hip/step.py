@@ -165,7 +165,9 @@ class TrainStep:
             if self.plan:
                 L.plan_begin()
             try:
-                with torch.cuda.graph(g, pool=pool, stream=self._cap_stream):
+                # thread_local: another thread's HIP calls (the RCCL watchdog polling the events of the parameter broadcast that
+                # ran before the capture) must not invalidate the capture — in "global" mode they did, now and then (status 901)
+                with torch.cuda.graph(g, pool=pool, stream=self._cap_stream, capture_error_mode="thread_local"):
                     try:
                         net = next(gen)
                     except StopIteration as stop:
