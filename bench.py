@@ -510,13 +510,13 @@ def main():
                 line["roofline_" + k] = {"bound": "hbm", "kernel": w["kernel"], "achieved": w["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                          "frac": w["gbs"] / HBM_PEAK_GBS, "traffic": tr.get(k), "ms_per_launch": w["ms"],
                                          "bytes_per_launch": w["bytes_per_launch"], "tflops": w["tflops"]}
-            line["roofline_dwt"] = [{"bound": "hbm", "kernel": w["kernel"], "achieved": w["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                     "frac": w["gbs"] / HBM_PEAK_GBS, "traffic": tr.get("dwt_" + w["kernel"].split()[1].rstrip(",")),
-                                     "ms_per_launch": w["ms"], "bytes_per_launch": w["bytes_per_launch"],
-                                     "bytes_note": "bytes_per_launch: every level reads and writes its region once (round 2's accounting); "
-                                                   "the fused kernels keep the levels after the first in LDS, so the plane is read once and "
-                                                   "the coefficients written once: achieved_min_bytes = 2 x 4 B x elements / time",
-                                     "achieved_min_bytes": w["gbs_min_bytes"], "frac_min_bytes": w["gbs_min_bytes"] / HBM_PEAK_GBS,
+            line["roofline_dwt"] = [{"bound": "hbm", "kernel": w["kernel"], "achieved": w["gbs_min_bytes"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": w["gbs_min_bytes"] / HBM_PEAK_GBS, "traffic": tr.get("dwt_" + w["kernel"].split()[1].rstrip(",")),
+                                     "ms_per_launch": w["ms"], "bytes_per_launch": w["min_bytes"],
+                                     "bytes_note": "bytes_per_launch = 2 x 4 B x elements: the fused kernel keeps the levels after the first in "
+                                                   "LDS, so the plane is read once and the coefficients are written once; round 2 priced every "
+                                                   "level's read + write of its region (achieved_level_sum), which a fused transform never moves",
+                                     "achieved_level_sum": w["gbs"], "bytes_level_sum": w["bytes_per_launch"],
                                      "note": "stand-alone micro-benchmark: the reference has no wavelet transform — not part of WT-PSE, "
                                              "parity unpinned (SURVEY.md 8f-4)"} for w in kr["dwt"]]
         if world == 1 and not args.no_cpu_baseline:

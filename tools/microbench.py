@@ -64,7 +64,8 @@ def main():
     B = a.batch
     tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
     flops_tot = 0.0
-    for c0, c1, co, H, k, name in SHAPES:
+    layers = a.only in ("", "fwd", "dgrad", "wgrad")      # the other selections time no convolution layer
+    for c0, c1, co, H, k, name in (SHAPES if layers else []):
         if a.filter and a.filter not in name:
             continue
         x0 = torch.randn(B, c0, H, H, device=DEV)
@@ -97,8 +98,9 @@ def main():
             tot["wgrad"] += med
             line += "wgrad %7.1f us %5.1f TF" % (med, flops / med / 1e6)
         print(line, flush=True)
-    print("sum over listed shapes: fwd %.0f us, dgrad %.0f us, wgrad %.0f us; %.1f GFLOP per pass" %
-          (tot["fwd"], tot["dgrad"], tot["wgrad"], flops_tot / 1e9))
+    if layers:
+        print("sum over listed shapes: fwd %.0f us, dgrad %.0f us, wgrad %.0f us; %.1f GFLOP per pass" %
+              (tot["fwd"], tot["dgrad"], tot["wgrad"], flops_tot / 1e9))
     if a.only in ("", "wt"):
         z = torch.randn(B, 16, 256, 256, device=DEV)
         nbytes = z.numel() * 4.0
