@@ -58,6 +58,11 @@ def _single_device_reference():
     return main, shape, out.cpu(), scal.cpu(), s2.cpu(), g_main, g_shape, sd_before, sd_mid
 
 
+# The data-parallel gradients may be this many times as far from the fp64 oracle as the reference's own fp32 CPU run (same yardstick and
+# bound as test_parity_gpu.assert_calibrated at the benchmark's resolution; measured ratios are printed)
+CAL_DP = 3.0
+
+
 def _check_exact(res, world):
     from oracle import wtpse_cpu as O
     from oracle.inputs import make_inputs, make_noise
@@ -90,8 +95,8 @@ def _check_exact(res, world):
     for rk in res:
         da, db = _rel_to(main, rk["g_main"], a64), _rel_to(shape, rk["g_shape"], b64)
         print("  %d ranks, rank rows %s...: A %.2e B %.2e" % (world, rk["rows"][:3], da, db))
-        assert da <= 10.0 * yard_a + 2e-4, (da, yard_a)
-        assert db <= 10.0 * yard_b + 2e-4, (db, yard_b)
+        assert da <= CAL_DP * yard_a + 2e-4, (da, yard_a)
+        assert db <= CAL_DP * yard_b + 2e-4, (db, yard_b)
         assert torch.allclose(rk["out"], out[rk["rows"]], atol=1e-4)
         assert torch.allclose(rk["scal_main"], scal, rtol=1e-3, atol=1e-6)
         if "scal_shape" in rk:
