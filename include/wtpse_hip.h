@@ -24,7 +24,7 @@ extern "C" {
  *      shape_networks.py:182-193,332-338,376-383,459-465) ------------------------------------------------------- */
 
 /* OIHW parameters -> kernel layouts, all convs of a network in one launch.
- * desc: n_desc x 8 ints {w_off, Cout, Cin, taps, wf_off, wd_off(-1: none), 0, 0}, offsets in floats into
+ * desc: n_desc x 8 ints {w_off, Cout, Cin, taps, wf_off (-1: none), wd_off (-1: none), 0, 0}, offsets in floats into
  * `params` / `packed`.  wf = [ceil4(Cin)][taps][ceil16(Cout)], wd = [ceil4(Cout)][taps][ceil16(Cin)] (tap-flipped). */
 int wtpse_pack_conv_weights(const float* params, const int* desc, int n_desc, float* packed, void* stream);
 

@@ -847,7 +847,7 @@ __global__ __launch_bounds__(256) void pack_weights_k(const float* __restrict__ 
   const int CiP4 = (Ci + 3) & ~3, CoP16 = (Co + 15) & ~15;
   const int CoP4 = (Co + 3) & ~3, CiP16 = (Ci + 15) & ~15;
   const float* w = params + w_off;
-  const int nf = CiP4 * T * CoP16;
+  const int nf = wf_off >= 0 ? CiP4 * T * CoP16 : 0;      // a direction that runs on the x3 kernels has no fp32 layout (-1)
   for (int e = blockIdx.x * 256 + threadIdx.x; e < nf; e += gridDim.x * 256) {
     int co = e % CoP16;
     int t = (e / CoP16) % T;

@@ -189,14 +189,6 @@ class HipNet(nn.Module):
         for m in self.modules():
             if isinstance(m, (ConvP, BNP, AttentionP, TeacherP, DeepWTP)):
                 object.__setattr__(m, "_root", self)
-        off = 0
-        for c in self._convs:
-            t = c.k * c.k
-            c.wf_off = off
-            off += ((c.cin + 3) & ~3) * t * ((c.cout + 15) & ~15)
-            c.wd_off = off
-            off += ((c.cout + 3) & ~3) * t * ((c.cin + 15) & ~15)
-        self._packed_size = off
         # weights of the layers that run on the split-bf16 ("x3") convolution (csrc/conv_x3.hip), pre-split into bf16 triples
         off = 0
         self._x3_convs = []
@@ -226,6 +218,19 @@ class HipNet(nn.Module):
                 if c.x16f_off >= 0 or c.x16d_off >= 0:
                     self._x16_convs.append(c)
         self._x3_size = off
+        # fp32-input MFMA layouts: only the directions that do not run on the x3 kernels (re-packing all 6.4 M weights of a
+        # network into layouts nobody reads cost 120 us per network and step)
+        off = 0
+        for c in self._convs:
+            t = c.k * c.k
+            c.wf_off = c.wd_off = -1
+            if c.xf_off < 0:
+                c.wf_off = off
+                off += ((c.cin + 3) & ~3) * t * ((c.cout + 15) & ~15)
+            if c.xd_off < 0:
+                c.wd_off = off
+                off += ((c.cout + 3) & ~3) * t * ((c.cin + 15) & ~15)
+        self._packed_size = max(off, 4)
 
     # ---- flat storage --------------------------------------------------------------------------------------
     def _is_flat(self):
