@@ -204,7 +204,8 @@ int wtpse_wt_gram_fwd(const float* z, int B, int C, int HW, float eps, float* pa
 int wtpse_wt_final(const float* offdiag, const float* diag, int B, int Bnorm, float margin, const double* rowval, int R,
                    float* losses, void* stream);
 /* dz (+)= d(w_off*g_off*ins_off + w_diag*g_diag*ins_diag + w_dom*g_dom*dom)/dz.  g_*: device scalars (NULL = 1).
- * Mws: [B][256] scratch. */
+ * Mws: [B][256] scratch.  accumulate & 1: add to dz; accumulate & 2 (with & 1): the incoming dz is a gradient wrt relu(z) and is
+ * masked with [z > 0] first (the teacher reads relu(z2): algorithms.py:1066) — z is in registers here anyway. */
 int wtpse_wt_loss_bwd(const float* z, int B, int C, int HW, float margin, int domain_num, int per_domain,
                       const float* gram, const float* offdiag, const float* diag, const float* dmmd_dv,
                       const float* g_off, const float* g_diag, const float* g_dom, float w_off, float w_diag, float w_dom,
@@ -217,6 +218,8 @@ int wtpse_mmd_fwd(const float* v, int domain_num, int per_domain, double* rowval
 
 /* ---- pooling / upsampling (algorithms.py:890,901,929,949) ------------------------------------------------------- */
 int wtpse_maxpool2_fwd(const float* x, const float* pro, int relu, float* out, int B, int C, int H, int W, void* stream);
+/* accumulate & 1: dx += ; accumulate & 2: the result (after the add) is masked with [act(x) > 0], act = the prologue as loaded —
+ * the backward of the ReLU that produced x (algorithms.py:1068-1069: fusion conv -> ReLU -> U-Net), fused. */
 int wtpse_maxpool2_bwd(const float* x, const float* pro, int relu, const float* dout, float* dx, int accumulate, int B,
                        int C, int H, int W, void* stream);
 /* bilinear x2, align_corners=False; H, W are the INPUT sizes. */
@@ -286,7 +289,8 @@ int wtpse_head_fwd(const float* x, const float* pro, int pro_relu, const float* 
                    void* stream);
 /* dy: [B][nc][HW] (three layers) or [B][8][HW] (two layers: gradient of the h2 output).  dx: [B][32][HW] gradient wrt the
  * activated input.  dparams: [32*32 + 32 + 8*32 + 8 (+ 8*nc + nc)] = (dW1, db1, dW2, db2[, dW3, db3]) contiguous, which is
- * the order the head's parameters have in the flat gradient buffer; written, or added to when accumulate != 0.
+ * the order the head's parameters have in the flat gradient buffer; written, or added to when accumulate & 1.
+ * accumulate & 2: dx += instead of dx = (a second head reading the same input).
  * slab: scratch of wtpse_head_slabs(B, HW) * that many floats. */
 int wtpse_head_bwd(const float* dy, const float* x, const float* pro, int pro_relu, const float* h1, const float* h2,
                    const float* w1, const float* w2, const float* w3, int nc, float* dx, float* slab, float* dparams,

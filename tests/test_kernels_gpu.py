@@ -235,6 +235,15 @@ def test_pool_and_upsample(shape):
     close(o.maxpool2_bwd(xd, dp.to(DEV), None, False, None, True), xr.grad, what="pool bwd")
     acc = rnd(*shape, seed=33)
     close(o.maxpool2_bwd(xd, dp.to(DEV), acc.clone().to(DEV), True, None, True), xr.grad + acc, what="pool bwd acc")
+    # ... with the backward of the ReLU that produced the tensor fused in: (acc + pooled gradient) * [relu(x) > 0]
+    live = (F.relu(x.detach()) > 0).float()
+    close(o.maxpool2_bwd(xd, dp.to(DEV), acc.clone().to(DEV), True, None, True, mask=True), (xr.grad + acc) * live, what="pool bwd acc mask")
+    close(o.maxpool2_bwd(xd, dp.to(DEV), None, False, None, True, mask=True), xr.grad * live, what="pool bwd mask")
+    ref = rnd(*shape, seed=36)
+    close(o.relu_mask(acc.to(DEV), ref.to(DEV)), acc * (ref > 0), what="relu mask")
+    dst = acc.clone().to(DEV)
+    o.axpy(dst, ref.to(DEV), 0.5)
+    close(dst, acc + 0.5 * ref, what="axpy")
     x2 = rnd(*shape, seed=34).requires_grad_(True)
     u = F.interpolate(x2, scale_factor=2, mode="bilinear", align_corners=False)
     du = rnd(*u.shape, seed=35)
@@ -293,6 +302,10 @@ def test_wt_loss_against_oracle_and_golden(golden_dir):
         two = torch.tensor(2.0, device=DEV)
         o.wt_loss_bwd(st, dz2, True, g_off=two, g_diag=two, g_dom=two, w_off=0.5, w_diag=0.5, w_dom=0.5)
         close(dz2, base + zr.grad, rtol=2e-3, atol=1e-6 + 2e-4 * float(zr.grad.abs().max()), what=p + "dz acc")
+        # accumulate & 2: the incoming gradient is wrt relu(z) and is masked with [z > 0] inside the same pass
+        dz3 = base.clone().to(DEV)
+        o.wt_loss_bwd(st, dz3, 3, g_off=two, g_diag=two, g_dom=two, w_off=0.5, w_diag=0.5, w_dom=0.5)
+        close(dz3, base * (z > 0) + zr.grad, rtol=2e-3, atol=1e-6 + 2e-4 * float(zr.grad.abs().max()), what=p + "dz mask-in")
 
 
 def test_wt_loss_unaligned_hw():
@@ -340,6 +353,12 @@ def test_fused_head(case):
     close(dpar, want, rtol=2e-4, atol=2e-5 * max(scale, 1.0), what="head dparams")
     o.head_bwd(D(dy), D(x), D(pro), use_pro, h1d, h2d, D(w1), D(w2), D(w3), dpar, accumulate=True)
     close(dpar, 2 * want, rtol=2e-4, atol=4e-5 * max(scale, 1.0), what="head dparams accumulate")
+    # a second head on the same input adds its input gradient in place
+    into = rnd(B, 32, H, W, seed=71).to(DEV)
+    base = into.clone()
+    r = o.head_bwd(D(dy), D(x), D(pro), use_pro, h1d, h2d, D(w1), D(w2), D(w3), dpar, dx_into=into)
+    assert r is into
+    close(into, base.cpu() + xa.grad, what="dx accumulate")
 
 
 @pytest.mark.parametrize("shape", [(3, 8, 9, 11), (5, 2, 256, 256)])   # the second takes the many-row reduction of (dw, db)

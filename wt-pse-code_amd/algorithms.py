@@ -264,10 +264,12 @@ class WT_PSE(E.HipNet, E.UNetBody):
             return self._dp.wt_loss_fwd(z, D, n, float(self.margin), self.eps, losses_out)
         return ops.wt_loss_fwd(z, D, n, float(self.margin), self.eps, losses_out, gram)
 
-    def _wt_loss_bwd(self, st, dz, **kw):
+    def _wt_loss_bwd(self, st, dz, mask_in=False, **kw):
+        """mask_in: dz arrives as the gradient wrt relu(z) and is masked with [z > 0] inside the same pass."""
+        acc = 3 if mask_in else 1
         if self._dp is not None:
-            return self._dp.wt_loss_bwd(st, dz, True, **kw)
-        return ops.wt_loss_bwd(st, dz, True, **kw)
+            return self._dp.wt_loss_bwd(st, dz, acc, **kw)
+        return ops.wt_loss_bwd(st, dz, acc, **kw)
 
     def _backward_update(self, t, d_out, d_ins=None, d_dom=None, w_ins=1.0, w_dom=1.0):
         """d_out: gradient wrt the logits; d_ins / d_dom: device scalars (None -> 1) scaled by the host weights
@@ -301,8 +303,8 @@ class WT_PSE(E.HipNet, E.UNetBody):
                 dlogvar = ops.reparam_bwd(dz_post, t.th.logvar, t.eps)
                 d_relu_z2 = E.teacher_bwd(self.prior_dist, t.th, dz_post, dlogvar)
                 self.grads_ready(self.prior_dist)           # data-parallel overlap: 12.7 MB go out beside DeepWT's backward
-                dz2 = ops.relu_mask(d_relu_z2, t.w.z2)
-                self._wt_loss_bwd(t.st2, dz2, **kw)
+                dz2 = d_relu_z2                              # masked with [z2 > 0] inside the WT-loss backward pass
+                self._wt_loss_bwd(t.st2, dz2, mask_in=True, **kw)
                 E.deepwt_bwd(self.wt_model, t.w, dz2, lambda dz1: self._wt_loss_bwd(t.st1, dz1, **kw))
 
             # the prior chain's backward on the second stream beside the segmentation U-Net's (see _forward_update); it

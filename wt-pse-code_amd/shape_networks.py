@@ -154,10 +154,12 @@ class ShapeVariationalDist_x(E.HipNet, E.UNetBody):
             return self._dp.wt_loss_fwd(z, D, n, float(self.margin), self.eps, losses_out)
         return ops.wt_loss_fwd(z, D, n, float(self.margin), self.eps, losses_out, gram)
 
-    def _wt_loss_bwd(self, st, dz, **kw):
+    def _wt_loss_bwd(self, st, dz, mask_in=False, **kw):
+        """mask_in: dz arrives as the gradient wrt relu(z) and is masked with [z > 0] inside the same pass."""
+        acc = 3 if mask_in else 1
         if self._dp is not None:
-            return self._dp.wt_loss_bwd(st, dz, True, **kw)
-        return ops.wt_loss_bwd(st, dz, True, **kw)
+            return self._dp.wt_loss_bwd(st, dz, acc, **kw)
+        return ops.wt_loss_bwd(st, dz, acc, **kw)
 
     def _backward_update(self, t, g_kd=None, g_off=None, g_diag=None, g_dom=None, w_kd=1.0, w_off=1.0, w_diag=1.0, w_dom=1.0):
         """g_*: device scalars (None -> 1), w_*: host weights.  Instance terms follow the reference's bookkeeping:
@@ -170,8 +172,8 @@ class ShapeVariationalDist_x(E.HipNet, E.UNetBody):
         # data-parallel overlap: up1 .. logvar_prior (registration order: the decoder and the two heads) are complete after the
         # decoder's backward and go out beside the encoder's and DeepWT's
         d_relu_z2 = E.unet_bwd(self, t.unet, dfmap, decoder_done=lambda: self.grads_ready(self.up1, self.logvar_prior))
-        dz2 = ops.relu_mask(d_relu_z2, t.w2.z2)
-        self._wt_loss_bwd(t.st2, dz2, g_off=g_off, g_diag=g_diag, g_dom=g_dom, w_off=w_off / 3.0, w_diag=2.0 * w_diag / 3.0,
+        dz2 = d_relu_z2                                      # masked with [z2 > 0] inside the WT-loss backward pass
+        self._wt_loss_bwd(t.st2, dz2, mask_in=True, g_off=g_off, g_diag=g_diag, g_dom=g_dom, w_off=w_off / 3.0, w_diag=2.0 * w_diag / 3.0,
                           w_dom=w_dom / 3.0)
         E.deepwt_bwd(self.wt_model, t.w2, dz2,
                      lambda dz1: self._wt_loss_bwd(t.st1, dz1, g_off=g_off, g_diag=g_diag, g_dom=g_dom, w_off=w_off / 3.0,

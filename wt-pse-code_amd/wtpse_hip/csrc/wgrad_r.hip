@@ -435,7 +435,10 @@ static bool wgrad_r_plan(int B, int H, int W, int Cin, int Cout, WgradRPlan& p) 
   p.strips = W / 32;
   // waves: one per SIMD for the blocks of two or four fragments (more than 256 registers), two per SIMD for the 16 x 16 blocks
   p.nw = (p.mf * p.nf >= 2) ? 4 : 8;
-  const int target = (p.mf * p.nf >= 2) ? 1024 : 2048;
+  // tuning override, read once per process (the slab count the host sizes its scratch with must agree with the launch)
+  static const int target_override = [] { const char* e = getenv("WTPSE_WGRAD_R_WAVES"); return e ? atoi(e) : 0; }();
+  int target = (p.mf * p.nf >= 2) ? 1024 : 2048;
+  if (target_override >= 64 && p.mf * p.nf >= 2) target = target_override;
   int wpp = (target / p.pairs) / p.nw * p.nw;
   if (wpp < p.nw) wpp = p.nw;
   const int cols = B * p.strips;                          // (image, strip) columns of H rows

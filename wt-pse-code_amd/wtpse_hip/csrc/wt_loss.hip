@@ -335,13 +335,19 @@ __global__ __launch_bounds__(256) void gram_bwd_k(const float* __restrict__ z, c
     if (VEC) {
       float4* dst = reinterpret_cast<float4*>(db + (size_t)c * HW);
       float4 t = make_float4(o[0], o[1], o[2], o[3]);
-      if (accumulate) {
+      if (accumulate & 1) {
         float4 old = *dst;
+        if (accumulate & 2) {      // the incoming gradient is wrt relu(z): mask it with [z > 0] (z is in registers)
+          old.x = in[c][0] > 0.f ? old.x : 0.f; old.y = in[c][1] > 0.f ? old.y : 0.f;
+          old.z = in[c][2] > 0.f ? old.z : 0.f; old.w = in[c][3] > 0.f ? old.w : 0.f;
+        }
         t.x += old.x; t.y += old.y; t.z += old.z; t.w += old.w;
       }
       *dst = t;
     } else {
-      db[(size_t)c * HW] = accumulate ? db[(size_t)c * HW] + o[0] : o[0];
+      float old = (accumulate & 1) ? db[(size_t)c * HW] : 0.f;
+      if ((accumulate & 2) && !(in[c][0] > 0.f)) old = 0.f;
+      db[(size_t)c * HW] = old + o[0];
     }
   }
 }

@@ -703,8 +703,9 @@ def convd_fwd(blk, x, training, want_tape=True):
     return c, t
 
 
-def convd_bwd(blk, t, dz, dx_accum=None, need_dx=True):
-    """dx_accum: existing gradient buffer of x (skip connection) to accumulate into, or None."""
+def convd_bwd(blk, t, dz, dx_accum=None, need_dx=True, mask_x=False):
+    """dx_accum: existing gradient buffer of x (skip connection) to accumulate into, or None.  mask_x: x is the output of a ReLU
+    whose backward is applied to the returned gradient here (in the max-pool backward, which reads x anyway)."""
     d, _ = convbn_bwd(blk.conv3, blk.bn3, t.c3, dz, below0=t.c2)
     d, _ = convbn_bwd(blk.conv2, blk.bn2, t.c2, d, below0=t.c1)
     d, _ = convbn_bwd(blk.conv1, blk.bn1, t.c1, d, need_dx=need_dx)
@@ -713,9 +714,9 @@ def convd_bwd(blk, t, dz, dx_accum=None, need_dx=True):
     if blk.first:
         if dx_accum is not None:
             ops.axpy(dx_accum, d)
-            return dx_accum
-        return d
-    return ops.maxpool2_bwd(t.x.t, d, dx_accum, dx_accum is not None, t.x.pro, t.x.relu)
+            d = dx_accum
+        return ops.relu_mask(d, t.x.t) if mask_x else d
+    return ops.maxpool2_bwd(t.x.t, d, dx_accum, dx_accum is not None, t.x.pro, t.x.relu, mask=mask_x)
 
 
 # ---- ConvU (algorithms.py:941-962) ---------------------------------------------------------------------------
@@ -807,7 +808,7 @@ def unet_fwd(net, x1, training, want_tape=True):
     return x, t
 
 
-def unet_bwd(net, t, dfeat, need_dx1=True, decoder_done=None):
+def unet_bwd(net, t, dfeat, need_dx1=True, decoder_done=None, mask_x=None):
     """-> gradient wrt the activated x1 (None if not needed).  decoder_done(): called once up4 .. up1 have been queued (their
     parameter gradients are then complete: the data-parallel exchange of that range starts beside the encoder's backward)."""
     # (the output of up3 / up2 / up1 / down4 feeds only the next ConvU: its gradient carries that layer's BatchNorm statistics)
@@ -820,7 +821,8 @@ def unet_bwd(net, t, dfeat, need_dx1=True, decoder_done=None):
     convd_bwd(net.down4, t.d4, g5, g4)
     convd_bwd(net.down3, t.d3, g4, g3)
     convd_bwd(net.down2, t.d2, g3, g2)
-    convd_bwd(net.down1, t.d1, g2, g1)
+    # mask_x: x1 came out of a ReLU (the teacher's fusion conv): its backward rides in the last kernel that writes g1
+    g1 = convd_bwd(net.down1, t.d1, g2, g1, mask_x=mask_x is not None)
     return g1 if need_dx1 else None
 
 
@@ -863,8 +865,8 @@ def head_fwd(seq, x, idxs, want_tape=True):
     return h, t
 
 
-def head_bwd(seq, t, d, idxs):
-    """-> gradient wrt the activated head input."""
+def head_bwd(seq, t, d, idxs, dx_into=None):
+    """-> gradient wrt the activated head input (added to `dx_into` if given: a second head on the same input)."""
     if t.fused:
         ls = [seq[i] for i in idxs]
         root = ls[0]._root
@@ -873,13 +875,16 @@ def head_bwd(seq, t, d, idxs):
         off = root._offsets[root._pindex[id(ls[0].weight)]]
         dparams = root._gtarget[off:off + total]
         return ops.head_bwd(d, t.x.t, t.x.pro, t.x.relu, t.h1, t.h2, ls[0].weight, ls[1].weight,
-                            ls[2].weight if len(ls) == 3 else None, dparams)
+                            ls[2].weight if len(ls) == 3 else None, dparams, dx_into=dx_into)
     for n in reversed(range(len(idxs))):
         layer = seq[idxs[n]]
         inp = t.x if n == 0 else t.acts[n - 1]
         _wgrad(layer, d, inp)
         # the ReLU backward of the activation below rides in this data gradient's epilogue
         d, _ = _dgrad(layer, d, mask_ref=(t.acts[n - 1] if n > 0 else None))
+    if dx_into is not None:
+        ops.axpy(dx_into, d)
+        return dx_into
     return d
 
 
@@ -954,10 +959,8 @@ def teacher_bwd(tn, t, dmu, dlogvar):
     """-> gradient wrt the activated feat (i.e. wrt relu(z2) when feat carries ReLU-on-load)."""
     d = head_bwd(tn.mu_prior, t.hmu, dmu, (0, 2, 4))
     if dlogvar is not None:
-        d2 = head_bwd(tn.logvar_prior, t.hlv, dlogvar, (0, 2, 4))
-        ops.axpy(d, d2)
-    dxf = unet_bwd(tn, t.unet, d)
-    dxf = ops.relu_mask(dxf, t.xf)
+        head_bwd(tn.logvar_prior, t.hlv, dlogvar, (0, 2, 4), dx_into=d)
+    dxf = unet_bwd(tn, t.unet, d, mask_x=t.xf)      # the ReLU of the fusion conv rides in the last data gradient's epilogue
     _wgrad(tn.fusion[0], dxf, t.m2, t.feat)
     dm2, dfeat = _dgrad(tn.fusion[0], dxf, split=t.m2.t.shape[1], below0=t.i3)
     inc = tn.inc.double_conv
