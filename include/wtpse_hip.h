@@ -222,6 +222,13 @@ int wtpse_maxpool2_fwd(const float* x, const float* pro, int relu, float* out, i
  * the backward of the ReLU that produced x (algorithms.py:1068-1069: fusion conv -> ReLU -> U-Net), fused. */
 int wtpse_maxpool2_bwd(const float* x, const float* pro, int relu, const float* dout, float* dx, int accumulate, int B,
                        int C, int H, int W, void* stream);
+/* wtpse_maxpool2_bwd(accumulate | 2) where x is the raw output of a conv + BatchNorm + ReLU layer (pro = its scale/shift): the
+ * result is the masked gradient wrt that layer's activated output, and the launch also forms the two reductions of its BatchNorm
+ * backward: stats [wtpse_maxpool2_bwd_stats_blocks(B,H,W)][C][2] = (sum g, sum g (y - mean)) partials, the layout
+ * wtpse_bn_bwd_from_stats folds.  H even, W % 4 == 0, 16-byte aligned tensors, B*C < 32768. */
+int wtpse_maxpool2_bwd_stats_blocks(int B, int H, int W);
+int wtpse_maxpool2_bwd_bnb(const float* x, const float* pro, int relu, const float* dout, float* dx, int accumulate,
+                           const float* mean, float* stats, int B, int C, int H, int W, void* stream);
 /* bilinear x2, align_corners=False; H, W are the INPUT sizes. */
 int wtpse_upsample2x_fwd(const float* x, const float* pro, int relu, float* out, int B, int C, int H, int W, void* stream);
 int wtpse_upsample2x_bwd(const float* dout, float* dx, int accumulate, int B, int C, int H, int W, void* stream);

@@ -544,3 +544,43 @@ def test_conv_gram_epilogue_and_wt_loss_from_partials(shape):
     o.wt_loss_bwd(st_f, dz_f, False)
     o.wt_loss_bwd(st_d, dz_d, False)
     close(dz_f, dz_d, rtol=1e-4, atol=1e-7 * float(dz_d.abs().max()) + 1e-12, what="dL/dz fused vs stand-alone")
+
+
+@pytest.mark.parametrize("shape,acc", [((4, 16, 32, 64), True), ((3, 8, 16, 8), False), ((2, 32, 64, 64), True)])
+def test_maxpool_bwd_with_batchnorm_statistics(shape, acc):
+    """The max-pool backward on the raw output of a conv + BatchNorm + ReLU layer that also forms that layer's BatchNorm-backward
+    reductions (wtpse_maxpool2_bwd_bnb) + wtpse_bn_bwd_from_stats, against the separate passes (max-pool backward, then the
+    three-kernel BatchNorm backward) and against autograd."""
+    o = ops()
+    B, C, H, W = shape
+    y = rnd(*shape, seed=81).double().requires_grad_(True)
+    gamma = (rnd(C, seed=82) * 0.2 + 1).double().requires_grad_(True)
+    beta = (rnd(C, seed=83) * 0.2).double().requires_grad_(True)
+    z = F.relu(F.batch_norm(y, None, None, gamma, beta, True, 0.1, 1e-5))
+    skip = rnd(*shape, seed=84)
+    dp = rnd(B, C, H // 2, W // 2, seed=85)
+    loss = (F.max_pool2d(z, 2) * dp.double()).sum() + ((z * skip.double()).sum() if acc else 0.0)
+    loss.backward()
+    yd = y.detach().float().to(DEV)
+    mean = yd.double().mean((0, 2, 3))
+    invstd = 1.0 / torch.sqrt(yd.double().var((0, 2, 3), unbiased=False) + 1e-5)
+    g_d, b_d = gamma.detach().float().to(DEV), beta.detach().float().to(DEV)
+    ss = torch.stack([g_d.double() * invstd, b_d.double() - mean * g_d.double() * invstd], 1).float().contiguous()
+    mean_f, invstd_f = mean.float().contiguous(), invstd.float().contiguous()
+    r = o.maxpool2_bwd_bnb(yd, dp.to(DEV), skip.clone().to(DEV) if acc else None, ss, True, mean_f)
+    assert r is not None
+    g, stats = r
+    dg, db = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    dy = o.bn_bwd_from_stats(g, yd, stats, g_d, mean_f, invstd_f, dg, db)
+    # the separate passes
+    g2 = o.maxpool2_bwd(yd, dp.to(DEV), skip.clone().to(DEV) if acc else None, acc, ss, True)
+    dg2, db2 = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    dy2 = o.bn_bwd(g2, yd, ss, True, g_d, mean_f, invstd_f, dg2, db2)
+    sc = float(dy2.abs().max())
+    close(dy, dy2, rtol=1e-4, atol=2e-5 * sc, what="fused vs separate dy")
+    close(dg, dg2, rtol=1e-4, atol=1e-4 * float(dg2.abs().max()) + 1e-6, what="dgamma")
+    close(db, db2, rtol=1e-4, atol=1e-4 * float(db2.abs().max()) + 1e-6, what="dbeta")
+    on_kink = (F.batch_norm(y.detach(), None, None, gamma.detach(), beta.detach(), True, 0.1, 1e-5).abs() < 2e-6)
+    kz = lambda t: torch.where(on_kink.to(t.device), torch.zeros_like(t), t)
+    close(kz(dy), kz(y.grad.float()), rtol=1e-3, atol=2e-4 * float(y.grad.abs().max()), what="dy vs autograd")
+    close(dg, gamma.grad, rtol=1e-3, atol=2e-4 * float(gamma.grad.abs().max()) + 1e-5, what="dgamma vs autograd")

@@ -323,6 +323,6 @@ class WT_PSE(E.HipNet, E.UNetBody):
                 prior_chain_bwd()
         dfeat = E.head_bwd(self.mu, t.mu, demb, (0, 2))
         self.grads_ready(self.mu, self.attention_layer)      # heads: mu, outc, attention_layer (registration order)
-        dx1 = E.unet_bwd(self, t.unet, dfeat, decoder_done=lambda: self.grads_ready(self.up1, self.up4))
+        dx1 = E.unet_bwd(self, t.unet, dfeat, decoder_done=lambda: self.grads_ready(self.up1, self.up4), below_x1=t.inc.c3)
         E.convd_bwd(self.inc, t.inc, dx1, need_dx=False)
         self.end_backward()

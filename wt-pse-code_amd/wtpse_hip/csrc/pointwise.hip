@@ -65,12 +65,21 @@ __device__ __forceinline__ int pool_argmax(float v0, float v1, float v2, float v
   return am;
 }
 
+// stats (optional, with accumulate & 2 and x = the raw output y of a conv + BatchNorm + ReLU layer, pro = its scale/shift): the
+// result is the gradient wrt that layer's activated output, masked with its ReLU — so the two reductions of its BatchNorm
+// backward (sum g, sum g (y - mean)) are formed here, per workgroup and plane: stats[(b * gridDim.x + blockIdx.x)][C][2]
+// (the layout wtpse_bn_bwd_from_stats folds).  The skip connections' gradients of the encoder arrive through this kernel:
+// 20 stand-alone reduce passes over full-resolution maps per step otherwise.
 __global__ __launch_bounds__(256) void maxpool2_bwd_v_k(const float* __restrict__ x, const float* __restrict__ pro, int relu,
                                                         const float* __restrict__ dout, float* __restrict__ dx, int accumulate,
-                                                        int BC, int C, int H, int W) {
+                                                        int BC, int C, int H, int W, const float* __restrict__ mean,
+                                                        float* __restrict__ stats) {
+  __shared__ float sh4[4];
   const int Ho = H / 2, Wo = W / 2, W4 = W / 4;   // H even, W % 4 == 0: a thread owns two windows (2 rows x 4 columns)
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= Ho * W4) return;
+  const int jj = blockIdx.x * 256 + threadIdx.x;
+  const bool valid = jj < Ho * W4;
+  if (!valid && !stats) return;
+  const int j = valid ? jj : 0;
   const int k = j % W4, yo = j / W4;
   for (int bc = blockIdx.y; bc < BC; bc += gridDim.y) {
     const int c = bc % C;
@@ -92,8 +101,27 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_v_k(const float* __restrict_
       d1.x = act_in(r1.x, pro, c, relu) > 0.f ? d1.x : 0.f; d1.y = act_in(r1.y, pro, c, relu) > 0.f ? d1.y : 0.f;
       d1.z = act_in(r1.z, pro, c, relu) > 0.f ? d1.z : 0.f; d1.w = act_in(r1.w, pro, c, relu) > 0.f ? d1.w : 0.f;
     }
-    *reinterpret_cast<float4*>(dx + off) = d0;
-    *reinterpret_cast<float4*>(dx + off + W) = d1;
+    if (valid) {
+      *reinterpret_cast<float4*>(dx + off) = d0;
+      *reinterpret_cast<float4*>(dx + off + W) = d1;
+    }
+    if (stats) {
+      const float mu = mean[c];
+      float s1 = 0.f, s2 = 0.f;
+      if (valid) {
+#pragma clang fp contract(off)
+        s1 = ((d0.x + d0.y) + (d0.z + d0.w)) + ((d1.x + d1.y) + (d1.z + d1.w));
+        s2 = ((d0.x * (r0.x - mu) + d0.y * (r0.y - mu)) + (d0.z * (r0.z - mu) + d0.w * (r0.w - mu))) +
+             ((d1.x * (r1.x - mu) + d1.y * (r1.y - mu)) + (d1.z * (r1.z - mu) + d1.w * (r1.w - mu)));
+      }
+      s1 = block_sum(s1, sh4);
+      s2 = block_sum(s2, sh4);
+      if (threadIdx.x == 0) {
+        float* dst = stats + (((size_t)(bc / C) * gridDim.x + blockIdx.x) * C + c) * 2;
+        dst[0] = s1;
+        dst[1] = s2;
+      }
+    }
   }
 }
 
@@ -678,9 +706,20 @@ extern "C" int wtpse_maxpool2_bwd(const float* x, const float* pro, int relu, co
   long long total = (long long)B * C * H * W;
   if (W % 4 == 0 && H % 2 == 0 && (((uintptr_t)x | (uintptr_t)dx | (uintptr_t)dout) & 15) == 0)
     hipLaunchKernelGGL(maxpool2_bwd_v_k, PLANE_GRID((H / 2) * (W / 4), B * C), dim3(256), 0, ST, x, pro, relu, dout, dx, accumulate,
-                       B * C, C, H, W);
+                       B * C, C, H, W, (const float*)nullptr, (float*)nullptr);
   else
     hipLaunchKernelGGL(maxpool2_bwd_k, GRID1(total), dim3(256), 0, ST, x, pro, relu, dout, dx, accumulate, C, H, W, total);
+  return wtpse_status();
+}
+extern "C" int wtpse_maxpool2_bwd_stats_blocks(int B, int H, int W) { return B * (((H / 2) * (W / 4) + 255) / 256); }
+// wtpse_maxpool2_bwd(accumulate | 2) that also forms the BatchNorm-backward reductions of the layer that produced x (see the kernel)
+extern "C" int wtpse_maxpool2_bwd_bnb(const float* x, const float* pro, int relu, const float* dout, float* dx, int accumulate,
+                                      const float* mean, float* stats, int B, int C, int H, int W, void* stream) {
+  WTPSE_REQUIRE(x && pro && dout && dx && mean && stats && B > 0 && C > 0 && H >= 2 && W >= 4);
+  WTPSE_REQUIRE(W % 4 == 0 && H % 2 == 0 && (((uintptr_t)x | (uintptr_t)dx | (uintptr_t)dout) & 15) == 0);
+  WTPSE_REQUIRE(B * C < 32768);   // one plane per blockIdx.y: the statistics rows are indexed by gridDim.x
+  hipLaunchKernelGGL(maxpool2_bwd_v_k, PLANE_GRID((H / 2) * (W / 4), B * C), dim3(256), 0, ST, x, pro, relu, dout, dx,
+                     (accumulate & 1) | 2, B * C, C, H, W, mean, stats);
   return wtpse_status();
 }
 extern "C" int wtpse_upsample2x_fwd(const float* x, const float* pro, int relu, float* out, int B, int C, int H, int W, void* stream) {

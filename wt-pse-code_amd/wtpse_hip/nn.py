@@ -703,9 +703,11 @@ def convd_fwd(blk, x, training, want_tape=True):
     return c, t
 
 
-def convd_bwd(blk, t, dz, dx_accum=None, need_dx=True, mask_x=False):
+def convd_bwd(blk, t, dz, dx_accum=None, need_dx=True, mask_x=False, below=None):
     """dx_accum: existing gradient buffer of x (skip connection) to accumulate into, or None.  mask_x: x is the output of a ReLU
-    whose backward is applied to the returned gradient here (in the max-pool backward, which reads x anyway)."""
+    whose backward is applied to the returned gradient here (in the max-pool backward, which reads x anyway).  below: tape of the
+    conv + BatchNorm + ReLU layer that produced x: the max-pool backward then also forms that layer's BatchNorm-backward
+    reductions and the gradient comes back as a PreBN."""
     d, _ = convbn_bwd(blk.conv3, blk.bn3, t.c3, dz, below0=t.c2)
     d, _ = convbn_bwd(blk.conv2, blk.bn2, t.c2, d, below0=t.c1)
     d, _ = convbn_bwd(blk.conv1, blk.bn1, t.c1, d, need_dx=need_dx)
@@ -716,6 +718,12 @@ def convd_bwd(blk, t, dz, dx_accum=None, need_dx=True, mask_x=False):
             ops.axpy(dx_accum, d)
             d = dx_accum
         return ops.relu_mask(d, t.x.t) if mask_x else d
+    root = blk.conv1._root
+    if (BN_FUSED_STATS and below is not None and below.mean is not None and t.x.relu and t.x.pro is not None
+            and not (root._dp is not None and root._dp.bn_sync)):
+        r = ops.maxpool2_bwd_bnb(t.x.t, d, dx_accum, t.x.pro, t.x.relu, below.mean)
+        if r is not None:
+            return PreBN(r[0], r[1])
     return ops.maxpool2_bwd(t.x.t, d, dx_accum, dx_accum is not None, t.x.pro, t.x.relu, mask=mask_x)
 
 
@@ -808,7 +816,7 @@ def unet_fwd(net, x1, training, want_tape=True):
     return x, t
 
 
-def unet_bwd(net, t, dfeat, need_dx1=True, decoder_done=None, mask_x=None):
+def unet_bwd(net, t, dfeat, need_dx1=True, decoder_done=None, mask_x=None, below_x1=None):
     """-> gradient wrt the activated x1 (None if not needed).  decoder_done(): called once up4 .. up1 have been queued (their
     parameter gradients are then complete: the data-parallel exchange of that range starts beside the encoder's backward)."""
     # (the output of up3 / up2 / up1 / down4 feeds only the next ConvU: its gradient carries that layer's BatchNorm statistics)
@@ -818,11 +826,14 @@ def unet_bwd(net, t, dfeat, need_dx1=True, decoder_done=None, mask_x=None):
     g5, g4 = convu_bwd(net.up1, t.u1, d, below_x=t.d4.c3)
     if decoder_done is not None:
         decoder_done()
-    convd_bwd(net.down4, t.d4, g5, g4)
-    convd_bwd(net.down3, t.d3, g4, g3)
-    convd_bwd(net.down2, t.d2, g3, g2)
-    # mask_x: x1 came out of a ReLU (the teacher's fusion conv): its backward rides in the last kernel that writes g1
-    g1 = convd_bwd(net.down1, t.d1, g2, g1, mask_x=mask_x is not None)
+    # (the skip gradients g4 .. g1 get their pooled share added by the max-pool backward, which then also forms the BatchNorm-backward
+    # reductions of the conv3 that produced the tensor: they come back as PreBN)
+    g4 = convd_bwd(net.down4, t.d4, g5, g4, below=t.d3.c3)
+    g3 = convd_bwd(net.down3, t.d3, g4, g3, below=t.d2.c3)
+    g2 = convd_bwd(net.down2, t.d2, g3, g2, below=t.d1.c3)
+    # mask_x: x1 came out of a ReLU (the teacher's fusion conv): its backward rides in the last kernel that writes g1;
+    # below_x1: x1 came out of a conv + BatchNorm + ReLU layer (the segmentation net's inc block)
+    g1 = convd_bwd(net.down1, t.d1, g2, g1, mask_x=mask_x is not None, below=below_x1)
     return g1 if need_dx1 else None
 
 

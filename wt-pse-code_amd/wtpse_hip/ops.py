@@ -423,6 +423,22 @@ def maxpool2_bwd(x, dout, dx, accumulate, pro=None, relu=False, mask=False):
     return dx
 
 
+def maxpool2_bwd_bnb(x, dout, dx, pro, relu, mean):
+    """maxpool2_bwd(mask=True) on the raw output of a conv + BatchNorm + ReLU layer that also forms the BatchNorm-backward
+    reductions of that layer.  -> (masked gradient, stats [nblk, C, 2]) or None when the shape is not supported."""
+    B, C, H, W = x.shape
+    if W % 4 or H % 2 or B * C >= 32768 or pro is None:
+        return None
+    L = lib()
+    acc = dx is not None
+    if dx is None:
+        dx = torch.empty_like(x)
+    stats = torch.empty((L.query("wtpse_maxpool2_bwd_stats_blocks", B, H, W), C, 2), dtype=torch.float32, device=x.device)
+    L.call("wtpse_maxpool2_bwd_bnb", ptr(x), ptr(pro), int(relu), ptr(dout), ptr(dx), int(acc), ptr(mean), ptr(stats), B, C, H, W,
+           stream_ptr())
+    return dx, stats
+
+
 def upsample2x_fwd(x, pro=None, relu=False):
     _chk(x, "x")
     B, C, H, W = x.shape
