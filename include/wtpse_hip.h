@@ -104,6 +104,8 @@ int wtpse_conv_fwd_bnf(const float* in0, int C0, const float* in1, int C1, const
  * arrives, the last group of an output-channel block folds the group sums (fixed order: bitwise reproducible, nobody waits) and
  * writes coef [Cbn][3] = (k1, k2, k3) and dgamma / dbeta (+)= (accumulate) of the BatchNorm'd channels — what
  * wtpse_bn_bwd_from_stats does in its first launch.  wtpse_bn_bwd_apply_coef is then the whole rest of the BatchNorm backward.
+ * (Launches of more than 2048 workgroups — WTPSE_TAIL_MAX_WGS — run that fold as a second launch inside the call instead: the
+ * hand-off costs every workgroup ~2.5 us of lifetime, which beats a 6 us launch only where a CU sees few workgroups.)
  * layout: 0 = wtpse_dgrad_bnb (fp32 `wd`), 1 = wtpse_dgrad_x3_bnb, 2 = wtpse_conv16_x3's fragments (Csplit == Cout, all channels).
  * gamma / invstd: of the BatchNorm'd channels.  partial2: wtpse_bnb_tail_partial2(nblk, Cout) doubles of scratch; tickets:
  * wtpse_bnb_tail_tickets(nblk, Cout) unsigneds, ZERO on entry and zero again when the launch has finished (nblk = rows of stats);
@@ -181,6 +183,11 @@ int wtpse_bn_bwd_from_stats(const float* g, const float* y, const float* stats_p
                             const float* save_mean, const float* save_invstd, float* coef, float* dgamma, float* dbeta,
                             int accumulate, float* dy, int B, int C, int HW, void* stream);
 
+/* partials [nblk][C][2] = (sum g, sum g (y - mean)) -> coef [C][3], dgamma / dbeta (+)=: the first launch of
+ * wtpse_bn_bwd_from_stats on its own. */
+int wtpse_bn_bwd_finalize_coef(const float* stats_partial, int nblk, int C, long long count, const float* gamma,
+                               const float* save_mean, const float* save_invstd, float* coef, float* dgamma, float* dbeta,
+                               int accumulate, void* stream);
 /* dy = k1 * g + k2 * y + k3 with coef [C][3] from wtpse_dgrad_bnb_coef. */
 int wtpse_bn_bwd_apply_coef(const float* g, const float* y, const float* coef, float* dy, int B, int C, int HW, void* stream);
 
@@ -296,8 +303,7 @@ int wtpse_head_fwd(const float* x, const float* pro, int pro_relu, const float* 
                    void* stream);
 /* dy: [B][nc][HW] (three layers) or [B][8][HW] (two layers: gradient of the h2 output).  dx: [B][32][HW] gradient wrt the
  * activated input.  dparams: [32*32 + 32 + 8*32 + 8 (+ 8*nc + nc)] = (dW1, db1, dW2, db2[, dW3, db3]) contiguous, which is
- * the order the head's parameters have in the flat gradient buffer; written, or added to when accumulate & 1.
- * accumulate & 2: dx += instead of dx = (a second head reading the same input).
+ * the order the head's parameters have in the flat gradient buffer; written, or added to when accumulate != 0.
  * slab: scratch of wtpse_head_slabs(B, HW) * that many floats. */
 int wtpse_head_bwd(const float* dy, const float* x, const float* pro, int pro_relu, const float* h1, const float* h2,
                    const float* w1, const float* w2, const float* w3, int nc, float* dx, float* slab, float* dparams,

@@ -408,6 +408,7 @@ def test_conv16_x3_bnb(case):
     (0, 3, 3, 0, 16, 24, 40, 3),        # fp32 16-channel path
     (0, 4, 8, 0, 40, 16, 32, 1),        # fp32 ragged channels
     (2, 20, 16, 0, 16, 64, 64, 3),      # 16-channel x3 fragments, 320 tiles -> 5 groups
+    (1, 33, 16, 0, 32, 128, 128, 3),    # 2112 workgroups: beyond WTPSE_TAIL_MAX_WGS the call runs the stand-alone finalize itself
 ])
 def test_conv_fwd_bnf(case):
     """A convolution that finishes its own BatchNorm statistics (last-arriver tickets) against conv + wtpse_bn_finalize: same output

@@ -353,12 +353,6 @@ def test_fused_head(case):
     close(dpar, want, rtol=2e-4, atol=2e-5 * max(scale, 1.0), what="head dparams")
     o.head_bwd(D(dy), D(x), D(pro), use_pro, h1d, h2d, D(w1), D(w2), D(w3), dpar, accumulate=True)
     close(dpar, 2 * want, rtol=2e-4, atol=4e-5 * max(scale, 1.0), what="head dparams accumulate")
-    # a second head on the same input adds its input gradient in place
-    into = rnd(B, 32, H, W, seed=71).to(DEV)
-    base = into.clone()
-    r = o.head_bwd(D(dy), D(x), D(pro), use_pro, h1d, h2d, D(w1), D(w2), D(w3), dpar, dx_into=into)
-    assert r is into
-    close(into, base.cpu() + xa.grad, what="dx accumulate")
 
 
 @pytest.mark.parametrize("shape", [(3, 8, 9, 11), (5, 2, 256, 256)])   # the second takes the many-row reduction of (dw, db)

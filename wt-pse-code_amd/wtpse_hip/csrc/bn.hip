@@ -422,6 +422,17 @@ extern "C" int wtpse_bn_bwd_from_stats(const float* g, const float* y, const flo
   return wtpse_status();
 }
 
+// The first launch of wtpse_bn_bwd_from_stats on its own: partials (sum g, sum g (y - mean)) -> coef (k1, k2, k3), dgamma, dbeta (+)=.
+// (wtpse_dgrad_bnb_coef uses it for launches with so many workgroups that folding inside the launch costs more than this.)
+extern "C" int wtpse_bn_bwd_finalize_coef(const float* stats_partial, int nblk, int C, long long count, const float* gamma,
+                                          const float* save_mean, const float* save_invstd, float* coef, float* dgamma,
+                                          float* dbeta, int accumulate, void* stream) {
+  WTPSE_REQUIRE(stats_partial && gamma && save_mean && save_invstd && coef && dgamma && dbeta && nblk > 0 && C > 0 && count > 0);
+  hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(C), dim3(256), 0, (hipStream_t)stream, stats_partial, nblk, C, (double)count, gamma,
+                     save_mean, save_invstd, dgamma, dbeta, accumulate, coef, (const float*)nullptr, (float*)nullptr, 1);
+  return wtpse_status();
+}
+
 // dy = k1 * g + k2 * y + k3 with the coefficients a data gradient's tail left in `coef` (wtpse_dgrad_bnb_coef): the whole
 // BatchNorm backward that remains once the reductions and their fold happened in the producing launch.
 extern "C" int wtpse_bn_bwd_apply_coef(const float* g, const float* y, const float* coef, float* dy, int B, int C, int HW,

@@ -116,23 +116,38 @@ __device__ __forceinline__ double pub_load(const double* p) {
 }
 __device__ __forceinline__ void pub_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-// The two-level fold.  The caller has written this workgroup's partials stats[tile][Cst][2] (channels [c_lo, c_hi) of the
-// launch's output, Cst = c_hi - c_lo) with pub_store().  -> true in the ONE workgroup of output-channel block `y` that arrives
-// last; there sh[2 * crel + k] holds the fp64 totals of the block's channels (threads tid < 2 CB: crel = tid >> 1, k = tid & 1).
-template <int CB>
-__device__ __forceinline__ bool tail_fold(double* partial2, unsigned* tickets, int ngroups, int ntiles, int ctot, int t2_off,
-                                          const float* stats, int c_lo, int c_hi, int cout0, int tile, int y, int tid, double* sh,
-                                          int* flag_s) {
-  static_assert(CB * 2 <= 256, "one thread per (channel, sum)");
-  const int Cst = c_hi - c_lo;
+// The two-level fold, in two halves so that the round trip of the first ticket (an L2 atomic: ~1-2 us, during which a workgroup
+// that waited for it right away held its CU slot idle — 9-19 % of the short 32-channel launches) hides behind the workgroup's output
+// stores: tail_begin() publishes the partials and ISSUES the ticket, the caller stores its tile, tail_fold() picks the ticket up.
+// The caller has written this workgroup's partials stats[tile][Cst][2] (channels [c_lo, c_hi) of the launch's output,
+// Cst = c_hi - c_lo) with pub_store().
+struct TailTicket {
+  unsigned old;      // thread 0: what the group's ticket counter held
+  int armed;         // uniform: this workgroup takes part
+};
+
+__device__ __forceinline__ TailTicket tail_begin(unsigned* tickets, int ngroups, int tile, int y, int tid) {
+  TailTicket tk;
+  tk.old = 0u;
+  tk.armed = 1;
   pub_drain();
   __syncthreads();
+  if (tid == 0)
+    tk.old = __hip_atomic_fetch_add(tickets + (size_t)y * ngroups + (tile >> 6), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return tk;
+}
+
+// -> true in the ONE workgroup of output-channel block `y` that arrives last; there sh[2 * crel + k] holds the fp64 totals of the
+// block's channels (threads tid < 2 CB: crel = tid >> 1, k = tid & 1).
+template <int CB>
+__device__ __forceinline__ bool tail_fold(const TailTicket& tk, double* partial2, unsigned* tickets, int ngroups, int ntiles, int ctot,
+                                          int t2_off, const float* stats, int c_lo, int c_hi, int cout0, int tile, int y, int tid,
+                                          double* sh, int* flag_s) {
+  static_assert(CB * 2 <= 256, "one thread per (channel, sum)");
+  const int Cst = c_hi - c_lo;
   const int grp = tile >> 6, g0 = grp << 6;
   const int gsize = min(64, ntiles - g0);
-  if (tid == 0) {
-    const unsigned old = __hip_atomic_fetch_add(tickets + (size_t)y * ngroups + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    *flag_s = old == (unsigned)(gsize - 1);
-  }
+  if (tid == 0) *flag_s = tk.old == (unsigned)(gsize - 1);
   __syncthreads();
   if (!*flag_s) return false;
   const int crel = tid >> 1, k = tid & 1, c = cout0 + crel;
@@ -182,11 +197,20 @@ __device__ __forceinline__ bool tail_fold(double* partial2, unsigned* tickets, i
 }
 
 template <int CB>
-__device__ __forceinline__ void bnb_tail(const BnbTail& tl, const float* stats, const float* __restrict__ bn_mean,
+__device__ __forceinline__ TailTicket bnb_tail_begin(const BnbTail& tl, int bn_c0, int bn_c1, int cout0, int tile, int y, int tid) {
+  TailTicket none;
+  none.old = 0u;
+  none.armed = 0;
+  if (tl.tickets == nullptr) return none;
+  if (cout0 >= bn_c1 || cout0 + CB <= bn_c0) return none;      // no BatchNorm'd channel in this block (uniform)
+  return tail_begin(tl.tickets, tl.ngroups, tile, y, tid);
+}
+
+template <int CB>
+__device__ __forceinline__ void bnb_tail(const TailTicket& tk, const BnbTail& tl, const float* stats, const float* __restrict__ bn_mean,
                                          int bn_c0, int bn_c1, int cout0, int tile, int y, int tid, double* sh, int* flag_s) {
-  if (tl.tickets == nullptr) return;
-  if (cout0 >= bn_c1 || cout0 + CB <= bn_c0) return;          // no BatchNorm'd channel in this block (uniform)
-  if (!tail_fold<CB>(tl.partial2, tl.tickets, tl.ngroups, tl.ntiles, tl.ctot, tl.t2_off, stats, bn_c0, bn_c1, cout0, tile, y, tid,
+  if (!tk.armed) return;
+  if (!tail_fold<CB>(tk, tl.partial2, tl.tickets, tl.ngroups, tl.ntiles, tl.ctot, tl.t2_off, stats, bn_c0, bn_c1, cout0, tile, y, tid,
                      sh, flag_s))
     return;
   const int c = cout0 + (tid >> 1);
@@ -224,11 +248,19 @@ struct BnfTail {
   int ngroups, ntiles, ctot, t2_off;
 };
 
+__device__ __forceinline__ TailTicket bnf_tail_begin(const BnfTail& tl, int tile, int y, int tid) {
+  TailTicket none;
+  none.old = 0u;
+  none.armed = 0;
+  if (tl.tickets == nullptr) return none;
+  return tail_begin(tl.tickets, tl.ngroups, tile, y, tid);
+}
+
 template <int CB>
-__device__ __forceinline__ void bnf_tail(const BnfTail& tl, const float* stats, int Cout, int cout0, int tile, int y, int tid,
-                                         double* sh, int* flag_s) {
-  if (tl.tickets == nullptr) return;
-  if (!tail_fold<CB>(tl.partial2, tl.tickets, tl.ngroups, tl.ntiles, tl.ctot, tl.t2_off, stats, 0, Cout, cout0, tile, y, tid, sh,
+__device__ __forceinline__ void bnf_tail(const TailTicket& tk, const BnfTail& tl, const float* stats, int Cout, int cout0, int tile,
+                                         int y, int tid, double* sh, int* flag_s) {
+  if (!tk.armed) return;
+  if (!tail_fold<CB>(tk, tl.partial2, tl.tickets, tl.ngroups, tl.ntiles, tl.ctot, tl.t2_off, stats, 0, Cout, cout0, tile, y, tid, sh,
                      flag_s))
     return;
   const int c = cout0 + (tid >> 1);
@@ -275,4 +307,32 @@ static inline BnfTail bnf_tail_none() {
 static inline void bnf_tail_geometry(BnfTail& t, int ntiles, int Cout, double count) {
   t.ntiles = ntiles; t.ngroups = bnb_tail_groups(ntiles); t.ctot = bnb_tail_ctot(Cout); t.t2_off = bnb_tail_t2off(ntiles, Cout);
   t.count = count;
+}
+
+// Folding the statistics inside the launch makes every workgroup live ~2.5 us longer (its partials must be visible before it takes
+// its ticket: store acknowledgement + one L2 atomic round trip).  Measured on the step (back to back, profiles/r03_*): with the
+// fold in every launch the convolutions took 2.4 ms more per step than the 346 finalize launches it replaced took (2.2 ms).  A CU
+// slot sees nWG / (256 x 2..3) workgroups in a row, so the hand-off wins where that is about one or less; beyond the threshold the
+// entry points launch the stand-alone finalize kernel themselves.
+#include <cstdlib>
+static inline bool tail_in_launch(long long workgroups) {
+  static const long long max_wgs = [] { const char* e = getenv("WTPSE_TAIL_MAX_WGS"); return e ? atoll(e) : 2048ll; }();
+  return workgroups <= max_wgs;
+}
+extern "C" int wtpse_bn_finalize(const float* stats_partial, int nblk, int C, long long count, const float* gamma, const float* beta,
+                                 float* running_mean, float* running_var, long long* num_batches, float momentum, float eps,
+                                 float* scale_shift, float* save_mean, float* save_invstd, void* stream);
+extern "C" int wtpse_bn_bwd_finalize_coef(const float* stats_partial, int nblk, int C, long long count, const float* gamma,
+                                          const float* save_mean, const float* save_invstd, float* coef, float* dgamma,
+                                          float* dbeta, int accumulate, void* stream);
+// after a launch whose tails were switched off for size: the same results from the stand-alone kernels
+static inline int tail_after_launch(const BnbTail& tl, const BnfTail& fl, float* stats, int nblk, int Cout, int bn_c0, int bn_c1,
+                                    const float* bn_mean, long long count, void* stream) {
+  if (tl.tickets)
+    return wtpse_bn_bwd_finalize_coef(stats, nblk, bn_c1 - bn_c0, count, tl.gamma, bn_mean, tl.invstd, tl.coef, tl.dgamma, tl.dbeta,
+                                      tl.accumulate, stream);
+  if (fl.tickets)
+    return wtpse_bn_finalize(stats, nblk, Cout, count, fl.gamma, fl.beta, fl.rmean, fl.rvar, fl.nbt, fl.momentum, fl.eps,
+                             fl.scale_shift, fl.save_mean, fl.save_invstd, stream);
+  return 0;
 }

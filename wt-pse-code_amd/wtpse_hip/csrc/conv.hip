@@ -453,6 +453,9 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
     }
   }
   const unsigned hw4 = (unsigned)HW * 4u;
+  // a launch that folds its own statistics publishes them and takes its tickets BEFORE it stores its output tile (see conv_x3.hip:
+  // the hand-off drains the workgroup's outstanding stores); the values to store stay in the accumulators
+  const bool defer = want_stats && (BNB ? a.tail.tickets != nullptr : a.ftail.tickets != nullptr);
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     float mk[NACC][NT];
@@ -504,7 +507,7 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
           if (!(zz > 0.f)) v = 0.f;
           acc[mt][nt][r] = v;
         }
-        buf_store(rs_o, pvo[nt], soff, v);
+        if (!defer) buf_store(rs_o, pvo[nt], soff, v);
       }
     }
     if (want_stats) {
@@ -571,11 +574,31 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
         pub_store(a.stats + ((size_t)blockIdx.x * a.Cout + cout0 + crel) * 2 + (tid & 1), s);
       }
     }
+  }
+  TailTicket tk;
+  tk.old = 0u;
+  tk.armed = 0;
+  if (defer) {
+    if constexpr (BNB) tk = bnb_tail_begin<CB>(a.tail, a.bn_c0, a.bn_c1, cout0, (int)blockIdx.x, (int)blockIdx.y, tid);
+    else tk = bnf_tail_begin(a.ftail, (int)blockIdx.x, (int)blockIdx.y, tid);
+  }
+  if (defer) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < NACC; ++r) {
+        const int cbase = cout0 + (P16 ? r : (mt * 32 + (r & 3) + 8 * (r >> 2)));
+        const bool second = a.out1 != nullptr && cbase >= a.Csplit;
+        const __amdgpu_buffer_rsrc_t rs_o = second ? rs_o1 : rs_o0;
+        const unsigned soff = (unsigned)(second ? min(cbase, a.Cout) - a.Csplit : min(cbase, a.Csplit)) * hw4;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) buf_store(rs_o, pvo[nt], soff, fmaxf(acc[mt][nt][r], relu_lo));
+      }
     if constexpr (BNB)
-      bnb_tail<CB>(a.tail, a.stats, a.bn_mean, a.bn_c0, a.bn_c1, cout0, (int)blockIdx.x, (int)blockIdx.y, tid,
+      bnb_tail<CB>(tk, a.tail, a.stats, a.bn_mean, a.bn_c0, a.bn_c1, cout0, (int)blockIdx.x, (int)blockIdx.y, tid,
                    reinterpret_cast<double*>(red), reinterpret_cast<int*>(red + 4 * CB));
     else
-      bnf_tail<CB>(a.ftail, a.stats, a.Cout, cout0, (int)blockIdx.x, (int)blockIdx.y, tid, reinterpret_cast<double*>(red),
+      bnf_tail<CB>(tk, a.ftail, a.stats, a.Cout, cout0, (int)blockIdx.x, (int)blockIdx.y, tid, reinterpret_cast<double*>(red),
                    reinterpret_cast<int*>(red + 4 * CB));
   }
   STAMP(61);
@@ -590,13 +613,18 @@ static int launch_fwd(const ConvArgs& a, hipStream_t st) {
   args.tiles_x = ceil_div(a.W, TW);
   args.tiles_y = ceil_div(a.H, TH);
   dim3 grid((unsigned)(a.B * args.tiles_x * args.tiles_y), (unsigned)ceil_div(a.CoutP, CB));
+  const bool in_launch = tail_in_launch((long long)grid.x * grid.y);     // else: the stand-alone finalize kernel behind the launch
+  if (!in_launch) args.tail.tickets = args.ftail.tickets = nullptr;
   if (args.tail.tickets) bnb_tail_geometry(args.tail, (int)grid.x, a.Cout, (double)a.B * a.H * a.W);
   if (args.ftail.tickets) bnf_tail_geometry(args.ftail, (int)grid.x, a.Cout, (double)a.B * a.H * a.W);
   if (narrow)
     hipLaunchKernelGGL((conv_fwd_k<KS, MODE, 4, DB, EPI>), grid, dim3(256), 0, st, args);
   else
     hipLaunchKernelGGL((conv_fwd_k<KS, MODE, 5, DB, EPI>), grid, dim3(256), 0, st, args);
-  return wtpse_status();
+  int rc = wtpse_status();
+  if (rc == 0 && !in_launch)
+    rc = tail_after_launch(a.tail, a.ftail, a.stats, (int)grid.x, a.Cout, a.bn_c0, a.bn_c1, a.bn_mean, (long long)a.B * a.H * a.W, st);
+  return rc;
 }
 
 static int fwd_tiles(int B, int H, int W) {

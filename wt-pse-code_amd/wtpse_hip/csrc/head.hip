@@ -28,7 +28,6 @@ struct HeadArgs {
   const float* dy;     // backward: [B][nc][HW] (three layers) or [B][8][HW] (two layers)
   float* dx;           // backward: [B][32][HW] gradient wrt the activated input
   float* slab;         // backward: [gridDim.x][NS] partial weight gradients
-  int dx_add;          // backward: dx += (a second head on the same input: no separate add pass over the 32-channel map)
   int B, HW, nblk;     // nblk = B*HW/32 pixel blocks
 };
 
@@ -219,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void head_bwd_k(HeadArgs a) {
     {
       float* db = a.dx + (size_t)b * 32 * HW + p;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) db[(size_t)rho(r, u) * HW] = a.dx_add ? db[(size_t)rho(r, u) * HW] + acc4[r] : acc4[r];
+      for (int r = 0; r < 16; ++r) db[(size_t)rho(r, u) * HW] = acc4[r];
     }
     // weight gradients: pixels from lanes to the K dimension through the wave-private LDS tiles
 #pragma unroll
@@ -342,8 +341,6 @@ extern "C" int wtpse_head_bwd(const float* dy, const float* x, const float* pro,
   a.x = x; a.pro = pro; a.pro_relu = pro_relu; a.w1 = w1; a.w2 = w2; a.w3 = w3; a.nc = w3 ? nc : 0;
   a.h1 = const_cast<float*>(h1); a.h2 = const_cast<float*>(h2); a.dy = dy; a.dx = dx; a.slab = slab;
   a.B = B; a.HW = HW; a.nblk = B * (HW / 32);
-  a.dx_add = (accumulate & 2) != 0;
-  accumulate &= 1;
   const int g = head_grid(a.nblk);
   hipStream_t st = (hipStream_t)stream;
   if (w3) hipLaunchKernelGGL(head_bwd_k<true>, dim3(g), dim3(256), 0, st, a);

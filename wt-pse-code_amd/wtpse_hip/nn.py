@@ -876,8 +876,8 @@ def head_fwd(seq, x, idxs, want_tape=True):
     return h, t
 
 
-def head_bwd(seq, t, d, idxs, dx_into=None):
-    """-> gradient wrt the activated head input (added to `dx_into` if given: a second head on the same input)."""
+def head_bwd(seq, t, d, idxs):
+    """-> gradient wrt the activated head input."""
     if t.fused:
         ls = [seq[i] for i in idxs]
         root = ls[0]._root
@@ -886,16 +886,13 @@ def head_bwd(seq, t, d, idxs, dx_into=None):
         off = root._offsets[root._pindex[id(ls[0].weight)]]
         dparams = root._gtarget[off:off + total]
         return ops.head_bwd(d, t.x.t, t.x.pro, t.x.relu, t.h1, t.h2, ls[0].weight, ls[1].weight,
-                            ls[2].weight if len(ls) == 3 else None, dparams, dx_into=dx_into)
+                            ls[2].weight if len(ls) == 3 else None, dparams)
     for n in reversed(range(len(idxs))):
         layer = seq[idxs[n]]
         inp = t.x if n == 0 else t.acts[n - 1]
         _wgrad(layer, d, inp)
         # the ReLU backward of the activation below rides in this data gradient's epilogue
         d, _ = _dgrad(layer, d, mask_ref=(t.acts[n - 1] if n > 0 else None))
-    if dx_into is not None:
-        ops.axpy(dx_into, d)
-        return dx_into
     return d
 
 
@@ -970,7 +967,10 @@ def teacher_bwd(tn, t, dmu, dlogvar):
     """-> gradient wrt the activated feat (i.e. wrt relu(z2) when feat carries ReLU-on-load)."""
     d = head_bwd(tn.mu_prior, t.hmu, dmu, (0, 2, 4))
     if dlogvar is not None:
-        head_bwd(tn.logvar_prior, t.hlv, dlogvar, (0, 2, 4), dx_into=d)
+        # (adding the second head's input gradient inside its kernel was measured: the loads in front of the stores cost the
+        # MFMA-bound kernel 290 us, the separate 16-byte add 120)
+        d2 = head_bwd(tn.logvar_prior, t.hlv, dlogvar, (0, 2, 4))
+        ops.axpy(d, d2)
     dxf = unet_bwd(tn, t.unet, d, mask_x=t.xf)      # the ReLU of the fusion conv rides in the last data gradient's epilogue
     _wgrad(tn.fusion[0], dxf, t.m2, t.feat)
     dm2, dfeat = _dgrad(tn.fusion[0], dxf, split=t.m2.t.shape[1], below0=t.i3)

@@ -510,7 +510,7 @@ def head_fwd(x, pro, relu, w1, b1, w2, b2, w3, b3, want_tape=True):
     return (y if three else h2), h1, h2
 
 
-def head_bwd(dy, x, pro, relu, h1, h2, w1, w2, w3, dparams, accumulate=False, dx_into=None):
+def head_bwd(dy, x, pro, relu, h1, h2, w1, w2, w3, dparams, accumulate=False):
     """-> dx (gradient wrt the activated input); the parameter gradients land in `dparams`, the contiguous flat-buffer
     range (dW1, db1, dW2, db2[, dW3, db3])."""
     _chk(dy, "dy"); _chk(x, "x"); _chk(h1, "h1"); _chk(h2, "h2")
@@ -520,9 +520,9 @@ def head_bwd(dy, x, pro, relu, h1, h2, w1, w2, w3, dparams, accumulate=False, dx
     ns = 1024 + 32 + 256 + 8 + 9 * nc
     assert dparams.numel() == ns and dparams.is_contiguous()
     slab = workspace("head_slab", L.query("wtpse_head_slabs", B, H * W) * ns, x.device)
-    dx = torch.empty_like(x) if dx_into is None else dx_into          # dx_into: add this head's input gradient to it
+    dx = torch.empty_like(x)
     L.call("wtpse_head_bwd", ptr(dy), ptr(x), ptr(pro), int(bool(relu)), ptr(h1), ptr(h2), ptr(w1), ptr(w2), ptr(w3), nc,
-           ptr(dx), ptr(slab), ptr(dparams), int(bool(accumulate)) | (2 if dx_into is not None else 0), B, H * W, stream_ptr())
+           ptr(dx), ptr(slab), ptr(dparams), int(accumulate), B, H * W, stream_ptr())
     return dx
 
 
