@@ -40,8 +40,8 @@ GFLOP_PER_IMAGE = 224.5      # SURVEY.md §8d / BASELINE.md §5: necessary conv 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="images per GPU")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--workload", choices=["full", "seg"], default="full",

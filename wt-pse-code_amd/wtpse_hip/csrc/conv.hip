@@ -165,6 +165,20 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
     float xv[NIT][8];
     int ipos[NIT], ihalf[NIT];
     bool iin[NIT];
+    // prologue coefficients of the two channel halves: fetched (scalar loads, the half of an item is wave-uniform) in front of the
+    // tile loads, so that their latency is not paid where they are used (conv_x3.hip: the same pattern cost the forward kernel 9 %;
+    // here: 116 -> 106 us with prologue + statistics).  Tried on this path and dropped, no gain either way: 16-byte tile loads (a
+    // thread takes four columns of eight channels: 94 vs 88-94 us) and one MFMA per pixel tile and cross term instead of six
+    // dependent ones per tile (98 vs 94) — the workgroup's phases (load, convert, multiply, epilogue) add up per SIMD.
+    float psc[2][8], psh[2][8];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int cg = min(hh * 8 + j, a.C0 - 1);
+        psc[hh][j] = a.pro0 ? a.pro0[2 * cg] : 1.f;
+        psh[hh][j] = a.pro0 ? a.pro0[2 * cg + 1] : 0.f;
+      }
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
       const int blk = __builtin_amdgcn_readfirstlane(i * 4 + wave);
@@ -192,8 +206,7 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
       for (int i = 0; i < NIT; ++i)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const int cg = min(ihalf[i] * 8 + j, a.C0 - 1);
-          const float sc = a.pro0 ? a.pro0[2 * cg] : 1.f, sh = a.pro0 ? a.pro0[2 * cg + 1] : 0.f;
+          const float sc = ihalf[i] ? psc[1][j] : psc[0][j], sh = ihalf[i] ? psh[1][j] : psh[0][j];
           float v = fmaf(xv[i][j], sc, sh);
           if (relu) v = fmaxf(v, 0.f);
           xv[i][j] = (iin[i] && ihalf[i] * 8 + j < a.C0) ? v : 0.f;
