@@ -136,12 +136,13 @@ def conv_fwd_x3(in0, in1, wpacked_ptr, bias, cout, ksize, pro0=None, pro_relu=0,
 
 
 _TICKETS = {}
-_TICKET_RING = 1 << 21      # unsigneds: ~900 launches of the largest layer before a slice comes round again
+_TICKET_RING = 1 << 22      # unsigneds (16 MB): ~1900 launches of the largest layer (5 training steps) before a slice comes round again; the
+                            # streams of a step are joined at its end, so two users of a slice never run at the same time
 
 
 def _tickets(n, device):
     """n zeroed unsigneds for a launch that leaves them zeroed (include/wtpse_hip.h: wtpse_dgrad_bnb_coef).  Slices of one ring per
-    device: a slice is handed out again only after ~900 further launches, long after its launch has finished; launches recorded in
+    device: a slice is handed out again only after ~1900 further launches, long after its launch has finished; launches recorded in
     a launch plan keep theirs."""
     st = _TICKETS.get(device)
     if st is None:
