@@ -1,7 +1,7 @@
 #!/bin/bash
 # One gpurun call's worth of profiling for a round (run from the repo root on the GPU box):
 #   bash tools/profile_round.sh gpurun_out/r02prof
-# in-step and kernels-only rocprofv3 kernel statistics, HBM-traffic and MFMA-busy PMC passes (each in its own run, as the
+# in-step (three streams, and back to back on one stream: the profile to read kernel costs from) and kernels-only rocprofv3 kernel statistics, HBM-traffic and MFMA-busy PMC passes (each in its own run, as the
 # MI355X guide prescribes), the per-layer microbenchmarks.  Copy what should be judged into profiles/.
 set -o pipefail
 OUT=${1:-gpurun_out/prof}
@@ -9,6 +9,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 B="python3 bench.py"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/step" -o step -- $B --steps 7 --warmup 2 --no-cpu-baseline --no-kernel-roofline > "$OUT/step.log" 2>&1 &&
+WTPSE_WGRAD_STREAM=0 WTPSE_TEACHER_STREAM=0 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/single" -o step -- $B --steps 7 --warmup 2 --no-cpu-baseline --no-kernel-roofline > "$OUT/single.log" 2>&1 &&
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/ko" -o ko -- $B --kernels-only > "$OUT/ko.log" 2>&1 &&
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_f" -o f -- $B --kernels-only > "$OUT/pmc_f.log" 2>&1 &&
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_w" -o w -- $B --kernels-only > "$OUT/pmc_w.log" 2>&1 &&
