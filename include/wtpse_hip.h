@@ -56,6 +56,10 @@ int wtpse_conv_fwd_gram(const float* in0, int C0, const float* wpacked, const fl
  * conv and direction ceil16(K) * ceil32(rows) * taps * 3 unsigned shorts (forward: rows = Cout, K = Cin; data gradient:
  * rows = Cin, K = Cout), layout [K chunk 16][row block 32][tap][term 3][k half 2][row 32][8 k]. */
 int wtpse_conv_x3_stats_blocks(int B, int H, int W, int Cout);   /* rows of `stats` for wtpse_conv_fwd_x3 */
+/* 3x3 launches of the x3 entry points run conv_x3r_k (weights fed from registers, input tile double-buffered in LDS) when on = 1
+ * (default; environment WTPSE_X3R=0 turns it off) and conv_x3_k (weights staged through LDS) when on = 0; on < 0 only queries.
+ * Returns the previous setting.  The two kernels give bitwise the same results (tests/test_conv_x3_gpu.py). */
+int wtpse_x3r_enable(int on);
 int wtpse_pack_conv_weights_x3(const float* params, const int* desc, int n_desc, unsigned short* packed, void* stream);
 int wtpse_conv_fwd_x3(const float* in0, int C0, const float* in1, int C1, const unsigned short* wpacked, const float* bias,
                       const float* pro0, const float* pro1, int pro_relu, float* out0, float* out1, int Csplit, float* stats,

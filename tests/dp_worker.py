@@ -111,6 +111,55 @@ def gpu_exact(rank, world, port, out_dir, B_g, pb_g, H):
     dist.destroy_process_group()
 
 
+def gpu_ddp_overlap(rank, world, port, out_dir, B_g, pb_g, H):
+    """GPU (all ranks share cuda:0, gloo transport), throughput (DDP) mode: one TrainStep with the gradient exchange started INSIDE
+    the backward (dp.bucket_ready from an issue stream behind the weight-gradient streams), one with the single exchange between
+    backward and Adam, one captured as HIP graphs (graph=True: the collectives must stay between the captured stretches).  All three
+    must leave bitwise the same parameters: the exchange adds the same numbers in the same order whatever its timing."""
+    import torch
+    import torch.distributed as dist
+    from wtpse_hip.dp import DataParallel, local_rows
+    from wtpse_hip.step import TrainStep
+    from oracle.inputs import make_inputs
+    from test_parity_gpu import build_nets, HP
+    _init(rank, world, port)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    n_l = pb_g // world
+    rows = local_rows(pb_g, 3, world, rank)
+    img, od, oc = make_inputs(600, B_g, H, H)
+    x, m, c = img[rows].to(dev).contiguous(), od[rows].to(dev).contiguous(), oc[rows].to(dev).contiguous()
+    res = {}
+    params = {}
+    for tag, overlap, graph in (("overlap", True, False), ("single", False, False), ("graph", True, True)):
+        nets = build_nets(n_l)
+        for n in nets:
+            n.seed_noise(55)
+        dpm = DataParallel(world, rank, dev, bn_sync=False, overlap=overlap)
+        ts = TrainStep(*nets, HP, dp=dpm, graph=graph)
+        pieces_seen = [0]
+        if overlap and not graph:
+            orig = dpm.bucket_ready
+
+            def counting(net, gflat, lo, hi, streams=(), _o=orig):
+                pieces_seen[0] += 1
+                return _o(net, gflat, lo, hi, streams)
+            dpm.bucket_ready = counting
+        for _ in range(2):
+            lo = ts.step(x, m, c)
+        torch.cuda.synchronize()
+        res["losses_" + tag] = {k: float(v) for k, v in lo.items()}
+        res["pieces_" + tag] = pieces_seen[0]
+        params[tag] = [n.flat_params().detach().cpu().clone() for n in nets]
+        ts.close()
+    res["params"] = params["overlap"]
+    res["overlap_equals_single"] = all(bool(torch.equal(a, b)) for a, b in zip(params["overlap"], params["single"]))
+    res["graph_equals_single"] = all(bool(torch.equal(a, b)) for a, b in zip(params["graph"], params["single"]))
+    torch.save(res, os.path.join(out_dir, "r%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def nccl_rccl(rank, world, port, out_dir, B_g, pb_g, H):
     """RCCL leg (backend "nccl"), one GPU per rank: all-reduce AVG, broadcast_params, the exact-mode calls A/B of
     gpu_exact, and one TrainStep in each mode.  world = 1 runs it on a single GPU (the collectives still go through
@@ -198,5 +247,7 @@ if __name__ == "__main__":
         host_buckets(rank, world, port, out_dir)
     elif fn == "nccl":
         nccl_rccl(rank, world, port, out_dir, *[int(a) for a in sys.argv[6:9]])
+    elif fn == "ddp_overlap":
+        gpu_ddp_overlap(rank, world, port, out_dir, *[int(a) for a in sys.argv[6:9]])
     else:
         gpu_exact(rank, world, port, out_dir, *[int(a) for a in sys.argv[6:9]])

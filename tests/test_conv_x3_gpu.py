@@ -458,3 +458,63 @@ def test_conv_fwd_bnf(case):
                 assert torch.equal(a, b), "launch %d differs" % it
     torch.cuda.synchronize()
     assert all(int(t[0].abs().sum()) == 0 for t in o._TICKETS.values()), "tickets must be left at zero"
+
+
+X3R_CASES = [
+    # B, C0, C1, Cout, H, W: every tile shape of conv_x3r_k (2 x 2 waves / 1 x 4 waves, 32- and 16-wide tiles, 128-pixel tiles)
+    (20, 32, 32, 64, 32, 64),      # WM 2, 32-wide tiles, concat, two chunks per input
+    (20, 64, 0, 64, 32, 32),       # WM 2, four chunks
+    (36, 64, 0, 128, 16, 16),      # WM 2, 16-wide tiles
+    (2, 16, 16, 32, 24, 48),       # WM 1, ragged 8x32 tiles
+    (2, 40, 0, 96, 12, 20),        # WM 1, ragged chunk, three cout blocks
+    (2, 128, 0, 64, 16, 16),       # WM 1, 128-pixel tiles (few workgroups on a 16-wide map)
+    (3, 16, 0, 32, 40, 72),        # a single chunk (the prefetch runs past the end)
+]
+
+
+@pytest.mark.parametrize("case", X3R_CASES)
+def test_x3r_equals_x3(case):
+    """conv_x3r_k (weights fed from registers, double-buffered input tile; the default for 3x3) against conv_x3_k (weights staged in
+    LDS): same products in the same order on every accumulator, so every output — result, BatchNorm partials, masked data gradient,
+    BatchNorm-backward epilogue — must be BITWISE equal.  All other x3 tests run the default kernel against stock PyTorch."""
+    o = ops()
+    B, C0, C1, Co, H, W = case
+    dev = DEV
+    x0 = rnd(B, C0, H, W, seed=31).to(dev)
+    x1 = rnd(B, C1, H, W, seed=32).to(dev) if C1 else None
+    w = rnd(Co, C0 + C1, 3, 3, seed=33, scale=0.2)
+    b = rnd(Co, seed=34).to(dev)
+    pro = torch.stack([rnd(C0 + C1, seed=35) * 0.5 + 1.0, rnd(C0 + C1, seed=36)], 1).contiguous().to(dev)
+    pro0, pro1 = pro[:C0].contiguous(), (pro[C0:].contiguous() if C1 else None)
+    dy = rnd(B, Co, H, W, seed=37).to(dev)
+    ref_act = rnd(B, C0 + C1, H, W, seed=38).to(dev)
+    bn_y = rnd(B, C0, H, W, seed=39).to(dev)
+    bn_ss = torch.stack([rnd(C0, seed=40) * 0.3 + 1.0, rnd(C0, seed=41) * 0.2], 1).contiguous().to(dev)
+    bn_mean = (rnd(C0, seed=42) * 0.1).to(dev)
+    packed, xf, xd = pack_x3(w)
+
+    def run():
+        outs = []
+        y, _, st = o.conv_fwd_x3(x0, x1, packed.data_ptr() + 2 * xf, b, Co, 3, pro0, 1, want_stats=True, pro1=pro1)
+        outs += [y, st]
+        outs.append(o.conv_fwd_x3(x0, x1, packed.data_ptr() + 2 * xf, None, Co, 3, relu_out=True)[0])
+        d0, d1, _ = o.conv_fwd_x3(dy, None, packed.data_ptr() + 2 * xd, None, C0 + C1, 3, split=(C0 if C1 else None))
+        outs += [d0] + ([d1] if C1 else [])
+        if not C1:
+            outs.append(o.conv_fwd_x3(dy, None, packed.data_ptr() + 2 * xd, None, C0, 3, mask_ref=ref_act)[0])
+        if C0 % 16 == 0:
+            g0, g1, st, _ = o.dgrad_bnb(dy, packed.data_ptr() + 2 * xd, 1, C0 + C1, 3, bn_y, bn_ss, bn_mean, True,
+                                        split=(C0 if C1 else None))
+            outs += [g0, st] + ([g1] if C1 else [])
+        torch.cuda.synchronize()
+        return outs
+
+    assert o.lib().query("wtpse_x3r_enable", -1) == 1, "conv_x3r_k must be the default"
+    new = run()
+    o.lib().query("wtpse_x3r_enable", 0)
+    try:
+        old = run()
+    finally:
+        o.lib().query("wtpse_x3r_enable", 1)
+    for i, (a_, b_) in enumerate(zip(new, old)):
+        assert torch.equal(a_, b_), "output %d differs: max |d| = %g" % (i, float((a_ - b_).abs().max()))

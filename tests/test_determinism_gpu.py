@@ -82,33 +82,56 @@ def test_captured_step_equals_eager_step(mode):
         assert torch.equal(x, y)
 
 
+def _pack_x16(o, w):
+    """OIHW 16x16x3x3 -> (buffer, forward offset, data-gradient offset) through wtpse_pack_conv16_x3 (csrc/conv.hip MODE 3)."""
+    from test_kernels_gpu import DEV
+    packed = torch.zeros(2 * o.X16_SIZE, dtype=torch.int16, device=DEV)
+    desc = torch.tensor([0, w.shape[0], w.shape[1], 9, 0, o.X16_SIZE, 0, 0], dtype=torch.int32, device=DEV)
+    o.lib().call("wtpse_pack_conv16_x3", w.reshape(-1).contiguous().to(DEV).data_ptr(), desc.data_ptr(), 1, packed.data_ptr(), o.stream_ptr())
+    return packed, 0, o.X16_SIZE
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("x3,C,H,W,k", [(True, 64, 32, 64, 3), (True, 32, 16, 32, 3), (True, 128, 8, 8, 1), (False, 16, 32, 64, 3),
-                                        (False, 32, 16, 32, 3)])
-def test_dgrad_bnb_repeatable(x3, C, H, W, k):
-    """The data gradient with the BatchNorm-backward epilogue, 150 launches on the same operands with the allocator's blocks
+@pytest.mark.parametrize("layout,C,H,W,k,B", [
+    (1, 64, 32, 64, 3, 20), (1, 32, 16, 32, 3, 8), (1, 128, 8, 8, 1, 8), (0, 16, 32, 64, 3, 20), (0, 32, 16, 32, 3, 8),
+    (2, 16, 32, 64, 3, 20),       # the 16-channel x3 kernel (csrc/conv.hip MODE 3): the sibling epilogue of the round-3 finding
+    (2, 16, 256, 256, 3, 8),      # ... on the maps it runs on in a step (2048 workgroups)
+    (1, 64, 128, 128, 3, 32),     # the benchmark's batch: 2048 workgroups — the largest launch that folds its own statistics
+    (1, 32, 256, 256, 3, 32),     # 8192 workgroups: beyond the threshold, the stand-alone finalize kernel behind the launch
+])
+def test_dgrad_bnb_repeatable(layout, C, H, W, k, B):
+    """The data gradient with the BatchNorm-backward epilogue, repeated on the same operands with the allocator's blocks
     dirtied in between: masked gradient and partials must come out bit-identical every time.  (Round 3 found a form of this
     epilogue — the two ReLU decisions of a register fused into one v_pk_fma_f32 — whose masks were wrong for a few lanes in
-    ~10 % of the launches; this is the regression test.)"""
+    ~10 % of the launches; this is the regression test, for all three kernels that carry the epilogue and for the step's largest
+    launches.)"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from test_kernels_gpu import rnd, ops, pack, DEV
     from test_conv_x3_gpu import pack_x3
     o = ops()
-    B = 20 if H * W >= 2048 else 8
+    big = B * H * W >= (1 << 20)
     y = rnd(B, C, H, W, seed=41).to(DEV)
     du = rnd(B, C, H, W, seed=42).to(DEV)
     w = rnd(C, C, k, k, seed=43, scale=0.2)
     ss = torch.stack([rnd(C, seed=44) * 0.2 + 1.0, rnd(C, seed=45) * 0.3], 1).contiguous().to(DEV)
     mean = (rnd(C, seed=46) * 0.1).to(DEV)
-    if x3:
+    x3 = layout
+    if layout == 1:
         packed, _, xd = pack_x3(w)
+        wptr = packed.data_ptr() + 2 * xd
+    elif layout == 2:
+        packed, _, xd = _pack_x16(o, w)
         wptr = packed.data_ptr() + 2 * xd
     else:
         packed, _, wd = pack(w)
         wptr = packed.data_ptr() + 4 * wd
     g0, _, st0, _ = o.dgrad_bnb(du, wptr, x3, C, k, y, ss, mean, True)
     g0, st0 = g0.clone(), st0.clone()
-    for it in range(150):
+    # the masks against the forward pass's own decision, computed the way the forward computes it (one fmaf per element)
+    act = torch.addcmul(ss[:, 1].view(1, -1, 1, 1), y, ss[:, 0].view(1, -1, 1, 1))
+    assert int(((g0 != 0) & ~(act > 0)).sum()) == 0, "a masked-out element carries a gradient"
+    del act
+    for it in range(40 if big else 150):
         junk = torch.empty((1 << 22) + 4096 * it, device=DEV).fill_(float(it))
         g, _, st, _ = o.dgrad_bnb(du, wptr, x3, C, k, y, ss, mean, True)
         assert torch.equal(g, g0), "launch %d: %d masked-gradient elements differ" % (it, int((g != g0).sum()))
@@ -119,7 +142,7 @@ def test_dgrad_bnb_repeatable(x3, C, H, W, k):
     gamma = (rnd(C, seed=47) * 0.2 + 1.0).to(DEV)
     invstd = (rnd(C, seed=48).abs() + 0.5).to(DEV)
     ref = None
-    for it in range(100):
+    for it in range(30 if big else 100):
         junk = torch.empty((1 << 22) + 4096 * it, device=DEV).fill_(float(it))
         dg, db = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
         g, _, st, coef = o.dgrad_bnb(du, wptr, x3, C, k, y, ss, mean, True, tail=(gamma, invstd, dg, db))
@@ -155,4 +178,30 @@ def test_wgrad_r_repeatable(Cin, Cout, H, W, bias):
         assert torch.equal(dw, dw0), "launch %d: %d weight-gradient elements differ" % (it, int((dw != dw0).sum()))
         if bias:
             assert torch.equal(db, db0), "launch %d: bias gradient differs" % it
+        del junk
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,C,H,W", [(8, 32, 32, 64), (32, 16, 256, 256)])
+def test_maxpool_bwd_bnb_repeatable(B, C, H, W):
+    """The max-pool backward that also applies the ReLU mask of the conv + BatchNorm layer below and forms its BatchNorm-backward
+    reductions (csrc/pointwise.hip: the third carrier of the ReLU decision `fmaf(y, scale, shift) > 0`): repeated launches on the
+    same operands give the same bits, and the mask equals the forward pass's decision."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_kernels_gpu import rnd, ops, DEV
+    o = ops()
+    x = rnd(B, C, H, W, seed=61).to(DEV)
+    dout = rnd(B, C, H // 2, W // 2, seed=62).to(DEV)
+    pro = torch.stack([rnd(C, seed=63) * 0.2 + 1.0, rnd(C, seed=64) * 0.3], 1).contiguous().to(DEV)
+    mean = (rnd(C, seed=65) * 0.1).to(DEV)
+    r = o.maxpool2_bwd_bnb(x, dout, None, pro, True, mean)
+    assert r is not None
+    g0, st0 = r[0].clone(), r[1].clone()
+    act = torch.addcmul(pro[:, 1].view(1, -1, 1, 1), x, pro[:, 0].view(1, -1, 1, 1))
+    assert int(((g0 != 0) & ~(act > 0)).sum()) == 0
+    for it in range(60):
+        junk = torch.empty((1 << 22) + 4096 * it, device=DEV).fill_(float(it))
+        g, st = o.maxpool2_bwd_bnb(x, dout, None, pro, True, mean)
+        assert torch.equal(g, g0), "launch %d: %d elements differ" % (it, int((g != g0).sum()))
+        assert torch.equal(st, st0), "launch %d: partials differ" % it
         del junk

@@ -120,6 +120,21 @@ def test_exact_mode_matches_single_device(tmp_path):
             assert torch.allclose(rk["bufs"][k].float(), v.cpu().float(), rtol=1e-4, atol=1e-5), k
 
 
+def test_overlapped_ddp_step_world2(tmp_path):
+    """The DEFAULT multi-GPU path of bench.py (eager launches, throughput mode, gradient all-reduces started inside the backward)
+    with two ranks sharing the test box's GPU over gloo: bitwise the parameters of the non-overlapped exchange, also when the step is
+    captured as HIP graphs (the in-backward announcements must then stay out of the capture: ADVICE r03), and identical on both
+    ranks.  RCCL itself still needs two GPUs (test_rccl_world2); this pins the host logic, the stream order and the capture guard."""
+    res = run_workers("ddp_overlap", 2, tmp_path, extra=(B_G, PB_G, 32), timeout=900)
+    for rk in res:
+        assert rk["overlap_equals_single"] and rk["graph_equals_single"], (rk["overlap_equals_single"], rk["graph_equals_single"])
+        assert rk["pieces_overlap"] >= 8, rk["pieces_overlap"]          # the announcements really happened (2 steps x 4 backwards)
+        for tag in ("overlap", "single", "graph"):
+            assert all(np.isfinite(v) for v in rk["losses_" + tag].values()), rk["losses_" + tag]
+    for a, b in zip(res[0]["params"], res[1]["params"]):
+        assert torch.equal(a, b)
+
+
 def _check_steps(res):
     for rk in res:
         assert rk["mean"] and rk["sum"] and rk["bcast"], {k: rk[k] for k in ("mean", "sum", "bcast")}

@@ -39,10 +39,16 @@ def test_validation_front_half_vs_oracle():
         ref, ref_oc = O.validate_predict(sds[0], sds[1], sds[2], sds[3], HP, img, label_size)
     assert float((pred.cpu() - ref).abs().max()) < 1e-4
     assert float((pred_oc.cpu() - ref_oc).abs().max()) < 1e-4
+    from oracle import postprocess_cpu as P
     for i in range(B):
+        # product side: validate.postprocess / validate.dice on the HIP logits; checker side: the oracle's own post-processing
+        # (flood-fill restatement of utils.py:267-329) and Dice (metrics.py:68-97) on the oracle's logits
         d_hip = V.dice(V.postprocess(pred[i])[0], lod[i, 0].numpy())
-        d_ref = V.dice(V.postprocess(ref[i])[0], lod[i, 0].numpy())
+        d_ref = O.dice_coefficient(P.postprocessing(ref[i])[0], lod[i, 0].numpy())
         assert abs(d_hip - d_ref) <= 1e-4, (i, d_hip, d_ref)
+        c_hip = V.dice(V.postprocess(pred_oc[i])[0], loc[i, 0].numpy())
+        c_ref = O.dice_coefficient(P.postprocessing(ref_oc[i])[0], loc[i, 0].numpy())
+        assert abs(c_hip - c_ref) <= 1e-4, (i, c_hip, c_ref)
     cup, disc = V.validate(*nets, [(img.to(DEV), lod, loc)])
     assert 0.0 <= cup <= 1.0 and 0.0 <= disc <= 1.0
     assert all(not n.training for n in nets)

@@ -22,7 +22,7 @@ def pack_x3(w):
 
 def main():
   B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-  tot = [0.0] * 6
+  tot = [0.0] * 8
   for c0, c1, co, H, k, name in SHAPES:
       if c0 + c1 < 16:
           continue
@@ -41,11 +41,23 @@ def main():
       line = "%-12s %3d+%-3d->%-3d k%d @%3d  fwd fp32 %7.1f us %5.1f TF | x3 %7.1f us %5.1f TF (%.2fx)" % (
           name, c0, c1, co, k, H, f32, flops / f32 / 1e6, f3, flops / f3 / 1e6, f32 / f3)
       tot[0] += f32; tot[1] += f3
+      if k == 3:        # the LDS-fed-weights kernel of rounds 2-3 (conv_x3_k) beside the default (conv_x3r_k)
+          ops.lib().query("wtpse_x3r_enable", 0)
+          fo, _ = timeit(lambda: ops.conv_fwd_x3(x0, x1, px.data_ptr(), bias, co, k, pro0, 3, want_stats=True, pro1=pro1), 10)
+          ops.lib().query("wtpse_x3r_enable", 1)
+          line += " [r3 kernel %7.1f us %5.1f TF]" % (fo, flops / fo / 1e6)
+          tot[6] += fo
       if c0 + c1 > 16:
           d32, _ = timeit(lambda: ops.conv_fwd(dy, None, packed.data_ptr() + 4 * wd_off, None, c0 + c1, k, split=(c0 if c1 else None)), 10)
           d3, _ = timeit(lambda: ops.conv_fwd_x3(dy, None, px.data_ptr() + 2 * xd_off, None, c0 + c1, k, split=(c0 if c1 else None)), 10)
           line += " || dgrad fp32 %7.1f us %5.1f TF | x3 %7.1f us %5.1f TF (%.2fx)" % (d32, flops / d32 / 1e6, d3, flops / d3 / 1e6, d32 / d3)
           tot[2] += d32; tot[3] += d3
+          if k == 3:
+              ops.lib().query("wtpse_x3r_enable", 0)
+              do, _ = timeit(lambda: ops.conv_fwd_x3(dy, None, px.data_ptr() + 2 * xd_off, None, c0 + c1, k, split=(c0 if c1 else None)), 10)
+              ops.lib().query("wtpse_x3r_enable", 1)
+              line += " [r3 kernel %7.1f us %5.1f TF]" % (do, flops / do / 1e6)
+              tot[7] += do
       if ops.wgrad_x3_supported(c0 + c1, co, k, c0 if c1 else 8):
           dw = torch.empty_like(w)
           w32, _ = timeit(lambda: ops.conv_wgrad(dy, x0, x1, k, dw, None, pro0, 3, False, pro1), 10)
@@ -55,6 +67,7 @@ def main():
       print(line, flush=True)
   print("wgrad (supported layers): fp32 %.0f us, x3 %.0f us" % (tot[4], tot[5]))
   print("sum: fwd fp32 %.0f us, x3 %.0f us; dgrad fp32 %.0f us, x3 %.0f us" % tuple(tot[:4]))
+  print("3x3 layers with the round-3 kernel (1x1 layers as above): fwd +%.0f us, dgrad +%.0f us" % (tot[6], tot[7]))
 
 
 if __name__ == "__main__":

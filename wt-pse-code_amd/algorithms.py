@@ -8,8 +8,9 @@ There is no CPU path: modules must live on a HIP device.
 
 Only the reachable configuration space of the reference is supported: ``shape_prior`` and ``whitening`` both on
 (the WT-PSE method) or both off (plain segmentation U-Net, BASELINE.json configs[1]); the mixed settings crash in
-the reference itself, and so does ``shape_attention=False`` (see ``__init__``).  The one reachable
-non-default branch that is not built is ``cat_shape=True``.
+the reference itself, and so does ``shape_attention=False`` (see ``__init__``).  The reachable
+non-default branch ``cat_shape=True`` (``outc`` over ``cat(fuse_embedding, z_posterior)``, reference :1192,1253,1348)
+is built and pinned by tests/golden/catshape.npz.
 """
 import torch
 import torch.nn as nn

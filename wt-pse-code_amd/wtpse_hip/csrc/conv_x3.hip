@@ -99,13 +99,19 @@ __device__ __forceinline__ void split3_pair(float a, float b, unsigned& p0, unsi
 // EPI: 0 plain, 1 ReLU mask (out = mask > 0 ? value : 0), 2 BatchNorm-backward statistics (ConvX3Args::bn_*): the gradient is
 // masked with the ReLU of the layer it flows into and the two reductions of that layer's BatchNorm backward (reference
 // algorithms.py:883-889 via autograd) are formed from the accumulators, so bn_bwd_reduce_k never re-reads the two tensors.
-template <int MT, int NT, int TWL, int EPI, bool RED_ALIASES>
+// WM = waves along the output channels (conv_x3r_k: 2 — a wave then owns MT blocks of 32 channels x NT column tiles of 32 pixels of a
+// (4 / WM)-wave pixel split; conv_x3_k: 1, every wave holds all CB channels of its pixels).
+template <int MT, int NT, int TWL, int EPI, bool RED_ALIASES, int WM = 1>
 __device__ __forceinline__ void x3_epilogue(const ConvX3Args& a, f32x16 (&acc)[MT][NT], int b, int ty, int tx, int cout0, int tid,
                                             float* red, const float* bias_s, int stats_row, bool live) {
-  constexpr int TW = 1 << TWL, TH = (128 * NT) / TW;
-  constexpr int CB = 32 * MT, NACC = 16;
+  constexpr int PW = 4 / WM;
+  constexpr int TW = 1 << TWL, TH = (PW * 32 * NT) / TW;
+  constexpr int CBW = 32 * MT, CB = CBW * WM, NACC = 16;
   constexpr bool MASK = EPI == 1, BNB = EPI == 2;
-  const int lane = tid & 63, wave = tid >> 6;
+  // wave: index along the pixels; cw0: first channel of this wave's share (both wave-uniform: pinned to scalar registers, or the
+  // channel-dependent descriptors / scalar offsets below turn every store into a readfirstlane loop)
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane((tid >> 6) / WM);
+  const int cw0 = WM == 1 ? 0 : __builtin_amdgcn_readfirstlane(((tid >> 6) % WM) * CBW);
   const int r32 = lane & 31, h = lane >> 5;
   const int HW = a.H * a.W;
   if (a.bias) {
@@ -113,14 +119,14 @@ __device__ __forceinline__ void x3_epilogue(const ConvX3Args& a, f32x16 (&acc)[M
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int r = 0; r < NACC; ++r) {
-        const float bz = bias_s[mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
+        const float bz = bias_s[cw0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt][r] += bz;
       }
   }
   const bool want_stats = a.stats != nullptr;
   const float* bnp_s = bias_s + CB;                   // EPI 2: [3][CB] (scale | shift | mean) of this block's channels
-  if (want_stats && RED_ALIASES) __syncthreads();   // red[4 waves][CB][2] reuses the operand images
+  if (want_stats && RED_ALIASES) __syncthreads();   // red[PW waves][CB][2] reuses the operand images
   const int C1out = a.Cout - a.Csplit;
   const int Cbn = a.bn_c1 - a.bn_c0;
   int poff[NT];
@@ -146,7 +152,7 @@ __device__ __forceinline__ void x3_epilogue(const ConvX3Args& a, f32x16 (&acc)[M
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int r = 0; r < NACC; ++r) {
-        const bool cvalid = cout0 + mt * 32 + (r & 3) + 8 * (r >> 2) + clane < a.Cout;
+        const bool cvalid = cout0 + cw0 + mt * 32 + (r & 3) + 8 * (r >> 2) + clane < a.Cout;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt][r] = (cvalid && poff[nt] >= 0) ? acc[mt][nt][r] : 0.f;
       }
@@ -163,7 +169,7 @@ __device__ __forceinline__ void x3_epilogue(const ConvX3Args& a, f32x16 (&acc)[M
     if (MASK) {
 #pragma unroll
       for (int r = 0; r < NACC; ++r) {
-        const int cbase = cout0 + mt * 32 + (r & 3) + 8 * (r >> 2);
+        const int cbase = cout0 + cw0 + mt * 32 + (r & 3) + 8 * (r >> 2);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) mk[r][nt] = buf_load(rs_m, pvo[nt], (unsigned)min(cbase, a.Cout) * hw4);
       }
@@ -173,7 +179,7 @@ __device__ __forceinline__ void x3_epilogue(const ConvX3Args& a, f32x16 (&acc)[M
       // whether a register belongs to the BatchNorm'd tensor is wave-uniform; the others load out of range (0)
 #pragma unroll
       for (int r = 0; r < NACC; ++r) {
-        const int cbase = cout0 + mt * 32 + (r & 3) + 8 * (r >> 2);
+        const int cbase = cout0 + cw0 + mt * 32 + (r & 3) + 8 * (r >> 2);
         const bool bn = cbase >= a.bn_c0 && cbase < a.bn_c1;
         const unsigned soff = (unsigned)(bn ? cbase - a.bn_c0 : 0) * hw4;
 #pragma unroll
@@ -183,14 +189,14 @@ __device__ __forceinline__ void x3_epilogue(const ConvX3Args& a, f32x16 (&acc)[M
     float bmu[NACC];
 #pragma unroll
     for (int r = 0; r < NACC; ++r) {
-      const int cbase = cout0 + mt * 32 + (r & 3) + 8 * (r >> 2);
+      const int cbase = cout0 + cw0 + mt * 32 + (r & 3) + 8 * (r >> 2);
       const bool second = a.out1 != nullptr && cbase >= a.Csplit;
       const __amdgpu_buffer_rsrc_t rs_o = second ? rs_o1 : rs_o0;
       const unsigned soff = (unsigned)(second ? min(cbase, a.Cout) - a.Csplit : min(cbase, a.Csplit)) * hw4;
       float bsc = 0.f, bsh = 1.f;
       bmu[r] = 0.f;
       if (BNB) {
-        const int crel = mt * 32 + (r & 3) + 8 * (r >> 2) + clane;
+        const int crel = cw0 + mt * 32 + (r & 3) + 8 * (r >> 2) + clane;
         bsc = bnp_s[crel];
         bsh = bnp_s[CB + crel];
         bmu[r] = bnp_s[2 * CB + crel];
@@ -254,7 +260,7 @@ __device__ __forceinline__ void x3_epilogue(const ConvX3Args& a, f32x16 (&acc)[M
 #pragma unroll
       for (int st = 0; st < 5; ++st) idx += ((lane >> st) & 1) * (NSV >> (st + 1));
       const int k = idx & 1, rr = idx >> 1;
-      const int crel = mt * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h;
+      const int crel = cw0 + mt * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h;
       red[(wave * CB + crel) * 2 + k] = sv[0];
     }
   }
@@ -262,7 +268,9 @@ __device__ __forceinline__ void x3_epilogue(const ConvX3Args& a, f32x16 (&acc)[M
     __syncthreads();
     if (tid < CB * 2) {
       const int crel = tid >> 1;
-      const float s = red[tid] + red[CB * 2 + tid] + red[2 * CB * 2 + tid] + red[3 * CB * 2 + tid];
+      float s = red[tid];
+#pragma unroll
+      for (int q = 1; q < PW; ++q) s += red[q * CB * 2 + tid];
       if (BNB) {
         const int c = cout0 + crel;
         if (live && c >= a.bn_c0 && c < a.bn_c1) pub_store(a.stats + ((size_t)stats_row * Cbn + c - a.bn_c0) * 2 + (tid & 1), s);
@@ -283,7 +291,7 @@ __device__ __forceinline__ void x3_epilogue(const ConvX3Args& a, f32x16 (&acc)[M
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int r = 0; r < NACC; ++r) {
-        const int cbase = cout0 + mt * 32 + (r & 3) + 8 * (r >> 2);
+        const int cbase = cout0 + cw0 + mt * 32 + (r & 3) + 8 * (r >> 2);
         const bool second = a.out1 != nullptr && cbase >= a.Csplit;
         const __amdgpu_buffer_rsrc_t rs_o = second ? rs_o1 : rs_o0;
         const unsigned soff = (unsigned)(second ? min(cbase, a.Cout) - a.Csplit : min(cbase, a.Csplit)) * hw4;
@@ -591,6 +599,278 @@ __global__ __launch_bounds__(256, 2) void conv_x3_k(ConvX3Args a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// conv_x3r_k (round 4): the 3x3 forward / data gradient with REGISTER-FED weights.  Same arithmetic, same tiles, same loader and
+// epilogues as conv_x3_k — every accumulator sees the same products in the same order, so the results are bitwise those of
+// conv_x3_k (tests/test_conv_x3_gpu.py::test_x3r_equals_x3) — but a different operand supply:
+//   * the packed weights ARE in fragment order already ([chunk][32-row block][tap][term][k-half][row][8 k]: lane (h, r32) of a
+//     32x32x16 A fragment owns 16 consecutive bytes, a wave 1 KB): every wave loads its A fragments straight from global memory
+//     (L2 / L1 resident: 55 KB per 16-channel chunk and 64 output channels) into a ring of three tap slots, two taps ahead of their
+//     use.  No weight slab in LDS: 55 of the 88 KB a workgroup stored per chunk, and the two weight-row barriers per chunk, are gone;
+//   * the input tile keeps going through LDS (the halo is shared by the workgroup's waves), now DOUBLE-buffered: the next chunk is
+//     converted and stored piece by piece between the MFMA groups of the current one, one barrier per chunk (216 MFMAs per wave);
+//   * WM = 2 (64 output channels per workgroup): the waves form a 2 x 2 grid — 32 channels x 128 pixels each — instead of 1 x 4
+//     (64 channels x 64 pixels): half the weight bytes per MFMA through the vector-memory path (16 B/clk/CU instead of 31), twice the
+//     B-fragment reads from LDS (64 of 256 B/clk/CU), which is the cheaper of the two;
+//   * MFMAs run pixel-tile-major (six dependent products per accumulator back to back: a chain of v_mfma_f32_32x32x16_bf16 issues
+//     at the full rate, MI355X_MICROARCH.md), so only two B fragment sets (current, next) are live.
+#ifdef WTPSE_PROBE
+// per workgroup {s_memtime, s_memrealtime} at the start and the end of the main loop (thread 0): the clock the loop ran at
+__device__ unsigned long long* g_x3r_clk = nullptr;
+#define RCLK(i) do { if (g_x3r_clk && threadIdx.x == 0) { unsigned long long* q = g_x3r_clk + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 2 * (i); \
+    q[0] = __builtin_amdgcn_s_memtime(); q[1] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define RCLK(i)
+#endif
+
+// ABL (tools/probe/x3r_abl.py only; 0 in the library): pieces of the main loop left out, to price them — 1 conversion VALU, 2 LDS
+// stores, 4 weight-fragment loads, 8 input-fragment reads, 16 the chunk barrier, 32 the input tile's global loads.  Results are
+// garbage with any bit set.
+template <int WM, int MT, int NT, int TWL, int EPI, int ABL = 0>
+__global__ __launch_bounds__(256, 2) void conv_x3r_k(ConvX3Args a) {
+  constexpr int KS = 3, TAPS = 9, PAD = 1;
+  constexpr int PW = 4 / WM;                       // waves along the pixels
+  constexpr int TW = 1 << TWL, TH = (PW * 32 * NT) / TW;
+  constexpr int PITCH = TW + 2 * PAD, ROWS = TH + 2 * PAD;
+  constexpr int PE = PITCH * ROWS;
+  constexpr int PEP = (PE + 7) & ~7;
+  constexpr int CBW = 32 * MT, CB = CBW * WM;
+  constexpr int NACC = 16;
+  constexpr int KC = 16;
+  constexpr int XS_U4 = 6 * PEP;                   // 16-byte slots of one input image
+  constexpr int MAIN_U4 = 2 * XS_U4;
+  constexpr int PRO_MAX = 512;
+  static_assert(MAIN_U4 * 4 >= PW * CB * 2 + 4 * CB + 4, "epilogue scratch aliases the operand images");
+  constexpr int DUMP_U4 = MAIN_U4 + CB / 4 + (EPI == 2 ? CB : 0);
+  __shared__ u32x4v smem[DUMP_U4 + 64];
+  __shared__ float2 pro_s[PRO_MAX];
+  u32x4v* Xs = smem;
+  float* bias_s = reinterpret_cast<float*>(smem + MAIN_U4);
+
+  RCLK(2);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cw = __builtin_amdgcn_readfirstlane(wave % WM), pw = __builtin_amdgcn_readfirstlane(wave / WM);
+  const int r32 = lane & 31, h = lane >> 5;
+  int bx = blockIdx.x;
+  const int tx = bx % a.tiles_x;
+  bx /= a.tiles_x;
+  const int ty = bx % a.tiles_y;
+  const int b = bx / a.tiles_y;
+  const int cout0 = blockIdx.y * CB;
+  const int HW = a.H * a.W;
+  if (tid < CB) bias_s[tid] = (a.bias && cout0 + tid < a.Cout) ? a.bias[cout0 + tid] : 0.f;
+  if (EPI == 2 && tid < CB) {
+    const int c = cout0 + tid;
+    const bool bn = c >= a.bn_c0 && c < a.bn_c1;
+    float* q = bias_s + CB + tid;
+    q[0] = (bn && a.bn_relu) ? a.bn_ss[2 * (c - a.bn_c0)] : 0.f;
+    q[CB] = (bn && a.bn_relu) ? a.bn_ss[2 * (c - a.bn_c0) + 1] : 1.f;
+    q[2 * CB] = bn ? a.bn_mean[c - a.bn_c0] : 0.f;
+  }
+  for (int c = tid; c < a.CinP; c += 256) {
+    const bool first = c < a.C0;
+    const float* pro = first ? a.pro0 : a.pro1;
+    const int cl = first ? c : c - a.C0;
+    const bool live = c < a.C0 + a.C1;
+    pro_s[c] = !live ? make_float2(0.f, 0.f) : (pro ? make_float2(pro[2 * cl], pro[2 * cl + 1]) : make_float2(1.f, 0.f));
+  }
+
+  int off[NT];                                    // halo position of this lane's pixel (tap 0,0 corner)
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int p = pw * (32 * NT) + nt * 32 + r32;
+    off[nt] = (p >> TWL) * PITCH + (p & (TW - 1));
+  }
+  // loader work items exactly as in conv_x3_k: (halo position, k-half) = 8 channels of one position, dealt in whole-wave blocks
+  constexpr int PB = (PE + 63) / 64;
+  constexpr int NIT = (2 * PB + 3) / 4;
+  int ipos[NIT], ihalf[NIT];
+  unsigned voff[NIT];
+  bool iin[NIT];
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int blk = __builtin_amdgcn_readfirstlane(i * 4 + wave);
+    ihalf[i] = blk >= PB ? 1 : 0;
+    const int p = (blk - ihalf[i] * PB) * 64 + lane;
+    ipos[i] = (blk < 2 * PB && p < PE) ? p : -1;
+    const int r = p / PITCH, x = p - r * PITCH;
+    const int gy = ty * TH + r - PAD, gx = tx * TW + x - PAD;
+    iin[i] = ipos[i] >= 0 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+    voff[i] = iin[i] ? (unsigned)(gy * a.W + gx) * 4u + (unsigned)ihalf[i] * 8u * (unsigned)HW * 4u : BUF_OOB;
+  }
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < NACC; ++r) acc[mt][nt][r] = 0.f;
+
+  const int ncb32 = a.CoutP / 32;
+  const int nchunks = a.CinP / KC;
+  constexpr unsigned TAP_B = 6u * 32u * 16u;       // bytes of one (chunk, 32-row block, tap): three terms x two k-halves x 32 rows x 16 B
+  const __amdgpu_buffer_rsrc_t rsw = make_rsrc(a.wx, (unsigned)nchunks * ncb32 * TAPS * TAP_B);
+  const unsigned wlane = (unsigned)lane * 16u;     // (k-half h, row r32) = slot h * 32 + r32 = lane
+  const int cb32 = cout0 / 32 + cw * MT;
+
+  float xv[NIT][8];
+  const float* const xb0 = a.in0 + (size_t)b * a.C0 * HW;
+  const float* const xb1 = a.in1 ? a.in1 + (size_t)b * a.C1 * HW : xb0;
+  auto issue_x = [&](int c0) __attribute__((always_inline)) {
+    const bool first = c0 < a.C0;
+    // (a select between two ready-made descriptors came out as a VECTOR value here — every load then sat in a readfirstlane
+    // "waterfall" loop; the descriptor is built from a pointer and a size that are pinned to scalar registers instead)
+    const unsigned long long pb = (unsigned long long)(first ? xb0 : xb1);
+    const unsigned plo = __builtin_amdgcn_readfirstlane((unsigned)pb), phi = __builtin_amdgcn_readfirstlane((unsigned)(pb >> 32));
+    const int cbase = __builtin_amdgcn_readfirstlane(first ? c0 : c0 - a.C0);
+    const int cn = __builtin_amdgcn_readfirstlane(first ? a.C0 : a.C1);
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc((const void*)(((unsigned long long)phi << 32) | plo), (unsigned)cn * HW * 4u);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const unsigned soff = (unsigned)min(cbase + j, cn) * (unsigned)HW * 4u;     // past the tensor: out of range, reads 0
+#pragma unroll
+      for (int i = 0; i < NIT; ++i) xv[i][j] = buf_load(rs, voff[i], soff);
+    }
+  };
+  // one item = 8 channels of one halo position: prologue (affine, ReLU; zero padding AFTER it), split, three 16-byte LDS stores
+  u32x4v tq[3];
+  auto convert_pair = [&](int c0, int i, int j) __attribute__((always_inline)) {
+    float v0 = xv[i][2 * j], v1 = xv[i][2 * j + 1];
+    const bool relu = (c0 < a.C0) ? (a.pro_relu & 1) : (a.pro_relu & 2);
+    const int cg = min(c0 + ihalf[i] * 8 + 2 * j, PRO_MAX - 2);
+    const float2 p0 = pro_s[cg], p1 = pro_s[cg + 1];
+    v0 = fmaf(v0, p0.x, p0.y);
+    v1 = fmaf(v1, p1.x, p1.y);
+    v0 = relu ? fmaxf(v0, 0.f) : v0;
+    v1 = relu ? fmaxf(v1, 0.f) : v1;
+    v0 = iin[i] ? v0 : 0.f;
+    v1 = iin[i] ? v1 : 0.f;
+    unsigned q0, q1, q2;
+    split3_pair(v0, v1, q0, q1, q2);
+    tq[0][j] = q0;
+    tq[1][j] = q1;
+    tq[2][j] = q2;
+  };
+  // branch-free (the stores sit between MFMA groups): lanes without a position (the tail of a half's last 64-block) store to a
+  // per-lane dump slot behind the images
+  auto store_item = [&](int i, int xb) __attribute__((always_inline)) {
+    const bool ok = ipos[i] >= 0;
+    const int base = xb * XS_U4 + ihalf[i] * PEP + ipos[i];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) Xs[ok ? base + t * 2 * PEP : DUMP_U4 + lane] = tq[t];
+  };
+  // piece p of a chunk's conversion: pair (p & 3) of item (p >> 2); an item's fourth pair is followed by its stores
+  auto convert_piece = [&](int c0, int p, int xb, bool in_loop) __attribute__((always_inline)) {
+    if (!((ABL & 1) && in_loop)) convert_pair(c0, p >> 2, p & 3);
+    if ((p & 3) == 3 && !((ABL & 2) && in_loop)) store_item(p >> 2, xb);
+  };
+
+  // A fragments: ring of three tap slots
+  constexpr int RING = (ABL & 256) ? 3 : TAPS;     // tap slots of weight fragments: a whole chunk ahead (ABL 256: two taps ahead)
+  bf16x8 afr[RING][MT][3];
+  bf16x8 adummy[3][MT][3];           // ABL 64 only
+  auto issue_a1 = [&](int chunk, int tap, int slot, int t) __attribute__((always_inline)) {
+    const unsigned base = ((unsigned)(chunk * ncb32 + cb32) * TAPS + (unsigned)tap) * TAP_B;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const bf16x8 v = __builtin_bit_cast(bf16x8, buf_load4(rsw, wlane, base + (unsigned)mt * TAPS * TAP_B + (unsigned)t * 2u * 32u * 16u));
+      if constexpr (ABL & 64) adummy[slot][mt][t] = v; else afr[slot][mt][t] = v;
+    }
+  };
+  auto issue_a = [&](int chunk, int tap, int slot) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t) issue_a1(chunk, tap, slot, t);
+  };
+  bf16x8 bfr[2][3];
+  auto rd_b = [&](int xb, int tap, int nt, int set) __attribute__((always_inline)) {
+    const u32x4v* X = Xs + xb * XS_U4 + off[nt] + (tap / 3) * PITCH + (tap % 3);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) bfr[set][t] = __builtin_bit_cast(bf16x8, X[(t * 2 + h) * PEP]);
+  };
+  auto mm = [&](int slot, int nt, int set) __attribute__((always_inline)) {
+    // the six cross terms, smallest first — per accumulator the order of conv_x3_k
+    constexpr int TA[6] = {0, 1, 2, 0, 1, 0}, TB[6] = {2, 1, 0, 1, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mfma_bf16(afr[slot][mt][TA[q]], bfr[set][TB[q]], acc[mt][nt]);
+  };
+
+  constexpr int NPIECE = NIT * 4;
+  constexpr int NGRP = TAPS * NT;                  // MFMA groups (tap, column tile) per chunk
+  static_assert(NPIECE <= NGRP, "one conversion piece per MFMA group");
+  constexpr int G0 = NGRP - NPIECE;                // the pieces ride behind the last NPIECE groups
+
+  issue_x(0);
+  if constexpr (RING == TAPS) {
+    x3_static_for<TAPS>([&](auto tc) __attribute__((always_inline)) { issue_a(0, decltype(tc)::value, decltype(tc)::value); });
+  } else {
+    issue_a(0, 0, 0);
+    issue_a(0, 1, 1);
+  }
+  __syncthreads();                                 // pro_s
+  x3_static_for<NPIECE>([&](auto pc) __attribute__((always_inline)) { convert_piece(0, decltype(pc)::value, 0, false); });
+  issue_x(KC);
+  __syncthreads();
+  RCLK(0);
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    const int xb = chunk & 1;
+    const int chn = min(chunk + 1, nchunks - 1);   // fragments prefetched past the last chunk are never used
+    const int c0n = (chunk + 1) * KC;
+    __builtin_amdgcn_sched_barrier(0);
+    rd_b(xb, 0, 0, 0);
+    if constexpr (ABL & 8) rd_b(xb, 0, NT - 1, 1);
+    x3_static_for<NGRP>([&](auto gc) __attribute__((always_inline)) {
+      constexpr int g = decltype(gc)::value;
+      constexpr int tap = g / NT, nt = g % NT;
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (RING == TAPS) {
+        // the fragments of tap - 1 have been consumed: their slot takes the NEXT chunk's tap - 1 (nine taps = 216 MFMAs per wave
+        // ahead of its use: measured, a two-tap distance left the waves waiting on these loads for a fifth of the launch)
+        if constexpr (nt == 0 && tap >= 1 && !(ABL & 4)) issue_a(chn, tap - 1, tap - 1);
+      } else if constexpr ((ABL & 128) != 0 && NT >= 3) {       // spread: one term per group
+        if constexpr (nt < 3) {
+          if constexpr (tap + 2 < TAPS) issue_a1(chunk, tap + 2, (tap + 2) % 3, nt);
+          else issue_a1(chn, tap + 2 - TAPS, (tap + 2) % 3, nt);
+        }
+      } else if constexpr (nt == 0 && !(ABL & 4)) {
+        if constexpr (tap + 2 < TAPS) issue_a(chunk, tap + 2, (tap + 2) % 3);
+        else issue_a(chn, tap + 2 - TAPS, (tap + 2) % 3);
+      }
+      if constexpr (g + 1 < NGRP && !(ABL & 8)) rd_b(xb, (g + 1) / NT, (g + 1) % NT, (g + 1) & 1);
+      // the next group's fragment reads go out in FRONT of this group's six MFMAs (left alone, the scheduler re-uses the registers of
+      // the current b1 / b2 for them and sinks the reads behind the fourth MFMA: 64 cycles in front of their s_waitcnt)
+      __builtin_amdgcn_sched_barrier(0);
+      mm(tap % RING, nt, g & 1);
+      if constexpr (g >= G0) convert_piece(c0n, g - G0, xb ^ 1, true);
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (RING == TAPS && !(ABL & 4)) issue_a(chn, TAPS - 1, TAPS - 1);
+    if constexpr (!(ABL & 32)) issue_x((chunk + 2) * KC);
+    if constexpr (!(ABL & 16)) __syncthreads();
+  }
+  RCLK(1);
+  if constexpr (ABL != 0) {       // keep everything the ablations skipped alive
+    if (a.B < 0) {
+#pragma unroll
+      for (int i = 0; i < NIT; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[0][0][0] += xv[i][j];
+      acc[0][0][1] += __builtin_bit_cast(float, tq[0][0] ^ tq[1][1] ^ tq[2][2]);
+      if constexpr (ABL & 64) {
+#pragma unroll
+        for (int sl = 0; sl < 3; ++sl)
+#pragma unroll
+          for (int t = 0; t < 3; ++t) acc[0][0][2] += (float)adummy[sl][0][t][0];
+      }
+    }
+  }
+
+  x3_epilogue<MT, NT, TWL, EPI, true, WM>(a, acc, b, ty, tx, cout0, tid, reinterpret_cast<float*>(smem), bias_s, (int)blockIdx.x, true);
+  RCLK(3);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Weight packing for the x3 path: OIHW fp32 -> bf16 triples in the kernel's LDS image order.
 //   forward : rows = Cout, k = Cin, tap t          element = w[co][ci][t]
 //   dgrad   : rows = Cin,  k = Cout, tap T-1-t     element = w[co][ci][T-1-t]   (the data gradient is the forward kernel on dY)
@@ -639,6 +919,21 @@ static bool x3_small_tiles(int B, int H, int W, int CoutP, bool mt2) {
   return B * ceil_div(H, 16) * ceil_div(W, 16) * (CoutP / 32) < 512;
 }
 
+// 3x3 launches take conv_x3r_k (register-fed weights) unless WTPSE_X3R=0 / wtpse_x3r_enable(0): the two kernels give bitwise the
+// same results on the same tiles, so the switch is a pure A/B of the operand supply.
+static int g_x3r = [] { const char* e = getenv("WTPSE_X3R"); return (e && e[0] == '0') ? 0 : 1; }();
+extern "C" int wtpse_x3r_enable(int on) {
+  const int was = g_x3r;
+  if (on >= 0) g_x3r = on ? 1 : 0;
+  return was;
+}
+
+#ifdef WTPSE_PROBE
+static int g_x3r_abl = 0;
+extern "C" int wtpse_probe_x3r_abl(int abl) { g_x3r_abl = abl; return 0; }
+extern "C" int wtpse_probe_x3r_clock(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_x3r_clk), &p, sizeof(p)); }
+#endif
+
 template <int KS, int MT, int EPI>
 static int launch_x3(const ConvX3Args& a, hipStream_t st) {
   ConvX3Args args = a;
@@ -652,7 +947,31 @@ static int launch_x3(const ConvX3Args& a, hipStream_t st) {
   if (!in_launch) args.tail.tickets = args.ftail.tickets = nullptr;
   if (args.tail.tickets) bnb_tail_geometry(args.tail, (int)grid.x, a.Cout, (double)a.B * a.H * a.W);
   if (args.ftail.tickets) bnf_tail_geometry(args.ftail, (int)grid.x, a.Cout, (double)a.B * a.H * a.W);
-  if (small) {
+  if (KS == 3 && g_x3r) {
+    if constexpr (KS == 3) {
+      if (small) {
+        if constexpr (MT == 1) hipLaunchKernelGGL((conv_x3r_k<1, 1, 1, 4, EPI>), grid, dim3(256), 0, st, args);
+      } else if (MT == 2) {
+#ifdef WTPSE_PROBE
+        if (g_x3r_abl && !narrow && EPI == 0) {
+          switch (g_x3r_abl) {
+#define ABLCASE(n) case n: hipLaunchKernelGGL((conv_x3r_k<2, 1, 4, 5, 0, n>), grid, dim3(256), 0, st, args); break;
+            ABLCASE(1) ABLCASE(2) ABLCASE(3) ABLCASE(4) ABLCASE(8) ABLCASE(16) ABLCASE(32) ABLCASE(35) ABLCASE(39) ABLCASE(47) ABLCASE(63)
+            ABLCASE(64) ABLCASE(128) ABLCASE(99) ABLCASE(163) ABLCASE(256) ABLCASE(260) ABLCASE(291)
+#undef ABLCASE
+            default: return WTPSE_EINVAL;
+          }
+          return wtpse_status();
+        }
+#endif
+        if (narrow) hipLaunchKernelGGL((conv_x3r_k<2, 1, 4, 4, EPI>), grid, dim3(256), 0, st, args);
+        else hipLaunchKernelGGL((conv_x3r_k<2, 1, 4, 5, EPI>), grid, dim3(256), 0, st, args);
+      } else {
+        if (narrow) hipLaunchKernelGGL((conv_x3r_k<1, 1, 2, 4, EPI>), grid, dim3(256), 0, st, args);
+        else hipLaunchKernelGGL((conv_x3r_k<1, 1, 2, 5, EPI>), grid, dim3(256), 0, st, args);
+      }
+    }
+  } else if (small) {
     if constexpr (MT == 1) hipLaunchKernelGGL((conv_x3_k<KS, 1, 4, EPI, 1>), grid, dim3(256), 0, st, args);
   } else if (narrow)
     hipLaunchKernelGGL((conv_x3_k<KS, MT, 4, EPI>), grid, dim3(256), 0, st, args);

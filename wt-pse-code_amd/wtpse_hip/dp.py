@@ -47,9 +47,11 @@ def gathered_to_global_index(n_local, domains, world):
 
 
 class DataParallel:
-    def __init__(self, world, rank, device, bn_sync=False, group=None, domains=3, overlap=True):
+    def __init__(self, world, rank, device, bn_sync=False, group=None, domains=3, overlap=None):
         self.world, self.rank, self.device = int(world), int(rank), device
-        self.overlap = bool(overlap)
+        # overlap=None: on in the throughput mode, off in the exact mode — there the early bucket all-reduces would interleave with
+        # ~100 BatchNorm-statistics collectives per pass on the same communicator, an order no multi-GPU run has exercised yet
+        self.overlap = (not bn_sync) if overlap is None else bool(overlap)
         self._pieces = {}            # id(net) -> [(lo, hi, work, view)]: ranges whose all-reduce is in flight
         self._issue = {}             # device -> stream the early all-reduces are issued from
         self.bn_sync = bool(bn_sync)

@@ -164,6 +164,12 @@ class TeacherP(UNetBody):
 
 
 # ================================================================================================ root network
+def _invalidate_on_load(module, incompatible_keys):
+    root = module.__dict__.get("_root")
+    if root is not None:
+        root.invalidate_packed()
+
+
 class HipNet(nn.Module):
     """Root of a parameter tree: owns the flat parameter / gradient / packed-weight buffers."""
 
@@ -189,6 +195,12 @@ class HipNet(nn.Module):
         for m in self.modules():
             if isinstance(m, (ConvP, BNP, AttentionP, TeacherP, DeepWTP)):
                 object.__setattr__(m, "_root", self)
+        # A checkpoint loaded into a live network (test_visulization.py:132-193: filtered load_state_dict, also on sub-modules)
+        # changes the flat parameters behind the packed copies: every parameter holder reports the load to the root, which then
+        # repacks on the next entry even when a step harness vouches for the packed weights (`_packed_valid`).
+        for m in self.modules():
+            if isinstance(m, (ConvP, BNP)):
+                m.register_load_state_dict_post_hook(_invalidate_on_load)
         # weights of the layers that run on the split-bf16 ("x3") convolution (csrc/conv_x3.hip), pre-split into bf16 triples
         off = 0
         self._x3_convs = []
@@ -356,6 +368,11 @@ class HipNet(nn.Module):
         launch plan is being recorded (collectives stay outside plans) or when gradients accumulate: nothing happens."""
         dp = self._dp
         if dp is None or not dp.overlap or self._gtarget is not self._gflat or ops.lib()._rec is not None:
+            return
+        if self._gflat.is_cuda and torch.cuda.is_current_stream_capturing():
+            # TrainStep(graph=True): an asynchronous collective issued here would join the capture from the issue stream and
+            # be waited for only after the capture has ended (unjoined work / an illegal host sync with gloo).  Captured
+            # stretches keep their collectives between them (step.py): the whole buffer goes in allreduce_grads.
             return
         last = first if last is None else last
         pf, pl = next(first.parameters()), list(last.parameters())[-1]
@@ -544,7 +561,7 @@ WGRAD_SIDE_STREAM = os.environ.get("WTPSE_WGRAD_STREAM", "1") != "0"
 
 
 def _side_stream(device, owner=None):
-    """One weight-gradient stream per stream it is fed from (the training step runs two lanes, each with its own)."""
+    """One weight-gradient stream per stream it is fed from (the main stream and the prior-chain stream of a segmentation update)."""
     key = (device, ops.stream_ptr() if owner is None else owner)
     st = _SIDE.get(key)
     if st is None:
@@ -560,7 +577,7 @@ def second_stream(device):
     """Stream for forward-only work that is independent of the main schedule (the teacher in the student's update)."""
     if not TEACHER_SIDE_STREAM:
         return None
-    key = (device, ops.stream_ptr())          # per calling stream: the two lanes of the training step do not share it
+    key = (device, ops.stream_ptr())          # per calling stream
     st = _SECOND.get(key)
     if st is None:
         st = _SECOND[key] = torch.cuda.Stream(device=device)
