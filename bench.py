@@ -46,6 +46,10 @@ def parse():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--workload", choices=["full", "seg"], default="full",
                     help="full = configs[2] (seg + shape nets + WT loss); seg = configs[1] (seg-net only)")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="f32 (default): fp32 results — the MFMA-bound layers in the x3 arithmetic (three bf16 terms per operand, six "
+                         "products); bf16: BASELINE.json configs[1]'s stated dtype — those layers with ONE bf16 term per operand and one "
+                         "MFMA product, fp32 accumulation (wtpse_x3_terms(1)); outside the 1e-4 parity bar, reported as its own line only")
     ap.add_argument("--bn-sync", type=int, default=0, help="1: BatchNorm statistics over the global batch (parity mode)")
     ap.add_argument("--launch", choices=["eager", "plan", "graph"], default=None,
                     help="default: plan on one GPU, eager with several (the gradient all-reduces then start inside the backward, "
@@ -81,30 +85,128 @@ def build_nets(hp, pb, dev, seed=1):
 
 
 def time_kernel(fn, reps=20):
-    """Average duration (ms) of one launch of `fn` from HIP events on the stream the kernels run on."""
-    fn(); fn()
+    """Average duration (ms) of one launch from HIP events on the stream the kernels run on.  `fn`: a callable, or a LIST of
+    callables on different operand sets that the launches rotate through — the HBM-bound kernels are timed on >= 4 sets with a
+    footprint > 512 MB, so that no launch finds its input in the 256 MiB Infinity Cache from the launch before (with
+    one 134 MB set the 'HBM' rates were cache rates)."""
+    fns = fn if isinstance(fn, (list, tuple)) else [fn]
+    for f in fns:
+        f()
+    fns[0]()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(reps):
-        fn()
+    for i in range(reps):
+        fns[i % len(fns)]()
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
 
 
+ROT = 5        # operand sets of the HBM-bound micro-benchmarks: 5 x 134 MB = 671 MB of inputs alone
+
+
+# The convolution layers of ONE U-Net of the step at 256x256 (SURVEY.md Appendix B): (Cin0, Cin1 (virtual concat), Cout, H / 256, k, name)
+UNET_LAYERS = [
+    (3, 0, 16, 1, 3, "inc.conv1"), (16, 0, 16, 1, 3, "inc.conv2"), (16, 0, 16, 1, 3, "inc.conv3"),
+    (16, 0, 32, 2, 3, "down1.conv1"), (32, 0, 32, 2, 3, "down1.conv2"), (32, 0, 32, 2, 3, "down1.conv3"),
+    (32, 0, 64, 4, 3, "down2.conv1"), (64, 0, 64, 4, 3, "down2.conv2"), (64, 0, 64, 4, 3, "down2.conv3"),
+    (64, 0, 128, 8, 3, "down3.conv1"), (128, 0, 128, 8, 3, "down3.conv2"), (128, 0, 128, 8, 3, "down3.conv3"),
+    (128, 0, 256, 16, 3, "down4.conv1"), (256, 0, 256, 16, 3, "down4.conv2"), (256, 0, 256, 16, 3, "down4.conv3"),
+    (256, 0, 128, 16, 1, "up1.conv2 (before the upsampling)"), (128, 128, 256, 8, 3, "up1.conv3"),
+    (256, 0, 128, 8, 3, "up2.conv1"), (128, 0, 64, 8, 1, "up2.conv2 (before the upsampling)"), (64, 64, 128, 4, 3, "up2.conv3"),
+    (128, 0, 64, 4, 3, "up3.conv1"), (64, 0, 32, 4, 1, "up3.conv2 (before the upsampling)"), (32, 32, 64, 2, 3, "up3.conv3"),
+    (64, 0, 32, 2, 3, "up4.conv1"), (32, 0, 16, 2, 1, "up4.conv2 (before the upsampling)"), (16, 16, 32, 1, 3, "up4.conv3"),
+]
+
+
+def seg_gflop_per_image(H):
+    """Necessary convolution GFLOP per image of one seg-only step (configs[1]: two plain U-Nets — OD and OC — each forward + data
+    gradients + weight gradients; the first layer has no data gradient): from the layer table above plus the mu / outc 1x1 heads."""
+    fwd = sum(2.0 * (c0 + c1) * co * k * k * (H // d) ** 2 for c0, c1, co, d, k, _ in UNET_LAYERS)
+    fwd += 2.0 * (32 * 32 + 32 * 8 + 8 * 1) * H * H
+    first = 2.0 * 3 * 16 * 9 * H * H
+    return 2.0 * (3.0 * fwd - first) / 1e9
+
+
+def unet_layer_rooflines(B, H, dev):
+    """Every convolution of one U-Net, launched through the step's own dispatch (nn._conv / _dgrad / _wgrad: BatchNorm+ReLU prologue
+    on the inputs, bias + BatchNorm partials forward, split output of the concat layers' data gradient), HIP events.  -> per-layer rows
+    and, for the layers that run in the x3 arithmetic (the MFMA-bound ones), the FLOP-WEIGHTED rate over ALL of them per direction —
+    not the four friendliest layers."""
+    from wtpse_hip import nn as E
+    rows = []
+    for c0, c1, co, div, k, name in UNET_LAYERS:
+        Hc = H // div
+        cin = c0 + c1
+
+        class Holder(E.HipNet):
+            def __init__(self):
+                super().__init__()
+                self.conv = E.ConvP(cin, co, k)
+                self._finish_init()
+        net = Holder().to(dev)
+        net.ensure_ready(repack=True)
+        layer = net.conv
+        x0 = torch.randn(B, c0, Hc, Hc, device=dev)
+        x1 = torch.randn(B, c1, Hc, Hc, device=dev) if c1 else None
+        pro = c0 > 4
+        a0 = E.Act(x0, torch.rand(c0, 2, device=dev) + 0.5, True) if pro else E.Act(x0)
+        a1 = (E.Act(x1, torch.rand(c1, 2, device=dev) + 0.5, True) if c1 else None)
+        dy = torch.randn(B, co, Hc, Hc, device=dev)
+        fl = 2.0 * cin * co * k * k * Hc * Hc * B
+        r = {"layer": "%s %d%s->%d k%d @%dx%d" % (name, c0, ("+%d" % c1) if c1 else "", co, k, Hc, Hc), "flop": fl,
+             "fwd_path": "x3" if layer.xf_off >= 0 else ("x3/16" if layer.x16f_off >= 0 else "fp32"),
+             "dgrad_path": "x3" if layer.xd_off >= 0 else ("x3/16" if layer.x16d_off >= 0 else "fp32")}
+        r["fwd_ms"] = time_kernel(lambda: E._conv(layer, a0, a1, False, True))
+        if cin > 4:
+            r["dgrad_ms"] = time_kernel(lambda: E._dgrad(layer, dy, c0 if c1 else None))
+        net.begin_backward()
+        r["wgrad_ms"] = time_kernel(lambda: E._wgrad(layer, dy, a0, a1, with_bias=False))
+        for d in ("fwd", "dgrad", "wgrad"):
+            if d + "_ms" in r:
+                r[d + "_tflops"] = fl / r[d + "_ms"] / 1e9
+        rows.append(r)
+        del x0, x1, dy, net
+    out = {"layers": rows}
+    for d, pathkey in (("fwd", "fwd_path"), ("dgrad", "dgrad_path"), ("wgrad", "fwd_path")):
+        sel = [r for r in rows if r[pathkey] == "x3" and d + "_ms" in r and (d != "wgrad" or "k3" in r["layer"])]
+        fl, ms = sum(r["flop"] for r in sel), sum(r[d + "_ms"] for r in sel)
+        out[d] = {"tflops": fl / ms / 1e9, "frac": fl / ms / 1e9 / MFMA_X3_PEAK_TF, "layers": len(sel), "ms_sum": ms,
+                  "min_tflops": min(r[d + "_tflops"] for r in sel), "min_tflops_3x3": min(r[d + "_tflops"] for r in sel if " k3 " in r["layer"])}
+    f, g = out["fwd"], out["dgrad"]
+    fl = sum(r["flop"] for r in rows if r["fwd_path"] == "x3") + sum(r["flop"] for r in rows if r["dgrad_path"] == "x3" and "dgrad_ms" in r)
+    out["fwd_dgrad"] = {"tflops": fl / (f["ms_sum"] + g["ms_sum"]) / 1e9, "frac": fl / (f["ms_sum"] + g["ms_sum"]) / 1e9 / MFMA_X3_PEAK_TF}
+    return out
+
+
+FAMILIES = (("x3_conv", ("conv_x3_k", "conv_x3r_k")), ("x3_wgrad", ("wgrad_r_k<2", "wgrad_r_k<1, 2", "wgrad_r_k<2, 1", "conv_wgrad_x3_k", "wgrad_fold4_k")),
+            ("bn_backward", ("bn_bwd_",)), ("conv16", ("conv_fwd_k<3, 3", "wgrad_r_k<1, 1")), ("heads", ("head_",)),
+            ("conv_fp32", ("conv_fwd_k", "conv_wgrad_k", "wgrad_reduce_k")))
+
+
 def dominant_kernel_share():
-    """(kernel name, share of summed kernel time) of the largest row of the newest in-step rocprofv3 summary committed
-    under profiles/ (r*_bench_b32_kernel_stats.csv): the `roofline` object names the kernel the profile names."""
+    """The kernel FAMILY with the largest share of the summed kernel time in the newest in-step rocprofv3 summary committed under
+    profiles/ (r*_bench_b32_single_stream_kernel_stats.csv: the kernels back to back; falls back to the three-stream profile): the
+    `roofline` object is that family's (by family, not by the largest single template instantiation)."""
     import csv
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_b32_kernel_stats.csv")))
+    files = (sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_b32_single_stream_kernel_stats.csv")))
+             or sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_b32_kernel_stats.csv"))))
     if not files:
         return None
     with open(files[-1]) as f:
         rows = [r for r in csv.DictReader(f) if not r["Name"].startswith("__amd_rocclr")]
-    top = max(rows, key=lambda r: float(r["Percentage"]))
-    return {"profile": os.path.relpath(files[-1], ROOT), "kernel": top["Name"].split("(")[0], "percent": float(top["Percentage"]),
-            "calls": int(top["Calls"])}
+    tot = sum(float(r["TotalDurationNs"]) for r in rows)
+    fam = {}
+    for r in rows:
+        for name, pats in FAMILIES:
+            if any(p in r["Name"] for p in pats):
+                fam[name] = fam.get(name, 0.0) + float(r["TotalDurationNs"])
+                break
+    top = max(fam, key=fam.get)
+    return {"profile": os.path.relpath(files[-1], ROOT), "family": top, "percent": 100.0 * fam[top] / tot,
+            "families_percent": {k: round(100.0 * v / tot, 1) for k, v in sorted(fam.items(), key=lambda kv: -kv[1])},
+            "kernel": top}
 
 
 def kernel_rooflines(B, H, dev):
@@ -162,8 +264,9 @@ def kernel_rooflines(B, H, dev):
     # v_mfma_f32_16x16x32_bf16 with register-resident weight fragments (conv_fwd_k<3,3,5>; WTPSE_X16=0: the fp32-input MFMA
     # conv_fwd_k<3,0,5>), weight gradient on wgrad_r_k<1,1> — HBM-bound: 2 x 16 x H x W x 4 bytes per image either way
     C16 = 16
-    x16 = torch.randn(B, C16, H, H, device=dev)
-    dy16 = torch.randn(B, C16, H, H, device=dev)
+    x16s = [torch.randn(B, C16, H, H, device=dev) for _ in range(ROT)]
+    dy16s = [torch.randn(B, C16, H, H, device=dev) for _ in range(ROT)]
+    x16, dy16 = x16s[0], dy16s[0]
     p16 = torch.rand(C16, 2, device=dev) + 0.5
 
     class Holder16(E.HipNet):
@@ -174,12 +277,13 @@ def kernel_rooflines(B, H, dev):
     n16 = Holder16().to(dev)
     n16.ensure_ready(repack=True)
     a16 = E.Act(x16, p16, True)
+    a16s = [E.Act(x, p16, True) for x in x16s]
     nb16 = 2.0 * B * C16 * H * H * 4
-    ms = time_kernel(lambda: E._conv(n16.conv, a16, None, False, True))
+    ms = time_kernel([(lambda a=a: E._conv(n16.conv, a, None, False, True)) for a in a16s])
     out["c16_fwd"] = {"kernel": "conv_fwd_k<3,%d,5> 16->16 3x3 @%dx%d B=%d (BatchNorm+ReLU prologue, bias, BatchNorm partials)" % (3 if E.X16 else 0, H, H, B),
                       "ms": ms, "gbs": nb16 / ms / 1e6, "bytes_per_launch": nb16, "tflops": 2.0 * 16 * 16 * 9 * H * H * B / ms / 1e9}
     n16.begin_backward()
-    ms = time_kernel(lambda: E._wgrad(n16.conv, dy16, a16, None, with_bias=True))
+    ms = time_kernel([(lambda a=a, d=d: E._wgrad(n16.conv, d, a, None, with_bias=True)) for a, d in zip(a16s, dy16s)])
     out["c16_wgrad"] = {"kernel": "wgrad_r_k<1,1> + slab fold 16->16 3x3 @%dx%d B=%d (prologue, with bias gradient)" % (H, H, B),
                         "ms": ms, "gbs": nb16 / ms / 1e6, "bytes_per_launch": nb16, "tflops": 2.0 * 16 * 16 * 9 * H * H * B / ms / 1e9}
     C, Hc = 64, H // 2
@@ -199,7 +303,8 @@ def kernel_rooflines(B, H, dev):
     flops = 2.0 * C * C * 9 * Hc * Hc * B
     out["conv"] = {"kernel": "conv_fwd_k<3,2,5> (fp32-input MFMA) 64->64 3x3 @%dx%d B=%d (+bias, BN partials)" % (Hc, Hc, B), "ms": ms,
                    "tflops": flops / ms / 1e9, "flop_per_launch": flops}
-    z = torch.randn(B, 16, H, H, device=dev)
+    zs = [torch.randn(B, 16, H, H, device=dev) for _ in range(ROT)]
+    z = zs[0]
     L = ops.lib()
     S = L.query("wtpse_wt_split", B, H * H, 0)
     partial = torch.empty(B * S * 256, device=dev)
@@ -208,48 +313,56 @@ def kernel_rooflines(B, H, dev):
             torch.empty(3, device=dev)]
     pb = B // 3
 
-    def wt():
-        L.call("wtpse_wt_loss_fwd", z.data_ptr(), B, 16, H * H, 1e-5, 0.0, 3, pb, partial.data_ptr(), *[b.data_ptr() for b in bufs],
+    def wt(zz):
+        L.call("wtpse_wt_loss_fwd", zz.data_ptr(), B, 16, H * H, 1e-5, 0.0, 3, pb, partial.data_ptr(), *[b.data_ptr() for b in bufs],
                ops.stream_ptr())
-    ms = time_kernel(wt)
+    ms = time_kernel([(lambda zz=zz: wt(zz)) for zz in zs])
     nbytes = B * 16 * H * H * 4.0
-    out["wt_fwd"] = {"kernel": "wtpse_wt_loss_fwd (gram_partial_k + 2 tail launches) [%d,16,%d,%d]" % (B, H, H), "ms": ms,
+    out["wt_fwd"] = {"kernel": "wtpse_wt_loss_fwd (gram_partial_k + tail) [%d,16,%d,%d], %d operand sets in rotation" % (B, H, H, ROT), "ms": ms,
                      "gbs": nbytes / ms / 1e6, "bytes_per_launch": nbytes}
     # in a training step the Gram partials come from the epilogue of the DeepWT conv that writes z (wtpse_conv_fwd_gram):
     # the loss then costs the extra epilogue time plus the tail on the partials, and never reads z
-    t_plain = time_kernel(lambda: E._conv(n16.conv, x16))
-    t_gram = time_kernel(lambda: E._conv_gram(n16.conv, x16))
+    t_plain = time_kernel([(lambda x=x: E._conv(n16.conv, x)) for x in x16s])
+    t_gram = time_kernel([(lambda x=x: E._conv_gram(n16.conv, x)) for x in x16s])
     zz, gp = E._conv_gram(n16.conv, x16)
     t_tail = time_kernel(lambda: ops.wt_loss_fwd(zz, 3, pb, 0.0, gram_partial=gp))
-    del x16, dy16, n16
+    del x16, dy16, x16s, dy16s, a16s, n16
     out["wt_fwd"]["fused_in_step"] = {
         "what": "Gram partials in the epilogue of the conv that writes z (16->16 3x3, the kernel of c16_fwd) + wtpse_wt_loss_fwd_partials",
         "conv_ms": t_plain, "conv_with_gram_epilogue_ms": t_gram, "tail_on_partials_ms": t_tail,
         "loss_cost_ms": (t_gram - t_plain) + t_tail, "hbm_bytes_avoided_per_call": nbytes,
         "equivalent_gbs": nbytes / ((t_gram - t_plain) + t_tail) / 1e6}
-    dz = torch.empty_like(z)
+    dzs = [torch.empty_like(z) for _ in range(ROT)]
     M = torch.randn(B * 256, device=dev) * 1e-3
-    bpi = (H * H + 1023) // 1024
 
-    def wtb():
-        L.call("wtpse_wt_loss_bwd", z.data_ptr(), B, 16, H * H, 0.0, 3, pb, bufs[0].data_ptr(), bufs[2].data_ptr(), bufs[3].data_ptr(),
+    def wtb(zz, dz):
+        L.call("wtpse_wt_loss_bwd", zz.data_ptr(), B, 16, H * H, 0.0, 3, pb, bufs[0].data_ptr(), bufs[2].data_ptr(), bufs[3].data_ptr(),
                bufs[5].data_ptr(), 0, 0, 0, 1.0, 1.0, 1.0, M.data_ptr(), dz.data_ptr(), 0, ops.stream_ptr())
-    ms = time_kernel(wtb)
-    out["wt_bwd"] = {"kernel": "wtpse_wt_loss_bwd (gram_bwd_k) [%d,16,%d,%d]" % (B, H, H), "ms": ms,
+    ms = time_kernel([(lambda zz=zz, dz=dz: wtb(zz, dz)) for zz, dz in zip(zs, dzs)])
+    out["wt_bwd"] = {"kernel": "wtpse_wt_loss_bwd (gram_bwd_k) [%d,16,%d,%d], %d operand sets in rotation" % (B, H, H, ROT), "ms": ms,
                      "gbs": 2 * nbytes / ms / 1e6, "bytes_per_launch": 2 * nbytes}
-    del z, dz, partial
+    # counter calibration streams (tools/pmc_traffic.py): plain copies of a known size at 16 and 4 bytes per lane, rotating too
+    ncal = zs[0].numel()
+    for width in (16, 4):
+        ms = time_kernel([(lambda a=a, b=b: L.call("wtpse_copy_probe", a.data_ptr(), b.data_ptr(), ncal, width, ops.stream_ptr()))
+                          for a, b in zip(zs, dzs)])
+        out["copy_w%d" % width] = {"kernel": "copy_w%d_k: %d MB in + %d MB out, %d bytes per lane" % (width, ncal * 4 >> 20, ncal * 4 >> 20, width),
+                                   "ms": ms, "gbs": 2.0 * ncal * 4 / ms / 1e6, "bytes_per_launch": 2.0 * ncal * 4}
+    del z, zs, dzs, partial
     # The literal 2-D DWT BASELINE.json's wording names: a stand-alone micro-benchmark, NOT part of WT-PSE, parity unpinned
     # (csrc/dwt.hip).  Algorithmic bytes: every level reads and writes its region once.
     from wtpse_hip import dwt
     out["dwt"] = []
     for shp, lv in (((B, 16, H, H), 3), ((max(B // 2, 1), 16, 2 * H, 2 * H), 4)):
-        xd = torch.randn(*shp, device=dev)
+        xds = [torch.randn(*shp, device=dev) for _ in range(ROT if shp[2] == H else 3)]
+        xd = xds[0]
         nb = 8.0 * xd.numel() * sum(0.25 ** l for l in range(lv))
         for wv in ("haar", "db2"):
-            ms = time_kernel(lambda: dwt.dwt2(xd, wv, lv))
+            ms = time_kernel([(lambda x=x: dwt.dwt2(x, wv, lv)) for x in xds])
             out["dwt"].append({"kernel": "wtpse_dwt2_fwd %s, %d levels, %s" % (wv, lv, list(shp)), "ms": ms, "gbs": nb / ms / 1e6,
                                "bytes_per_launch": nb, "min_bytes": 8.0 * xd.numel(), "gbs_min_bytes": 8.0 * xd.numel() / ms / 1e6})
-        del xd
+        del xd, xds
+    out["unet"] = unet_layer_rooflines(B, H, dev)
     return out
 
 
@@ -329,14 +442,22 @@ def _x3_on():
 
 
 def measured_traffic():
-    """HBM bytes per launch measured with rocprofv3 --pmc (FETCH_SIZE / WRITE_SIZE in separate passes, gfx950
-    correction applied: FETCH_SIZE x2 for wide coalesced streams) on `bench.py --kernels-only`; committed under
-    profiles/ by tools/pmc_traffic.py.  Returns {} when no measurement has been committed."""
+    """HBM bytes per launch measured with rocprofv3 --pmc (FETCH_SIZE / WRITE_SIZE in separate passes; factors calibrated per access
+    width on the copy kernels of the same run: tools/pmc_traffic.py) on `bench.py --kernels-only`, committed under profiles/.  The
+    file carries the source hash of the library it was measured on (tools/profile_round.sh): a measurement taken on OTHER kernels
+    than the ones loaded now is refused.  -> ({key: traffic}, note)."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.isfile(path):
-        with open(path) as f:
-            return json.load(f)
-    return {}
+    if not os.path.isfile(path):
+        return {}, "no committed measurement"
+    with open(path) as f:
+        tr = json.load(f)
+    from wtpse_hip import build
+    stamp = tr.get("_stamp", {})
+    if stamp.get("source_hash") != build.source_hash():
+        return {}, ("profiles/pmc_traffic.json was measured on library %s, the loaded library is %s: traffic withheld (re-run "
+                    "tools/profile_round.sh)" % (stamp.get("source_hash"), build.source_hash()))
+    return tr, ("committed profile profiles/pmc_traffic.json (rocprofv3 --pmc of `bench.py --kernels-only`, git %s, same library "
+                "sources as loaded now), not measured by this run" % stamp.get("git_head", "?"))
 
 
 def main():
@@ -368,6 +489,11 @@ def main():
         from wtpse_hip.dp import DataParallel
         dp = DataParallel(world, rank, dev, bn_sync=bool(args.bn_sync))
 
+    if args.dtype == "bf16":
+        from wtpse_hip import ops as _ops
+        _ops.lib().query("wtpse_x3_terms", 1)
+        global MFMA_X3_PEAK_TF
+        MFMA_X3_PEAK_TF = 16.0 * 157.3          # one MFMA product per multiply: the full dense bf16 peak is the bound
     if args.kernels_only:
         kr = kernel_rooflines(args.batch, args.size, dev)
         print(json.dumps(kr))
@@ -453,8 +579,11 @@ def main():
             "metric": ("training images/sec (%dx%d fundus) — " % (H, H)) + ("full WT-PSE iteration" if full else "seg-net only"),
             "value": ips, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (layers with > 16 output channels: fp32 operands as 3 bf16 terms, 6 bf16 MFMA products, fp32 accumulation; "
-                     "the rest fp32-input MFMA)" if _x3_on() else "f32", "data": "synthetic",
+            "dtype": ("bf16 (layers with > 16 output channels: operands rounded to one bf16 term, one MFMA product, fp32 accumulation; the "
+                      "16-channel layers, the 1x1 heads, BatchNorm and Adam in fp32) — NOT within the 1e-4 parity bar"
+                      if args.dtype == "bf16" else
+                      "f32 (layers with > 16 output channels: fp32 operands as 3 bf16 terms, 6 bf16 MFMA products, fp32 accumulation; "
+                      "the rest fp32-input MFMA)" if _x3_on() else "f32"), "data": "synthetic",
             "config": {"workload": (("BASELINE.json configs[2]: full WT-PSE (seg+shape nets + WT loss)" if H == 256 else
                                      "BASELINE.json configs[4] per-GPU share: full WT-PSE at high resolution") if full else
                                     "BASELINE.json configs[1]: seg-net only") + ", 3x%dx%d, batch %d per GPU" % (H, H, B),
@@ -465,7 +594,8 @@ def main():
             "roi_presteps": presteps,
             "host_enqueue_ms_per_step": 1e3 * t_host / args.steps,
             "host_cpu_ms_per_step": 1e3 * timed.cpu / args.steps,
-            "conv_tflops_end_to_end": ips * GFLOP_PER_IMAGE * (H * H / 65536.0) / 1e3 if full else None,
+            "conv_tflops_end_to_end": (ips * GFLOP_PER_IMAGE * (H * H / 65536.0) / 1e3 if full else ips * seg_gflop_per_image(H) / 1e3),
+            "gflop_per_image": GFLOP_PER_IMAGE * (H * H / 65536.0) if full else seg_gflop_per_image(H),
             "losses": losses,
         }
         if degenerate is not None:
@@ -473,27 +603,52 @@ def main():
         if world == 1 and not args.no_kernel_roofline:
             log("kernel rooflines")
             kr = kernel_rooflines(B, H, dev)
-            tr = measured_traffic() if (B, H) == (32, 256) else {}
+            tr, tr_note = measured_traffic() if (B, H) == (32, 256) else ({}, "traffic is measured at B=32, 256x256 only")
             dom = dominant_kernel_share()
-            lead = "x3_wgrad" if (dom and "wgrad" in dom["kernel"]) else "x3_conv"
+            lead = "x3_wgrad" if (dom and dom["family"] == "x3_wgrad") else "x3_conv"
 
             def mfma_line(k, traffic_key):
                 r = kr[k]
                 return {"bound": "mfma", "kernel": r["kernel"], "achieved": r["tflops"], "peak": MFMA_X3_PEAK_TF,
                         "unit": "TFLOP/s", "frac": r["tflops"] / MFMA_X3_PEAK_TF, "traffic": tr.get(traffic_key),
-                        "traffic_source": "committed profile profiles/pmc_traffic.json (rocprofv3 --pmc of `bench.py --kernels-only`), "
-                                          "not measured by this run",
+                        "traffic_source": tr_note,
                         "dvfs_ceiling_note": "on random operands the chip holds 1.5-1.9 GHz under bf16 MFMA streams, not 2.4: a bare "
                                              "LDS-fed MFMA loop reaches ~250 TFLOP/s x3-equivalent, a register-fed 16x16x32 loop ~320 "
                                              "(profiles/r03_mfma_peak.txt, tools/probe/mfma_peak.hip)",
                         "frac_of_fp32_mfma_peak": r["tflops"] / MFMA_F32_PEAK_TF,
-                        "peak_note": "bf16 dense MFMA peak (16 x 157.3) / 6 products per fp32 multiply; fp32-input MFMA peak 157.3",
+                        "peak_note": ("bf16 dense MFMA peak (16 x 157.3): one product per multiply in the bf16 mode" if args.dtype == "bf16" else
+                                      "bf16 dense MFMA peak (16 x 157.3) / 6 products per fp32 multiply; fp32-input MFMA peak 157.3"),
                         "ms_per_launch": r["ms"], "flop_per_launch": r["flop_per_launch"], "launches": r.get("launches")}
             if dom:
                 dom["source"] = "committed profile %s, not measured by this run" % dom["profile"]
-            line["roofline"] = dict(mfma_line(lead, lead), dominant_in_profile=dom)
+            # Headline roofline: the kernel FAMILY that leads the in-step profile, priced on EVERY layer of a U-Net that runs on it
+            # (FLOP-weighted: total FLOP / total time of the launches measured live here), not on its best layers.  `launches` keeps
+            # the four conv3 layers of up1..up4 (rounds 1-3's number) for comparison; `step_frac` is the whole step against the bound.
+            un = kr["unet"]
+            fam = un["wgrad"] if lead == "x3_wgrad" else un["fwd_dgrad"]
+            head = mfma_line(lead, lead)
+            head.update({"achieved": fam["tflops"], "frac": fam["frac"],
+                         "achieved_note": "FLOP-weighted over all %d forward + %d data-gradient launches of one U-Net that run on the x3 "
+                                          "kernels (3x3 and 1x1, every level: `roofline_unet_layers`), HIP events" % (un["fwd"]["layers"], un["dgrad"]["layers"])
+                         if lead == "x3_conv" else "FLOP-weighted over all %d 3x3 weight-gradient launches of one U-Net on the x3 kernels" % un["wgrad"]["layers"],
+                         "best_layers_tflops": kr[lead]["tflops"], "best_layers_frac": kr[lead]["tflops"] / MFMA_X3_PEAK_TF,
+                         "step_frac": (line["conv_tflops_end_to_end"] / MFMA_X3_PEAK_TF) if line["conv_tflops_end_to_end"] else None,
+                         "step_frac_note": "conv_tflops_end_to_end (224.5 GFLOP of necessary convolution work per image x images/s) / the x3 bound: "
+                                           "the whole step, every kernel and every gap included"})
+            line["roofline"] = dict(head, dominant_in_profile=dom)
+            line["roofline_unet_layers"] = {"what": "every convolution of one U-Net as the step launches it (B=%d): FLOP-weighted TFLOP/s over the "
+                                                    "layers on the x3 kernels, per direction, and the per-layer rows" % B,
+                                            "fwd": un["fwd"], "dgrad": un["dgrad"], "wgrad": un["wgrad"], "fwd_dgrad": un["fwd_dgrad"],
+                                            "peak": MFMA_X3_PEAK_TF, "layers": un["layers"]}
             for k in ("x3_fwd", "x3_dgrad", "x3_wgrad"):
                 line["roofline_" + k] = mfma_line(k, "x3_wgrad" if k == "x3_wgrad" else "x3_conv")
+            for k in ("copy_w16", "copy_w4"):
+                w = kr[k]
+                line["roofline_" + k] = {"bound": "hbm", "kernel": w["kernel"], "achieved": w["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                         "frac": w["gbs"] / HBM_PEAK_GBS, "traffic": tr.get(k), "ms_per_launch": w["ms"],
+                                         "bytes_per_launch": w["bytes_per_launch"],
+                                         "note": "plain streaming copy: what this box's HBM sustains at this access width (the yardstick "
+                                                 "for the HBM-bound kernels; MI355X_MICROARCH.md: ~6.3 TB/s achievable)"}
             c = kr["conv"]
             line["roofline_conv_fwd_fp32"] = {"bound": "mfma", "kernel": c["kernel"], "achieved": c["tflops"], "peak": MFMA_F32_PEAK_TF,
                                               "unit": "TFLOP/s", "frac": c["tflops"] / MFMA_F32_PEAK_TF, "traffic": tr.get("conv"),

@@ -56,10 +56,17 @@ int wtpse_conv_fwd_gram(const float* in0, int C0, const float* wpacked, const fl
  * conv and direction ceil16(K) * ceil32(rows) * taps * 3 unsigned shorts (forward: rows = Cout, K = Cin; data gradient:
  * rows = Cin, K = Cout), layout [K chunk 16][row block 32][tap][term 3][k half 2][row 32][8 k]. */
 int wtpse_conv_x3_stats_blocks(int B, int H, int W, int Cout);   /* rows of `stats` for wtpse_conv_fwd_x3 */
-/* 3x3 launches of the x3 entry points run conv_x3r_k (weights fed from registers, input tile double-buffered in LDS) when on = 1
- * (default; environment WTPSE_X3R=0 turns it off) and conv_x3_k (weights staged through LDS) when on = 0; on < 0 only queries.
- * Returns the previous setting.  The two kernels give bitwise the same results (tests/test_conv_x3_gpu.py). */
+/* Which 3x3 launches of the x3 entry points run conv_x3r_k (weights fed from registers, input tile double-buffered in LDS) instead
+ * of conv_x3_k (weights staged through LDS): on = 1 (default) the launches with 64-channel output blocks, 2 all of them, 0 none;
+ * on < 0 only queries (environment: WTPSE_X3R=0|1|2).  Returns the previous setting.  The two kernels give bitwise the same
+ * results (tests/test_conv_x3_gpu.py::test_x3r_equals_x3); the choice is by measurement (profiles/r04_microbench_x3.txt). */
 int wtpse_x3r_enable(int on);
+/* bf16 terms per fp32 operand in the x3 kernels (wtpse_conv_fwd_x3 and the data gradients on it, wtpse_conv_wgrad_r): 3 (default) =
+ * the fp32-accuracy arithmetic above; 1 = the `bf16` mode of BASELINE.json configs[1]: operands rounded to bf16 (nearest even), ONE
+ * bf16 MFMA product per multiply, fp32 accumulation — outside the 1e-4 parity bar by construction (tests/test_bf16_mode_gpu.py
+ * states its tolerance).  The weight gradients of the 16-pixel-wide maps (wtpse_conv_wgrad_x3) and the 16-channel layers
+ * (wtpse_conv16_x3) keep three terms.  Environment: WTPSE_X3_TERMS=1.  Other values only query; returns the previous setting. */
+int wtpse_x3_terms(int terms);
 int wtpse_pack_conv_weights_x3(const float* params, const int* desc, int n_desc, unsigned short* packed, void* stream);
 int wtpse_conv_fwd_x3(const float* in0, int C0, const float* in1, int C1, const unsigned short* wpacked, const float* bias,
                       const float* pro0, const float* pro1, int pro_relu, float* out0, float* out1, int Csplit, float* stats,
@@ -333,6 +340,9 @@ int wtpse_relu_mask(const float* dz, const float* ref, float* dy, int accumulate
 int wtpse_axpy(float* dst, const float* src, float alpha, long long n, void* stream);
 int wtpse_reduce_rows(const float* partial, int rows, int cols, float* out, int accumulate, float scale, void* stream);
 int wtpse_zero(void* p, long long nbytes, void* stream);
+/* dst[0:n] = src[0:n] (n % 4 == 0, 16-byte aligned) with 16 or 4 bytes per lane and access: measurement infrastructure only — the
+ * known-byte-count streams the rocprofv3 FETCH_SIZE / WRITE_SIZE factors are calibrated on (tools/pmc_traffic.py, bench.py --kernels-only). */
+int wtpse_copy_probe(const float* src, float* dst, long long n, int bytes_per_lane, void* stream);
 
 /* ---- standalone 2-D discrete wavelet transform (csrc/dwt.hip) — NOT part of WT-PSE ---------------------------------------
  * The reference has no wavelet transform (its "WT" is the whitening transform); these two entry points exist only as the

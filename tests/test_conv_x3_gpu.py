@@ -509,10 +509,10 @@ def test_x3r_equals_x3(case):
         torch.cuda.synchronize()
         return outs
 
-    assert o.lib().query("wtpse_x3r_enable", -1) == 1, "conv_x3r_k must be the default"
-    new = run()
-    o.lib().query("wtpse_x3r_enable", 0)
+    assert o.lib().query("wtpse_x3r_enable", 2) == 1, "conv_x3r_k on the 64-channel blocks must be the default"
     try:
+        new = run()                              # mode 2: conv_x3r_k on every 3x3 launch, also the shapes it is not the default for
+        o.lib().query("wtpse_x3r_enable", 0)
         old = run()
     finally:
         o.lib().query("wtpse_x3r_enable", 1)

@@ -127,8 +127,10 @@ def test_dgrad_bnb_repeatable(layout, C, H, W, k, B):
         wptr = packed.data_ptr() + 4 * wd
     g0, _, st0, _ = o.dgrad_bnb(du, wptr, x3, C, k, y, ss, mean, True)
     g0, st0 = g0.clone(), st0.clone()
-    # the masks against the forward pass's own decision, computed the way the forward computes it (one fmaf per element)
-    act = torch.addcmul(ss[:, 1].view(1, -1, 1, 1), y, ss[:, 0].view(1, -1, 1, 1))
+    # the masks against the forward pass's own decision fmaf(y, scale, shift) > 0: in fp64 the product is exact and the sum keeps
+    # its sign, so the sign of the fp64 value IS the sign of the single-rounding fmaf (an unfused fp32 y * scale + shift is not: it
+    # differed on 1 element of 67 M here)
+    act = y.double() * ss[:, 0].double().view(1, -1, 1, 1) + ss[:, 1].double().view(1, -1, 1, 1)
     assert int(((g0 != 0) & ~(act > 0)).sum()) == 0, "a masked-out element carries a gradient"
     del act
     for it in range(40 if big else 150):
@@ -197,7 +199,7 @@ def test_maxpool_bwd_bnb_repeatable(B, C, H, W):
     r = o.maxpool2_bwd_bnb(x, dout, None, pro, True, mean)
     assert r is not None
     g0, st0 = r[0].clone(), r[1].clone()
-    act = torch.addcmul(pro[:, 1].view(1, -1, 1, 1), x, pro[:, 0].view(1, -1, 1, 1))
+    act = x.double() * pro[:, 0].double().view(1, -1, 1, 1) + pro[:, 1].double().view(1, -1, 1, 1)     # sign of fmaf(x, scale, shift)
     assert int(((g0 != 0) & ~(act > 0)).sum()) == 0
     for it in range(60):
         junk = torch.empty((1 << 22) + 4096 * it, device=DEV).fill_(float(it))

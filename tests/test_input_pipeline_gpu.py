@@ -44,3 +44,28 @@ def test_pipeline_vs_oracle_256():
         assert np.array_equal(image[i].cpu().numpy(), im0), i
         assert np.array_equal(od[i].cpu().numpy(), od0), i
         assert np.array_equal(oc[i].cpu().numpy(), oc0), i
+
+
+def test_png_tree_to_device_batch(tmp_path):
+    """End of §8f row 3: the synthetic PNG tree (oracle/fundus_tree.py; layout of fundus_dataloader.py:41-44) -> FundusTree /
+    multi_batch (the reference's dataset + get_multi_batch on the host) -> DeviceInputPipeline: the fp32 batch equals, bit for bit,
+    the CPU oracle's Resize / RandomScaleCrop / Normalize_tf / ToTensor on the same decoded samples with the same random draws."""
+    from oracle import transforms_cpu as T
+    from oracle.fundus_tree import make_tree
+    from wtpse_hip.fundus_data import FundusTree, multi_batch
+    from wtpse_hip.input_pipeline import DeviceInputPipeline, draw
+    make_tree(str(tmp_path), seed=5)
+    sets = [FundusTree(str(tmp_path), "train", (i,)) for i in (1, 2, 4)]       # datasetTrain = [1, 2, 4] (BASELINE.json configs[0])
+    np.random.seed(21)
+    images, masks = multi_batch(sets, 2)
+    rng = random.Random(7)
+    draws = [draw(rng, 256) for _ in images]
+    image, od, oc = DeviceInputPipeline(256, "cuda")(images, masks, draws)
+    assert image.shape == (6, 3, 256, 256) and od.shape == (6, 1, 256, 256)
+    for i, d in enumerate(draws):
+        seed = 1.0 if d[:2] != (256, 256) else 0.0
+        im0, od0, oc0 = T.train_transform(images[i], masks[i], masks[i], (seed,) + d, 256)
+        assert np.array_equal(image[i].cpu().numpy(), im0), i
+        assert np.array_equal(od[i].cpu().numpy(), od0), i
+        assert np.array_equal(oc[i].cpu().numpy(), oc0), i
+    assert 0.0 < float(od.mean()) < 1.0 and float(oc.sum()) > 0        # disc and cup made it through the thresholds

@@ -4,6 +4,7 @@ under tests/golden/ and (ii) the CPU oracle on the same seeded inputs, through t
 
 Tolerance: north_star asks logits / Dice / WT-loss values within 1e-4 fp32 of the reference."""
 import os
+import time
 
 import numpy as np
 import pytest
@@ -120,8 +121,18 @@ def check_grads_vs_checksums(module, g, prefix, min_seen, kink_probe=None):
     assert np.median(np.asarray(pooled)) < (1e-2 if not kinked else 3e-2), np.median(np.asarray(pooled))
 
 
+def heartbeat(msg):
+    """The CPU oracle at the benchmark's batch runs for minutes without a sign of life: leave one under gpurun_out/ (the GPU box's
+    watchdog takes a command for hung after 7 minutes without new output) — a no-op anywhere else."""
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(d):
+        with open(os.path.join(d, "heartbeat.log"), "a") as f:
+            f.write("%s %s\n" % (time.strftime("%H:%M:%S"), msg))
+
+
 def oracle_grads(fn, sds, dtype):
     """Run `fn(*state_dicts cast to dtype)` -> scalar loss on the CPU oracle; -> list of {name: grad (fp64)}."""
+    heartbeat("oracle_grads %s" % str(dtype))
     cast = [{k: (v.detach().clone().to(dtype).requires_grad_(not O.is_buffer(k)) if v.is_floating_point() else v.clone())
              for k, v in sd.items()} for sd in sds]
     fn(*cast).backward()
@@ -132,7 +143,7 @@ CAL = 3.0      # the HIP path may be at most this many times as far from the fp6
 CAL_KINK = 10.0  # ... on the 32x32 / 64x64 fixtures at B=6, where kink flips (not rounding) set both distances: see below
 
 
-def assert_calibrated(module, g32, g64, what, cal=CAL, probes=None):
+def assert_calibrated(module, g32, g64, what, cal=CAL, probes=None, strict=False):
     """The HIP path must be an fp32 implementation of the reference's graph of the same quality as the reference's own
     CPU path.  Yardstick: relative L2 distance to the oracle evaluated in fp64.
       * over ALL gradients of the network concatenated: HIP <= cal x CPU-fp32 + 2e-4
@@ -147,6 +158,8 @@ def assert_calibrated(module, g32, g64, what, cal=CAL, probes=None):
     probes: callable -> fp32 oracle gradients on perturbed inputs, run only when the plain comparison fails (a 32x32 fixture
     whose deepest 2x2 maps hold a unit within rounding of its kink: the fp32 reference itself then moves by 0.3-9 % under a
     1e-6 input perturbation — measured on cases [3-1-32] and golden case 2 — and so may any other fp32 implementation).
+    strict (the benchmark's geometries, 256x256 and 512x512: no 2x2 maps to excuse anything, no probes): EVERY tensor must be within
+    cal x CPU-fp32 + 5e-4 — a fixed band, no allowance for outliers and no failure-triggered widening.
     -> (HIP distance, CPU-fp32 distance); messages carry the measured ratios."""
     def distances(g32_runs):
         """-> (HIP total, CPU-fp32 total, [(HIP, CPU-fp32, name)]); CPU-fp32 = the farthest of the given fp32 runs."""
@@ -175,7 +188,7 @@ def assert_calibrated(module, g32, g64, what, cal=CAL, probes=None):
             msgs.append(f"all gradients: HIP {tot_h:.3e} vs CPU-fp32 {tot_c:.3e} (ratio {tot_h / max(tot_c, 1e-30):.2f}, bound {cal:.0f}x + 2e-4)")
         if med > cal:
             msgs.append(f"median per-tensor ratio HIP / CPU-fp32 = {med:.2f} > {cal:.0f}")
-        if len(bad) > 0.03 * len(per):
+        if len(bad) > (0 if strict else 0.03 * len(per)):
             msgs.append(f"{len(bad)}/{len(per)} tensors beyond {cal:.0f}x + 5e-4, e.g. {sorted(bad, reverse=True)[:3]}")
         if worst[0] > 2e-2:
             msgs.append(f"{worst[2]}: HIP {worst[0]:.3e} vs CPU-fp32 {worst[1]:.3e}")
@@ -185,6 +198,7 @@ def assert_calibrated(module, g32, g64, what, cal=CAL, probes=None):
     med, msgs = verdict(tot_h, tot_c, per)
     print(f"[calibrated {what}] all gradients: HIP {tot_h:.3e} vs CPU-fp32 {tot_c:.3e} from the fp64 oracle: ratio "
           f"{tot_h / max(tot_c, 1e-30):.2f} (bound {cal:.0f}x + 2e-4); median per-tensor ratio {med:.2f} (bound {cal:.0f})")
+    assert not (strict and probes is not None)
     if msgs and probes is not None:
         # Is the fixture on a kink?  The yardstick becomes the farthest of the reference's fp32 runs on inputs perturbed by
         # 1e-6 / 3e-6 (perturbed()): what a flip of a near-zero unit is worth on this fixture, measured, not guessed.
@@ -415,12 +429,15 @@ def test_convu_both_orders_vs_oracle(shape, first):
         close(p.grad, ref, rtol=5e-3, atol=5e-4 * float(ref.abs().max()) + 1e-7, what=k)
 
 
-@pytest.mark.parametrize("B,pb,H", [(3, 1, 32), (6, 2, 32), (6, 2, 64), (6, 2, 256)])
+@pytest.mark.parametrize("B,pb,H", [(3, 1, 32), (6, 2, 32), (6, 2, 64), (6, 2, 256), (32, 10, 256), (3, 1, 512)])
 def test_gradients_calibrated(B, pb, H):
     """Every parameter gradient of call A (seg net + teacher + WT loss) and call B (student) against the oracle
-    evaluated in fp64, with the oracle's own fp32 run as the yardstick.  The 256x256 case runs the backward kernels in
+    evaluated in fp64, with the oracle's own fp32 run as the yardstick.  The 256x256 cases run the backward kernels in
     the instantiations the benchmark uses (weight gradients at ksplit 512 + slab fold, the big-map BatchNorm backward,
-    the bilinear adjoint and the fused heads at full resolution)."""
+    the bilinear adjoint and the fused heads at full resolution); [32-10-256] IS the benchmark's geometry (BASELINE.json
+    configs[2]: 8192-workgroup launches, the weight gradient's unit / segment split, statistics folded by the stand-alone finalize
+    beyond 2048 workgroups and by the launches' last workgroups below), [3-1-512] the per-image geometry of configs[4].  At
+    256x256 and 512x512 the per-tensor band is fixed (strict: every tensor, no probes)."""
     img, od, _ = make_inputs(600, B, H, H)
     eps = make_noise(700, (B, 1, H, H))
     main, shape, _, _ = build_nets(pb)
@@ -439,7 +456,9 @@ def test_gradients_calibrated(B, pb, H):
     cal = CAL if (H >= 256 or B == 3) else CAL_KINK
     n_probe = 12 if H <= 64 else 0          # kinks of this size only exist where the deepest maps are 2x2 / 4x4
     probes_a = (lambda: (oracle_grads(lambda sd: loss_a(sd, q), [sd_m], torch.float32)[0] for q in perturbed(img, n_probe))) if n_probe else None
-    assert_calibrated(main, g32, g64, "A", cal, probes_a)
+    strict = H >= 256
+    assert_calibrated(main, g32, g64, "A", cal, probes_a, strict=strict)
+    del g32, g64
     shape.zero_grad(); main.zero_grad()
     kd, ins_t, _, _, dom_s = shape.update(main, img.to(DEV), od.to(DEV), two_stage_inputs=img.to(DEV), two_step=True)
     (kd + ins_t + dom_s).backward()
@@ -452,7 +471,7 @@ def test_gradients_calibrated(B, pb, H):
     g32 = oracle_grads(loss_b, [sd_s, sd_m2], torch.float32)[0]
     g64 = oracle_grads(loss_b, [sd_s, sd_m2], torch.float64)[0]
     probes_b = (lambda: (oracle_grads(lambda a, b: loss_b(a, b, q), [sd_s, sd_m2], torch.float32)[0] for q in perturbed(img, n_probe))) if n_probe else None
-    assert_calibrated(shape, g32, g64, "B", cal, probes_b)
+    assert_calibrated(shape, g32, g64, "B", cal, probes_b, strict=strict)
 
 
 # ---------------------------------------------------------------- a-11: full A-D iterations

@@ -44,8 +44,10 @@ def main():
       if k == 3:        # the LDS-fed-weights kernel of rounds 2-3 (conv_x3_k) beside the default (conv_x3r_k)
           ops.lib().query("wtpse_x3r_enable", 0)
           fo, _ = timeit(lambda: ops.conv_fwd_x3(x0, x1, px.data_ptr(), bias, co, k, pro0, 3, want_stats=True, pro1=pro1), 10)
+          ops.lib().query("wtpse_x3r_enable", 2)
+          fr, _ = timeit(lambda: ops.conv_fwd_x3(x0, x1, px.data_ptr(), bias, co, k, pro0, 3, want_stats=True, pro1=pro1), 10)
           ops.lib().query("wtpse_x3r_enable", 1)
-          line += " [r3 kernel %7.1f us %5.1f TF]" % (fo, flops / fo / 1e6)
+          line += " [conv_x3_k %7.1f us %5.1f TF, conv_x3r_k %7.1f us %5.1f TF]" % (fo, flops / fo / 1e6, fr, flops / fr / 1e6)
           tot[6] += fo
       if c0 + c1 > 16:
           d32, _ = timeit(lambda: ops.conv_fwd(dy, None, packed.data_ptr() + 4 * wd_off, None, c0 + c1, k, split=(c0 if c1 else None)), 10)
@@ -55,8 +57,10 @@ def main():
           if k == 3:
               ops.lib().query("wtpse_x3r_enable", 0)
               do, _ = timeit(lambda: ops.conv_fwd_x3(dy, None, px.data_ptr() + 2 * xd_off, None, c0 + c1, k, split=(c0 if c1 else None)), 10)
+              ops.lib().query("wtpse_x3r_enable", 2)
+              dr, _ = timeit(lambda: ops.conv_fwd_x3(dy, None, px.data_ptr() + 2 * xd_off, None, c0 + c1, k, split=(c0 if c1 else None)), 10)
               ops.lib().query("wtpse_x3r_enable", 1)
-              line += " [r3 kernel %7.1f us %5.1f TF]" % (do, flops / do / 1e6)
+              line += " [conv_x3_k %7.1f us %5.1f TF, conv_x3r_k %7.1f us %5.1f TF]" % (do, flops / do / 1e6, dr, flops / dr / 1e6)
               tot[7] += do
       if ops.wgrad_x3_supported(c0 + c1, co, k, c0 if c1 else 8):
           dw = torch.empty_like(w)
@@ -67,7 +71,7 @@ def main():
       print(line, flush=True)
   print("wgrad (supported layers): fp32 %.0f us, x3 %.0f us" % (tot[4], tot[5]))
   print("sum: fwd fp32 %.0f us, x3 %.0f us; dgrad fp32 %.0f us, x3 %.0f us" % tuple(tot[:4]))
-  print("3x3 layers with the round-3 kernel (1x1 layers as above): fwd +%.0f us, dgrad +%.0f us" % (tot[6], tot[7]))
+  print("3x3 layers on conv_x3_k only (the kernel of rounds 2-3): fwd %.0f us, dgrad %.0f us" % (tot[6], tot[7]))
 
 
 if __name__ == "__main__":

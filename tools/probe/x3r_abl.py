@@ -56,7 +56,20 @@ def main():
             return dll.wtpse_conv_fwd_x3(vp(x.data_ptr()), cin, None, 0, vp(packed.data_ptr()), None, None, None, 0, vp(y.data_ptr()), None, cout,
                                          None, B, hw, hw, cout, 3, 0, None, None)
         line = []
-        for abl in (0, 63, -1):
+        for stag in (0, 5, 10, 20, 30, 40):
+            dll.wtpse_probe_x3r_abl(0); dll.wtpse_x3r_enable(1); dll.wtpse_probe_x3r_stagger(stag)
+            for _ in range(20):
+                run()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(100):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            line.append("stagger %dk cycles %.1f" % (stag, e0.elapsed_time(e1) * 10))
+        dll.wtpse_probe_x3r_stagger(0)
+        for abl in (0, -1):
             if abl >= 0:
                 dll.wtpse_probe_x3r_abl(abl)
                 dll.wtpse_x3r_enable(1)

@@ -309,8 +309,12 @@ __device__ __forceinline__ void x3_epilogue(const ConvX3Args& a, f32x16 (&acc)[M
 
 // NT = 32-pixel column tiles per wave: 2 (256-pixel workgroup tile) or 1 (128 pixels: twice the workgroups for the 16x16
 // maps, whose 256-pixel tiles would leave one workgroup per CU with nothing to overlap its loader phases with)
-template <int KS, int MT, int TWL, int EPI, int NT = 2>
+// TERMS = bf16 terms per fp32 operand: 3 (the x3 arithmetic: six products, fp32 accuracy) or 1 (plain bf16 operands, one product,
+// fp32 accumulation: the `bf16` mode of BASELINE.json configs[1] — wtpse_x3_terms(), include/wtpse_hip.h; NOT within the 1e-4
+// parity bar and never used by the fp32 workloads).  Same tiles, loader and epilogues; the images hold TERMS planes.
+template <int KS, int MT, int TWL, int EPI, int NT = 2, int TERMS = 3>
 __global__ __launch_bounds__(256, 2) void conv_x3_k(ConvX3Args a) {
+  static_assert(TERMS == 3 || TERMS == 1, "three bf16 terms (fp32 accuracy) or one (bf16 mode)");
   constexpr int TAPS = KS * KS, PAD = KS / 2;
   constexpr int TW = 1 << TWL, TH = (128 * NT) / TW;
   constexpr int PITCH = TW + 2 * PAD, ROWS = TH + 2 * PAD;
@@ -319,8 +323,8 @@ __global__ __launch_bounds__(256, 2) void conv_x3_k(ConvX3Args a) {
   constexpr int CB = 32 * MT;
   constexpr int NACC = 16;
   constexpr int KC = 16;
-  constexpr int XS_U4 = 6 * PEP;                   // 16-byte slots
-  constexpr int WS_U4 = KS * 6 * CB;               // one kernel row (KS taps)
+  constexpr int XS_U4 = 2 * TERMS * PEP;           // 16-byte slots
+  constexpr int WS_U4 = KS * 2 * TERMS * CB;       // one kernel row (KS taps)
   constexpr int NW = (WS_U4 + 255) / 256;          // 16-byte weight loads per thread and kernel row
   constexpr int RED_F = 4 * CB * 2;
   constexpr int MAIN_U4 = (XS_U4 + 2 * WS_U4) > (RED_F + 3) / 4 ? (XS_U4 + 2 * WS_U4) : (RED_F + 3) / 4;
@@ -424,7 +428,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_k(ConvX3Args a) {
   // groups of the chunk's last kernel row (they used to run behind the chunk's barrier, ~1600 cycles per chunk during which
   // the wave issued no MFMA: 9 % of the forward kernel with a prologue, 6 % without).  Branch-free: the coefficients come from
   // LDS ((1, 0) without a prologue), the ReLU is a select on a uniform flag.
-  u32x4v tq[NIT][3];
+  u32x4v tq[NIT][TERMS];
   const bool any_pro = a.pro0 != nullptr || a.pro1 != nullptr || a.pro_relu != 0;
   auto convert_pair = [&](int c0, int i, int j, bool pro) __attribute__((always_inline)) {
     float v0 = xv[i][2 * j], v1 = xv[i][2 * j + 1];
@@ -439,19 +443,22 @@ __global__ __launch_bounds__(256, 2) void conv_x3_k(ConvX3Args a) {
       v0 = iin[i] ? v0 : 0.f;
       v1 = iin[i] ? v1 : 0.f;
     }
-    unsigned q0, q1, q2;
-    split3_pair(v0, v1, q0, q1, q2);
-    tq[i][0][j] = q0;
-    tq[i][1][j] = q1;
-    tq[i][2][j] = q2;
+    if constexpr (TERMS == 3) {
+      unsigned q0, q1, q2;
+      split3_pair(v0, v1, q0, q1, q2);
+      tq[i][0][j] = q0;
+      tq[i][1][j] = q1;
+      tq[i][2][j] = q2;
+    } else {
+      tq[i][0][j] = pack_rne(v0, v1);
+    }
   };
   auto store_x = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
       if (ipos[i] >= 0) {
-        Xs[(0 * 2 + ihalf[i]) * PEP + ipos[i]] = tq[i][0];
-        Xs[(1 * 2 + ihalf[i]) * PEP + ipos[i]] = tq[i][1];
-        Xs[(2 * 2 + ihalf[i]) * PEP + ipos[i]] = tq[i][2];
+#pragma unroll
+        for (int t = 0; t < TERMS; ++t) Xs[(t * 2 + ihalf[i]) * PEP + ipos[i]] = tq[i][t];
       }
     }
   };
@@ -460,12 +467,13 @@ __global__ __launch_bounds__(256, 2) void conv_x3_k(ConvX3Args a) {
     x3_static_for<NIT * 4>([&](auto pc) __attribute__((always_inline)) { convert_pair(c0, decltype(pc)::value >> 2, decltype(pc)::value & 3, any_pro); });
     store_x();
   };
-  // one kernel row of weights: LDS slot s = ((tl*6 + q) * CB + co), tl = tap within the row, q = term*2 + half
+  // one kernel row of weights: LDS slot s = ((tl * 2 TERMS + q) * CB + co), tl = tap within the row, q = term*2 + half (the packed
+  // weights always carry three terms: TERMS = 1 fetches the leading one only)
   unsigned wslot[NW];
 #pragma unroll
   for (int it = 0; it < NW; ++it) {
     const int s = tid + 256 * it;
-    const int co = s % CB, q6 = (s / CB) % 6, tl = s / (CB * 6);
+    const int co = s % CB, q6 = (s / CB) % (2 * TERMS), tl = s / (CB * 2 * TERMS);
     const bool ok = s < WS_U4 && cout0 + co < a.CoutP;
     wslot[it] = ok ? (unsigned)(((co >> 5) * (TAPS * 6 * 32) + (tl * 6 + q6) * 32 + (co & 31)) * 16) : BUF_OOB;
   }
@@ -496,7 +504,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_k(ConvX3Args a) {
   // piecewise between the MFMA groups of the last row; after the chunk's barrier only the LDS stores remain.  1x1 (one row
   // per chunk): loaded in front of the row, converted behind the barrier.  The loads and the conversion also run on the last
   // chunk (out of range: zeros) — no branch inside the MFMA stream.
-  constexpr bool PIPE = KS == 3 && MT == 2;     // MT 1: the 36 extra registers cost the third wave per SIMD (measured 210 -> 248 us)
+  constexpr bool PIPE = KS == 3 && MT == 2 && TERMS == 3;     // MT 1: the 36 extra registers cost the third wave per SIMD (measured 210 -> 248 us)
   constexpr int NPIECE = NIT * 4;
   for (int chunk = 0; chunk < nchunks; ++chunk) {
 #pragma unroll
@@ -533,7 +541,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_k(ConvX3Args a) {
         auto rd_a = [&](int tl, int t) {
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
-            const bf16x8 v = __builtin_bit_cast(bf16x8, Wb[((tl * 6) + t * 2 + h) * CB + mt * 32 + r32]);
+            const bf16x8 v = __builtin_bit_cast(bf16x8, Wb[((tl * 2 * TERMS) + t * 2 + h) * CB + mt * 32 + r32]);
             if (t == 2) a2[mt] = v; else a01[tl & 1][mt][t] = v;
           }
         };
@@ -547,6 +555,14 @@ __global__ __launch_bounds__(256, 2) void conv_x3_k(ConvX3Args a) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma_bf16(ta == 2 ? a2[mt] : a01[tl & 1][mt][ta], bfr[nt][tb], acc[mt][nt]);
         };
+        if constexpr (TERMS == 1) {      // bf16 mode: one product per tap
+          rd_a(0, 0); rd_b(0, 0);
+#pragma unroll
+          for (int tl = 0; tl < KS; ++tl) {
+            mm(tl, 0, 0);
+            if (tl + 1 < KS) { rd_a(tl + 1, 0); rd_b(tl + 1, 0); }
+          }
+        } else {
         rd_a(0, 0); rd_b(0, 2); rd_a(0, 1); rd_b(0, 1); rd_a(0, 2); rd_b(0, 0);
 #pragma unroll
         for (int tl = 0; tl < KS; ++tl) {
@@ -574,6 +590,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_k(ConvX3Args a) {
           mm(tl, 0, 0);
           if (nx) rd_b(tl + 1, 0);
           convert_piece();
+        }
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -616,6 +633,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_k(ConvX3Args a) {
 #ifdef WTPSE_PROBE
 // per workgroup {s_memtime, s_memrealtime} at the start and the end of the main loop (thread 0): the clock the loop ran at
 __device__ unsigned long long* g_x3r_clk = nullptr;
+__device__ int g_x3r_stagger = 0;
 #define RCLK(i) do { if (g_x3r_clk && threadIdx.x == 0) { unsigned long long* q = g_x3r_clk + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 2 * (i); \
     q[0] = __builtin_amdgcn_s_memtime(); q[1] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
@@ -647,6 +665,12 @@ __global__ __launch_bounds__(256, 2) void conv_x3r_k(ConvX3Args a) {
   float* bias_s = reinterpret_cast<float*>(smem + MAIN_U4);
 
   RCLK(2);
+#ifdef WTPSE_PROBE
+  if (g_x3r_stagger > 0 && blockIdx.x < 512u) {        // first round only: the workgroup whose LDS allocation does not start at 0 waits
+    const unsigned lds_base = __builtin_amdgcn_s_getreg(((8 - 1) << 11) | 6);
+    if (lds_base != 0) for (int i = 0; i < g_x3r_stagger; ++i) __builtin_amdgcn_s_sleep(16);     // ~1k cycles per iteration
+  }
+#endif
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cw = __builtin_amdgcn_readfirstlane(wave % WM), pw = __builtin_amdgcn_readfirstlane(wave / WM);
   const int r32 = lane & 31, h = lane >> 5;
@@ -766,7 +790,10 @@ __global__ __launch_bounds__(256, 2) void conv_x3r_k(ConvX3Args a) {
   };
 
   // A fragments: ring of three tap slots
-  constexpr int RING = (ABL & 256) ? 3 : TAPS;     // tap slots of weight fragments: a whole chunk ahead (ABL 256: two taps ahead)
+  // tap slots of weight fragments: 3 = two taps ahead.  (ABL 256: 9 slots = a whole chunk ahead — measured: the waits on these loads
+  // shrink from 15 % to 5 % of the launch and the launch takes the same time, profiles/r04_x3r_ablation.txt: the chip is at its power
+  // limit on this arithmetic, cycles saved come back as a lower clock; 72 registers for nothing)
+  constexpr int RING = (ABL & 256) ? TAPS : 3;
   bf16x8 afr[RING][MT][3];
   bf16x8 adummy[3][MT][3];           // ABL 64 only
   auto issue_a1 = [&](int chunk, int tap, int slot, int t) __attribute__((always_inline)) {
@@ -825,8 +852,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3r_k(ConvX3Args a) {
       constexpr int tap = g / NT, nt = g % NT;
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (RING == TAPS) {
-        // the fragments of tap - 1 have been consumed: their slot takes the NEXT chunk's tap - 1 (nine taps = 216 MFMAs per wave
-        // ahead of its use: measured, a two-tap distance left the waves waiting on these loads for a fifth of the launch)
+        // the fragments of tap - 1 have been consumed: their slot takes the NEXT chunk's tap - 1 (nine taps = 216 MFMAs per wave ahead)
         if constexpr (nt == 0 && tap >= 1 && !(ABL & 4)) issue_a(chn, tap - 1, tap - 1);
       } else if constexpr ((ABL & 128) != 0 && NT >= 3) {       // spread: one term per group
         if constexpr (nt < 3) {
@@ -921,10 +947,10 @@ static bool x3_small_tiles(int B, int H, int W, int CoutP, bool mt2) {
 
 // 3x3 launches take conv_x3r_k (register-fed weights) unless WTPSE_X3R=0 / wtpse_x3r_enable(0): the two kernels give bitwise the
 // same results on the same tiles, so the switch is a pure A/B of the operand supply.
-static int g_x3r = [] { const char* e = getenv("WTPSE_X3R"); return (e && e[0] == '0') ? 0 : 1; }();
+static int g_x3r = [] { const char* e = getenv("WTPSE_X3R"); return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1; }();
 extern "C" int wtpse_x3r_enable(int on) {
   const int was = g_x3r;
-  if (on >= 0) g_x3r = on ? 1 : 0;
+  if (on >= 0) g_x3r = on > 2 ? 2 : on;
   return was;
 }
 
@@ -932,9 +958,19 @@ extern "C" int wtpse_x3r_enable(int on) {
 static int g_x3r_abl = 0;
 extern "C" int wtpse_probe_x3r_abl(int abl) { g_x3r_abl = abl; return 0; }
 extern "C" int wtpse_probe_x3r_clock(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_x3r_clk), &p, sizeof(p)); }
+extern "C" int wtpse_probe_x3r_stagger(int n) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_x3r_stagger), &n, sizeof(n)); }
 #endif
 
-template <int KS, int MT, int EPI>
+// bf16 terms per fp32 operand in every x3 kernel of the library (this file and wgrad_r.hip): 3 = fp32 accuracy (default), 1 = the
+// bf16 mode (environment WTPSE_X3_TERMS=1 or wtpse_x3_terms(1); include/wtpse_hip.h)
+int g_x3_terms = [] { const char* e = getenv("WTPSE_X3_TERMS"); return (e && e[0] == '1') ? 1 : 3; }();
+extern "C" int wtpse_x3_terms(int terms) {
+  const int was = g_x3_terms;
+  if (terms == 1 || terms == 3) g_x3_terms = terms;
+  return was;
+}
+
+template <int KS, int MT, int EPI, int TERMS = 3>
 static int launch_x3(const ConvX3Args& a, hipStream_t st) {
   ConvX3Args args = a;
   const bool narrow = a.W <= 16;
@@ -947,8 +983,10 @@ static int launch_x3(const ConvX3Args& a, hipStream_t st) {
   if (!in_launch) args.tail.tickets = args.ftail.tickets = nullptr;
   if (args.tail.tickets) bnb_tail_geometry(args.tail, (int)grid.x, a.Cout, (double)a.B * a.H * a.W);
   if (args.ftail.tickets) bnf_tail_geometry(args.ftail, (int)grid.x, a.Cout, (double)a.B * a.H * a.W);
-  if (KS == 3 && g_x3r) {
-    if constexpr (KS == 3) {
+  // g_x3r: 1 = conv_x3r_k where it measured at least as fast (64-channel blocks: +1..10 % on the forward launches, +-1 % on the data
+  // gradients), 2 = everywhere (32-channel blocks run 8-20 % SLOWER on it: half the MFMAs per converted input element), 0 = nowhere
+  if (KS == 3 && TERMS == 3 && (g_x3r == 2 || (g_x3r == 1 && MT == 2))) {
+    if constexpr (KS == 3 && TERMS == 3) {
       if (small) {
         if constexpr (MT == 1) hipLaunchKernelGGL((conv_x3r_k<1, 1, 1, 4, EPI>), grid, dim3(256), 0, st, args);
       } else if (MT == 2) {
@@ -957,7 +995,7 @@ static int launch_x3(const ConvX3Args& a, hipStream_t st) {
           switch (g_x3r_abl) {
 #define ABLCASE(n) case n: hipLaunchKernelGGL((conv_x3r_k<2, 1, 4, 5, 0, n>), grid, dim3(256), 0, st, args); break;
             ABLCASE(1) ABLCASE(2) ABLCASE(3) ABLCASE(4) ABLCASE(8) ABLCASE(16) ABLCASE(32) ABLCASE(35) ABLCASE(39) ABLCASE(47) ABLCASE(63)
-            ABLCASE(64) ABLCASE(128) ABLCASE(99) ABLCASE(163) ABLCASE(256) ABLCASE(260) ABLCASE(291)
+            ABLCASE(64) ABLCASE(128) ABLCASE(99) ABLCASE(163) ABLCASE(256) ABLCASE(260) ABLCASE(291) ABLCASE(319)
 #undef ABLCASE
             default: return WTPSE_EINVAL;
           }
@@ -972,11 +1010,11 @@ static int launch_x3(const ConvX3Args& a, hipStream_t st) {
       }
     }
   } else if (small) {
-    if constexpr (MT == 1) hipLaunchKernelGGL((conv_x3_k<KS, 1, 4, EPI, 1>), grid, dim3(256), 0, st, args);
+    if constexpr (MT == 1) hipLaunchKernelGGL((conv_x3_k<KS, 1, 4, EPI, 1, TERMS>), grid, dim3(256), 0, st, args);
   } else if (narrow)
-    hipLaunchKernelGGL((conv_x3_k<KS, MT, 4, EPI>), grid, dim3(256), 0, st, args);
+    hipLaunchKernelGGL((conv_x3_k<KS, MT, 4, EPI, 2, TERMS>), grid, dim3(256), 0, st, args);
   else
-    hipLaunchKernelGGL((conv_x3_k<KS, MT, 5, EPI>), grid, dim3(256), 0, st, args);
+    hipLaunchKernelGGL((conv_x3_k<KS, MT, 5, EPI, 2, TERMS>), grid, dim3(256), 0, st, args);
   int rc = wtpse_status();
   if (rc == 0 && !in_launch)
     rc = tail_after_launch(a.tail, a.ftail, a.stats, (int)grid.x, a.Cout, a.bn_c0, a.bn_c1, a.bn_mean, (long long)a.B * a.H * a.W, st);
@@ -1036,10 +1074,12 @@ static int conv_x3_impl(const float* in0, int C0, const float* in1, int C1, cons
   hipStream_t st = (hipStream_t)stream;
   const bool mt2 = x3_mt2(B, H, W, a.CoutP);
   WTPSE_REQUIRE(a.CinP <= (mt2 ? 512 : 256));            // prologue coefficients staged in LDS (conv_x3_k: PRO_MAX)
-#define X3(KS, M) (bnb ? launch_x3<KS, M, 2>(a, st) : mask_ref ? launch_x3<KS, M, 1>(a, st) : launch_x3<KS, M, 0>(a, st))
+#define X3T(KS, M, T) (bnb ? launch_x3<KS, M, 2, T>(a, st) : mask_ref ? launch_x3<KS, M, 1, T>(a, st) : launch_x3<KS, M, 0, T>(a, st))
+#define X3(KS, M) (g_x3_terms == 1 ? X3T(KS, M, 1) : X3T(KS, M, 3))
   if (ksize == 3) return mt2 ? X3(3, 2) : X3(3, 1);
   return mt2 ? X3(1, 2) : X3(1, 1);
 #undef X3
+#undef X3T
 }
 
 // Same contract as wtpse_conv_fwd (include/wtpse_hip.h) with `wpacked` in the x3 layout.  Cout <= 16 runs on a 32-row

@@ -763,6 +763,25 @@ extern "C" int wtpse_relu_mask(const float* dz, const float* ref, float* dy, int
     hipLaunchKernelGGL(relu_mask_k, GRID1(n), dim3(256), 0, ST, dz, ref, dy, accumulate, n);
   return wtpse_status();
 }
+// Counter calibration (tools/pmc_traffic.py): plain streaming copies with a KNOWN byte count in the two access widths the
+// kernels use — 16 bytes per lane (the WT-loss, weight-gradient and point-wise kernels) and 4 bytes per lane (the convolutions'
+// tile loaders and epilogues) — so that the FETCH_SIZE / WRITE_SIZE factors are derived per width instead of chosen per kernel
+// (MI355X_MICROARCH.md, HBM: "calibrate on a known byte count in your own access pattern").
+__global__ __launch_bounds__(256) void copy_w16_k(const float4* __restrict__ src, float4* __restrict__ dst, long long n4) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) dst[i] = src[i];
+}
+__global__ __launch_bounds__(256) void copy_w4_k(const float* __restrict__ src, float* __restrict__ dst, long long n) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dst[i] = src[i];
+}
+extern "C" int wtpse_copy_probe(const float* src, float* dst, long long n, int bytes_per_lane, void* stream) {
+  WTPSE_REQUIRE(src && dst && n > 0 && n % 4 == 0 && (bytes_per_lane == 4 || bytes_per_lane == 16));
+  WTPSE_REQUIRE((((uintptr_t)src | (uintptr_t)dst) & 15) == 0);
+  if (bytes_per_lane == 16)
+    hipLaunchKernelGGL(copy_w16_k, dim3(8192), dim3(256), 0, ST, reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst), n / 4);
+  else
+    hipLaunchKernelGGL(copy_w4_k, dim3(16384), dim3(256), 0, ST, src, dst, n);
+  return wtpse_status();
+}
 extern "C" int wtpse_axpy(float* dst, const float* src, float alpha, long long n, void* stream) {
   WTPSE_REQUIRE(dst && src && n > 0);
   if (n % 4 == 0 && (((uintptr_t)dst | (uintptr_t)src) & 15) == 0)

@@ -74,7 +74,7 @@ __device__ __forceinline__ f32x4 mfma16x32(u32x4v a, u32x4v b, f32x4 c) {
 }
 
 // 8 fp32 values -> three fragments (4 dwords each) of bf16 terms
-__device__ __forceinline__ void wr_split8(const f32x4& lo, const f32x4& hi, u32x4v (&t)[3]) {
+[[maybe_unused]] __device__ __forceinline__ void wr_split8(const f32x4& lo, const f32x4& hi, u32x4v (&t)[3]) {
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     unsigned q0, q1, q2;
@@ -90,9 +90,16 @@ __device__ __forceinline__ void wr_split8(const f32x4& lo, const f32x4& hi, u32x
 // their SIMD to themselves: four waves
 template <int MF, int NF> struct WgradRGeom { static constexpr int NW = (MF * NF >= 2) ? 4 : 8; };
 
-template <int MF, int NF, bool PRO, bool BIAS, bool AFF = false>
+// TERMS: bf16 terms per fp32 operand — 3 (x3 arithmetic, six products per multiply) or 1 (bf16 mode: wtpse_x3_terms, conv_x3.hip)
+template <int MF, int NF, bool PRO, bool BIAS, bool AFF = false, int TERMS = 3>
 __global__ __launch_bounds__((64 * WgradRGeom<MF, NF>::NW), 1) void wgrad_r_k(WgradRArgs a) {
+  static_assert(TERMS == 3 || TERMS == 1, "three bf16 terms or one");
   constexpr int NT = 9, NW = WgradRGeom<MF, NF>::NW;
+  // (a, b) -> TERMS dwords of packed bf16 pairs
+  auto split_pair = [](float v0, float v1, unsigned (&q)[TERMS]) __attribute__((always_inline)) {
+    if constexpr (TERMS == 3) wr_split3_pair(v0, v1, q[0], q[1], q[2]);
+    else q[0] = wr_pack_rne(v0, v1);
+  };
   // (the wave id is wave-uniform, but only readfirstlane tells the compiler: everything derived from it — the unit, the image,
   // the buffer descriptors — then stays in SGPRs instead of being re-derived per lane behind waterfall loops)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -114,9 +121,12 @@ __global__ __launch_bounds__((64 * WgradRGeom<MF, NF>::NW), 1) void wgrad_r_k(Wg
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[m][n][t][r] = 0.f;
-  float bsum[MF];
+  // bias gradient: per-lane sums in fp64 (a lane adds up hundreds of dY values whose total nearly cancels — the gradient of a bias
+  // behind the WT loss — and an fp32 running sum put this tensor 3.3x as far from the fp64 oracle as the reference's own fp32 run at
+  // the benchmark's geometry, tests/test_parity_gpu.py [32-10-256]; two v_add_f64 per pixel pair in the HBM-bound 16 x 16 blocks)
+  double bsum[MF];
 #pragma unroll
-  for (int m = 0; m < MF; ++m) bsum[m] = 0.f;
+  for (int m = 0; m < MF; ++m) bsum[m] = 0.0;
 
   // per cin fragment: which input tensor it reads (a 16-channel fragment never straddles the two halves of a concat),
   // its channel within that tensor, the prologue coefficients of this lane's channel
@@ -186,9 +196,9 @@ __global__ __launch_bounds__((64 * WgradRGeom<MF, NF>::NW), 1) void wgrad_r_k(Wg
     f32x4 rawx[2][NF][2], rawy[AD][MF][2], rawb[AD][AFF ? MF : 1][2];
     float ak3v[AD][MF];           // AFF: k3 of the stage's dY row, 0 for a row outside [y0, y1)
     float rawe[2][NF];
-    u32x4v ay[4][MF][3];          // split dY rows: row y in slot (y - rfirst) & 3      [slot][cout fragment][term]
-    u32x4v xb[2][NF][3];          // split X row s in slot (s - rfirst) & 1
-    unsigned eq[2][NF][3];        // its edge pixel (lane groups 0 and 3)
+    u32x4v ay[4][MF][TERMS];      // split dY rows: row y in slot (y - rfirst) & 3      [slot][cout fragment][term]
+    u32x4v xb[2][NF][TERMS];      // split X row s in slot (s - rfirst) & 1
+    unsigned eq[2][NF][TERMS];    // its edge pixel (lane groups 0 and 3)
     // (branch-free: a row outside its range turns into an out-of-range buffer offset by OR-ing the top bit in — every valid
     // offset is below 2^31 — and the row's byte offset rides in the scalar offset operand)
     auto issue_x = [&](auto Sc, int s) {                   // X row s -> raw slot S
@@ -241,10 +251,11 @@ __global__ __launch_bounds__((64 * WgradRGeom<MF, NF>::NW), 1) void wgrad_r_k(Wg
           v0 = fmaf(ak1[m], v0, fmaf(ak2[m], rawb[SA][m][q >> 1][2 * (q & 1)], ak3v[SA][m]));
           v1 = fmaf(ak1[m], v1, fmaf(ak2[m], rawb[SA][m][q >> 1][2 * (q & 1) + 1], ak3v[SA][m]));
         }
-        if (BIAS) bsum[m] += v0 + v1;
-        unsigned q0, q1, q2;
-        wr_split3_pair(v0, v1, q0, q1, q2);
-        ay[AS][m][0][q] = q0; ay[AS][m][1][q] = q1; ay[AS][m][2][q] = q2;
+        if (BIAS) bsum[m] += (double)v0 + (double)v1;
+        unsigned qq[TERMS];
+        split_pair(v0, v1, qq);
+#pragma unroll
+        for (int t = 0; t < TERMS; ++t) ay[AS][m][t][q] = qq[t];
       } else if constexpr (P < PX) {
         if (s_next >= 0) issue_a(Sc, s_next);
       } else if constexpr (P < PE_) {
@@ -254,14 +265,18 @@ __global__ __launch_bounds__((64 * WgradRGeom<MF, NF>::NW), 1) void wgrad_r_k(Wg
           v0 = fmaxf(fmaf(v0, psc[n], psh[n]), plo[n]);
           v1 = fmaxf(fmaf(v1, psc[n], psh[n]), plo[n]);
         }
-        unsigned q0, q1, q2;
-        wr_split3_pair(v0, v1, q0, q1, q2);
-        xb[S][n][0][q] = q0; xb[S][n][1][q] = q1; xb[S][n][2][q] = q2;
+        unsigned qq[TERMS];
+        split_pair(v0, v1, qq);
+#pragma unroll
+        for (int t = 0; t < TERMS; ++t) xb[S][n][t][q] = qq[t];
       } else if constexpr (P < NP - 1) {
         constexpr int n = P - PE_;
         float e = rawe[S][n];
         if (PRO) e = evalid ? fmaxf(fmaf(e, psc[n], psh[n]), plo[n]) : 0.f;     // zero padding applies after the activation
-        wr_split3_pair(e, 0.f, eq[S][n][0], eq[S][n][1], eq[S][n][2]);
+        unsigned qq[TERMS];
+        split_pair(e, 0.f, qq);
+#pragma unroll
+        for (int t = 0; t < TERMS; ++t) eq[S][n][t] = qq[t];
       } else {
         if (s_next >= 0) {
           issue_x(Sc, s_next + 1);
@@ -280,9 +295,9 @@ __global__ __launch_bounds__((64 * WgradRGeom<MF, NF>::NW), 1) void wgrad_r_k(Wg
       constexpr int J = decltype(Jc)::value, XS = J & 1, CS = (J + 1) & 1, AS = (J + 2) & 3;
       static_for<NF>([&](auto nc) {
         constexpr int n = decltype(nc)::value;
-        u32x4v xs[3][3];          // [kx][term]: the row shifted by kx - 1 pixels
+        u32x4v xs[3][TERMS];      // [kx][term]: the row shifted by kx - 1 pixels
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
+        for (int t = 0; t < TERMS; ++t) {
           const u32x4v d = xb[XS][n][t];
           // pixel 8 of this lane's group = pixel 0 of the next group (lane + 16); for the last group the strip's right edge,
           // which lane group 0 holds.  Pixel -1 = pixel 7 of the previous group (lane - 16); for group 0 the left edge (group 3).
@@ -306,12 +321,13 @@ __global__ __launch_bounds__((64 * WgradRGeom<MF, NF>::NW), 1) void wgrad_r_k(Wg
           constexpr int ky = c / (3 * MF), m = (c / 3) % MF, kx = c % 3;
           constexpr int slot = (J + 1 - ky + 4) & 3;         // dY row r + 1 - ky
           f32x4 v = acc[m][n][ky * 3 + kx];
-          // the six leading cross terms, smallest first (as conv_x3.hip)
-          v = mfma16x32(ay[slot][m][0], xs[kx][2], v);
-          v = mfma16x32(ay[slot][m][1], xs[kx][1], v);
-          v = mfma16x32(ay[slot][m][2], xs[kx][0], v);
-          v = mfma16x32(ay[slot][m][0], xs[kx][1], v);
-          v = mfma16x32(ay[slot][m][1], xs[kx][0], v);
+          if constexpr (TERMS == 3) {      // the six leading cross terms, smallest first (as conv_x3.hip)
+            v = mfma16x32(ay[slot][m][0], xs[kx][2], v);
+            v = mfma16x32(ay[slot][m][1], xs[kx][1], v);
+            v = mfma16x32(ay[slot][m][2], xs[kx][0], v);
+            v = mfma16x32(ay[slot][m][0], xs[kx][1], v);
+            v = mfma16x32(ay[slot][m][1], xs[kx][0], v);
+          }
           v = mfma16x32(ay[slot][m][0], xs[kx][0], v);
           acc[m][n][ky * 3 + kx] = v;
           constexpr int cg = n * 9 * MF + c;                 // chain index within the step
@@ -319,7 +335,7 @@ __global__ __launch_bounds__((64 * WgradRGeom<MF, NF>::NW), 1) void wgrad_r_k(Wg
           static_for<phi_ - plo_>([&](auto pp) { piece(IC<plo_ + decltype(pp)::value>{}, IC<CS>{}, IC<AS>{}, r + 2); });
 #ifndef WGRAD_R_NO_INTERLEAVE
 #pragma unroll
-          for (int i = 0; i < 6; ++i) {
+          for (int i = 0; i < (TERMS == 3 ? 6 : 1); ++i) {
             __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);      // 1 MFMA
             __builtin_amdgcn_sched_group_barrier(0x2, 2, 0);      // 2 VALU
           }
@@ -334,7 +350,7 @@ __global__ __launch_bounds__((64 * WgradRGeom<MF, NF>::NW), 1) void wgrad_r_k(Wg
 #pragma unroll
       for (int m = 0; m < MF; ++m)
 #pragma unroll
-        for (int t = 0; t < 3; ++t) ay[s][m][t] = (u32x4v){0u, 0u, 0u, 0u};
+        for (int t = 0; t < TERMS; ++t) ay[s][m][t] = (u32x4v){0u, 0u, 0u, 0u};
     // stages rfirst - 1 (its dY row only: X row rfirst - 1 lies outside the unit or the image) and rfirst are converted up
     // front; stages rfirst + 1 and rfirst + 2 are in flight when the row loop starts (AD = 1: only rfirst + 1 on the A side)
     if (AD == 2) {
@@ -400,10 +416,10 @@ __global__ __launch_bounds__((64 * WgradRGeom<MF, NF>::NW), 1) void wgrad_r_k(Wg
   if (BIAS) {
     if (cin0 == 0) {
       __syncthreads();
-      float* redb = reinterpret_cast<float*>(&red[0][0][0]);
+      double* redb = reinterpret_cast<double*>(&red[0][0][0]);
 #pragma unroll
       for (int m = 0; m < MF; ++m) {
-        float v = bsum[m];
+        double v = bsum[m];
         v += __shfl_xor(v, 16, 64);                       // the four pixel groups of a channel
         v += __shfl_xor(v, 32, 64);
         if (g == 0) redb[(wave * MF + m) * 16 + c16] = v;
@@ -411,11 +427,11 @@ __global__ __launch_bounds__((64 * WgradRGeom<MF, NF>::NW), 1) void wgrad_r_k(Wg
       __syncthreads();
       if (tid < 16 * MF) {
         const int m = tid >> 4, c = tid & 15;
-        float s = (redb[(0 * MF + m) * 16 + c] + redb[(1 * MF + m) * 16 + c]) +
-                  (redb[(2 * MF + m) * 16 + c] + redb[(3 * MF + m) * 16 + c]);
+        double s = (redb[(0 * MF + m) * 16 + c] + redb[(1 * MF + m) * 16 + c]) +
+                   (redb[(2 * MF + m) * 16 + c] + redb[(3 * MF + m) * 16 + c]);
         if (NW == 8) s += (redb[(4 * MF + m) * 16 + c] + redb[(5 * MF + m) * 16 + c]) +
                           (redb[(6 * MF + m) * 16 + c] + redb[(7 * MF + m) * 16 + c]);
-        a.slab_b[(size_t)wg * a.Cout + cout0 + 16 * m + c] = s;
+        a.slab_b[(size_t)wg * a.Cout + cout0 + 16 * m + c] = (float)s;       // the slabs are folded in fp64 (wgrad_reduce_k)
       }
     }
   }
@@ -464,6 +480,7 @@ extern "C" int wtpse_wgrad_r_slabs(int B, int H, int W, int Cin, int Cout) {
   return p.wpp / p.nw;
 }
 
+extern int g_x3_terms;      // conv_x3.hip: wtpse_x3_terms()
 extern "C" void wtpse_wgrad_reduce_launch2(const float* slab, int ksplit, int n, float* dw, int accumulate, const float* slab_b,
                                            int n_b, float* db, void* stream);
 
@@ -498,6 +515,16 @@ static int wgrad_r_impl(const float* dy, const float* x0, int C0, const float* x
                else hipLaunchKernelGGL((wgrad_r_k<M, N, false, false, true>), grid, blk, 0, st, a); } \
     else if (pro) hipLaunchKernelGGL((wgrad_r_k<M, N, true, false>), grid, blk, 0, st, a); \
     else hipLaunchKernelGGL((wgrad_r_k<M, N, false, false>), grid, blk, 0, st, a); } while (0)
+  // bf16 mode (wtpse_x3_terms(1), conv_x3.hip): one term per operand in the blocks of the MFMA-bound layers; the 16 x 16 blocks (the
+  // 16-channel layers, which keep three terms in their forward pass too) and the fused-BatchNorm form stay on three
+#define WR_LAUNCH1(M, N) do { \
+    if (pro) hipLaunchKernelGGL((wgrad_r_k<M, N, true, false, false, 1>), grid, blk, 0, st, a); \
+    else hipLaunchKernelGGL((wgrad_r_k<M, N, false, false, false, 1>), grid, blk, 0, st, a); } while (0)
+  if (g_x3_terms == 1 && !aff && p.mf * p.nf >= 2) {
+    if (p.mf == 2 && p.nf == 2) WR_LAUNCH1(2, 2);
+    else if (p.mf == 2) WR_LAUNCH1(2, 1);
+    else WR_LAUNCH1(1, 2);
+  } else
   if (p.mf == 2 && p.nf == 2) WR_LAUNCH(2, 2);
   else if (p.mf == 2) WR_LAUNCH(2, 1);
   else if (p.nf == 2) WR_LAUNCH(1, 2);
@@ -506,6 +533,7 @@ static int wgrad_r_impl(const float* dy, const float* x0, int C0, const float* x
     else hipLaunchKernelGGL((wgrad_r_k<1, 1, false, true>), grid, blk, 0, st, a);
   } else WR_LAUNCH(1, 1);
 #undef WR_LAUNCH
+#undef WR_LAUNCH1
   int rc = wtpse_status();
   if (rc) return rc;
   wtpse_wgrad_reduce_launch2(slab, nslab, Cout * Cin * 9, dw, accumulate, dbias_slab, Cout, dbias, stream);
