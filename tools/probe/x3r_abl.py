@@ -5,7 +5,9 @@
 
     python tools/probe/x3r_abl.py            # build here (CPU container: the .so travels with the snapshot)
     gpurun -- python tools/probe/x3r_abl.py  # measure
-ABL bits: 1 conversion VALU, 2 LDS stores, 4 weight-fragment loads, 8 input-fragment reads, 16 chunk barrier, 32 input tile loads."""
+ABL bits: 1 conversion VALU, 2 LDS stores, 4 weight-fragment loads, 8 input-fragment reads, 16 chunk barrier, 32 input tile loads,
+64 weight loads issued but not consumed, 128 weight loads spread one per MFMA group, 256 weight fragments a whole chunk ahead (ring of 9
+tap slots instead of 3), 512 every 32x32x16 MFMA issued as two 16x16x32 on the same registers (garbage results: clock / cycles only)."""
 import ctypes
 import os
 import subprocess
@@ -41,8 +43,9 @@ def main():
     B = 32
     names = {0: "complete", 1: "-convert", 2: "-lds stores", 3: "-convert -stores", 4: "-A loads", 8: "-B reads", 16: "-barrier", 32: "-X loads",
              35: "-all X work", 39: "-X work -A loads", 47: "-X work -A -B", 63: "MFMA only", 64: "A loads issued, not consumed",
-             128: "A loads spread 1/group", 99: "-X work, A not consumed", 163: "-X work, A spread", 256: "ring 3 (two taps ahead)",
-             260: "ring 3 -A loads", 291: "ring 3 -X work"}
+             128: "A loads spread 1/group", 99: "-X work, A not consumed", 163: "-X work, A spread", 256: "weight fragments a whole chunk ahead (ring of 9 tap slots)", 319: "ring of 9, MFMA only",
+             260: "ring 3 -A loads", 291: "ring 3 -X work", 512: "complete, MFMAs issued as 2 x 16x16x32 (garbage results)",
+             575: "MFMA only, 2 x 16x16x32"}
     for cin, cout, hw in ((32, 64, 128), (64, 64, 128), (128, 64, 128), (256, 64, 128)):
         x = torch.randn(B, cin, hw, hw, device=dev)
         w = torch.randn(cout, cin, 3, 3, device=dev) * 0.05
@@ -56,7 +59,7 @@ def main():
             return dll.wtpse_conv_fwd_x3(vp(x.data_ptr()), cin, None, 0, vp(packed.data_ptr()), None, None, None, 0, vp(y.data_ptr()), None, cout,
                                          None, B, hw, hw, cout, 3, 0, None, None)
         line = []
-        for stag in (0, 5, 10, 20, 30, 40):
+        for stag in ():
             dll.wtpse_probe_x3r_abl(0); dll.wtpse_x3r_enable(1); dll.wtpse_probe_x3r_stagger(stag)
             for _ in range(20):
                 run()
@@ -69,7 +72,7 @@ def main():
             torch.cuda.synchronize()
             line.append("stagger %dk cycles %.1f" % (stag, e0.elapsed_time(e1) * 10))
         dll.wtpse_probe_x3r_stagger(0)
-        for abl in (0, -1):
+        for abl in (0, 63, 512, 575, 256, 319, -1):
             if abl >= 0:
                 dll.wtpse_probe_x3r_abl(abl)
                 dll.wtpse_x3r_enable(1)

@@ -820,7 +820,19 @@ __global__ __launch_bounds__(256, 2) void conv_x3r_k(ConvX3Args a) {
 #pragma unroll
     for (int q = 0; q < 6; ++q)
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mfma_bf16(afr[slot][mt][TA[q]], bfr[set][TB[q]], acc[mt][nt]);
+      for (int mt = 0; mt < MT; ++mt) {
+        if constexpr (ABL & 512) {
+          // probe only (results are garbage): the same multiply-adds issued as TWO v_mfma_f32_16x16x32_bf16 on the same fragment
+          // registers — what the other MFMA shape would make of this operand supply (clock, cycles)
+          typedef float f32x4p __attribute__((ext_vector_type(4)));
+          f32x16& c = acc[mt][nt];
+          f32x4p c0 = {c[0], c[1], c[2], c[3]}, c1 = {c[4], c[5], c[6], c[7]};
+          c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[slot][mt][TA[q]], bfr[set][TB[q]], c0, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[slot][mt][TA[q]], bfr[set][TB[q]], c1, 0, 0, 0);
+          c[0] = c0[0]; c[1] = c0[1]; c[2] = c0[2]; c[3] = c0[3]; c[4] = c1[0]; c[5] = c1[1]; c[6] = c1[2]; c[7] = c1[3];
+        } else
+        acc[mt][nt] = mfma_bf16(afr[slot][mt][TA[q]], bfr[set][TB[q]], acc[mt][nt]);
+      }
   };
 
   constexpr int NPIECE = NIT * 4;
@@ -995,7 +1007,7 @@ static int launch_x3(const ConvX3Args& a, hipStream_t st) {
           switch (g_x3r_abl) {
 #define ABLCASE(n) case n: hipLaunchKernelGGL((conv_x3r_k<2, 1, 4, 5, 0, n>), grid, dim3(256), 0, st, args); break;
             ABLCASE(1) ABLCASE(2) ABLCASE(3) ABLCASE(4) ABLCASE(8) ABLCASE(16) ABLCASE(32) ABLCASE(35) ABLCASE(39) ABLCASE(47) ABLCASE(63)
-            ABLCASE(64) ABLCASE(128) ABLCASE(99) ABLCASE(163) ABLCASE(256) ABLCASE(260) ABLCASE(291) ABLCASE(319)
+            ABLCASE(64) ABLCASE(128) ABLCASE(99) ABLCASE(163) ABLCASE(256) ABLCASE(260) ABLCASE(291) ABLCASE(319) ABLCASE(512) ABLCASE(575)
 #undef ABLCASE
             default: return WTPSE_EINVAL;
           }
