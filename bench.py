@@ -174,6 +174,22 @@ def unet_layer_rooflines(B, H, dev):
         fl, ms = sum(r["flop"] for r in sel), sum(r[d + "_ms"] for r in sel)
         out[d] = {"tflops": fl / ms / 1e9, "frac": fl / ms / 1e9 / MFMA_X3_PEAK_TF, "layers": len(sel), "ms_sum": ms,
                   "min_tflops": min(r[d + "_tflops"] for r in sel), "min_tflops_3x3": min(r[d + "_tflops"] for r in sel if " k3 " in r["layer"])}
+    # mean algorithmic bytes (input + output, fp32) per launch over the 3x3 x3 forward / data-gradient launches of this table PLUS the
+    # eight conv3-of-up1..up4 launches of kernel_rooflines(): the launch set `traffic` of the x3 convolution family is averaged over in
+    # `--kernels-only` runs (tools/pmc_traffic.py matches conv_x3_k<3,...> / conv_x3r_k; every timed entry makes the same number of launches)
+    ent = []
+    for r in rows:
+        if " k3 " not in r["layer"]:
+            continue
+        c0, c1, co, div, k, name = next(t for t in UNET_LAYERS if r["layer"].startswith(t[5]))
+        nb = 4.0 * B * (c0 + c1 + co) * (H // div) ** 2
+        if r["fwd_path"] == "x3":
+            ent.append(nb)
+        if r["dgrad_path"] == "x3" and "dgrad_ms" in r:
+            ent.append(nb)
+        if name in ("up1.conv3", "up2.conv3", "up3.conv3", "up4.conv3"):
+            ent += [nb, nb]
+    out["x3_3x3_mean_bytes"] = sum(ent) / max(len(ent), 1)
     f, g = out["fwd"], out["dgrad"]
     fl = sum(r["flop"] for r in rows if r["fwd_path"] == "x3") + sum(r["flop"] for r in rows if r["dgrad_path"] == "x3" and "dgrad_ms" in r)
     out["fwd_dgrad"] = {"tflops": fl / (f["ms_sum"] + g["ms_sum"]) / 1e9, "frac": fl / (f["ms_sum"] + g["ms_sum"]) / 1e9 / MFMA_X3_PEAK_TF}
@@ -391,8 +407,30 @@ def cpu_baseline(H, full, full_protocol=False):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
+    granted = cores
     cores = max(1, min(cores, 16))       # a 1-GPU box is granted 16 host cores; more threads only oversubscribe them
     torch.set_num_threads(cores)
+
+    def host_info():
+        """CPU model and PHYSICAL core count of the box (state it next to `cores`), from /proc/cpuinfo."""
+        model, phys = None, set()
+        try:
+            pid = cid = None
+            for line in open("/proc/cpuinfo"):
+                if line.startswith("model name") and model is None:
+                    model = line.split(":", 1)[1].strip()
+                elif line.startswith("physical id"):
+                    pid = line.split(":", 1)[1].strip()
+                elif line.startswith("core id"):
+                    cid = line.split(":", 1)[1].strip()
+                elif not line.strip():
+                    if pid is not None and cid is not None:
+                        phys.add((pid, cid))
+                    pid = cid = None
+        except OSError:
+            pass
+        return {"cpu_model": model, "physical_cores_on_host": len(phys) or None, "logical_cpus_on_host": os.cpu_count(),
+                "cpus_granted_to_this_process": granted, "threads_used": cores}
 
     def iteration_rate(B, warm, timed):
         pb = B // 3
@@ -428,7 +466,9 @@ def cpu_baseline(H, full, full_protocol=False):
             tw.append(time.time() - t0)
     tw.sort()
     wt_gbs = z.numel() * 4.0 / tw[len(tw) // 2] / 1e9
-    return {"value": r6, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+    return {"value": r6, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port", "host": host_info(),
+            "protocol": "SURVEY.md 8d in full: 3 warm-up + 10 timed iterations at B=6 and B=30" if full_protocol else
+                        "bounded sample (1 warm-up + 3 timed at B=6, one iteration at B=30); the full protocol: --cpu-baseline-full",
             "sample": "median of %d full A-D iterations (4 fwd + 4 bwd + 4 Adam) after %d warm-up, B=6, 3x%dx%d, torch CPU fp32 "
                       "(%.1f s each)" % (len(t6), 3 if full_protocol else 1, H, H, t6[len(t6) // 2]),
             "b30": {"value": r30, "unit": "images/s", "sample": "median of %d iteration(s), B=30 (%.1f s each)" % (len(t30), t30[len(t30) // 2])},
@@ -628,6 +668,9 @@ def main():
             fam = un["wgrad"] if lead == "x3_wgrad" else un["fwd_dgrad"]
             head = mfma_line(lead, lead)
             head.update({"achieved": fam["tflops"], "frac": fam["frac"],
+                         "traffic_algorithmic": {"hbm_bytes": un["x3_3x3_mean_bytes"],
+                                                 "note": "input + output bytes, mean over the same 3x3 launches `traffic` is averaged over"}
+                         if lead == "x3_conv" else None,
                          "achieved_note": "FLOP-weighted over all %d forward + %d data-gradient launches of one U-Net that run on the x3 "
                                           "kernels (3x3 and 1x1, every level: `roofline_unet_layers`), HIP events" % (un["fwd"]["layers"], un["dgrad"]["layers"])
                          if lead == "x3_conv" else "FLOP-weighted over all %d 3x3 weight-gradient launches of one U-Net on the x3 kernels" % un["wgrad"]["layers"],

@@ -436,6 +436,69 @@ def test_convu_both_orders_vs_oracle(shape, first):
         close(p.grad, ref, rtol=5e-3, atol=5e-4 * float(ref.abs().max()) + 1e-7, what=k)
 
 
+FULL_ORACLE = os.environ.get("WTPSE_FULL_ORACLE", "0") != "0"
+
+
+@pytest.mark.parametrize("tag", ["b32", "s512"])
+def test_gradients_vs_offline_oracle(golden_dir, tag):
+    """The backward at the benchmark's own geometries — b32: B = 32, 10 rows per domain, 256x256 (BASELINE.json configs[2]: 8192-workgroup
+    launches, the weight gradient's unit / segment split, the stand-alone statistics finalize beyond 2048 workgroups and the in-launch
+    fold below); s512: B = 3 at 512x512 (configs[4]'s per-image geometry) — against the CPU oracle evaluated OFFLINE
+    (oracle/make_golden_grads.py -> tests/golden/grads_<tag>.npz: ten minutes and 30 GB of host per case, too slow for every run of the
+    suite; `WTPSE_FULL_ORACLE=1` runs the same comparison against a live oracle: test_gradients_calibrated[32-10-256] / [3-1-512]).
+    Per parameter tensor the fixture holds a fingerprint of the fp64 gradient (oracle/sketch.py: the tensor itself up to 4096 elements,
+    128 random projections beyond — an unbiased estimate of |h - g64|^2 with 6 % standard deviation on the norm) and the exact distances of
+    three fp32 evaluations of the reference graph from it (inputs as given, perturbed by 1e-6 and by 3e-6).  STRICT band, fixed in advance:
+    every tensor within 3 x the farthest fp32 evaluation + 5e-4 (sketched tensors: x 1.15 for the estimate's scatter), no allowance for
+    outliers, no failure-triggered widening; all gradients together within 3 x + 2e-4."""
+    from oracle import sketch
+    g = np.load(os.path.join(golden_dir, "grads_%s.npz" % tag))
+    B, pb, H, K, small = (int(v) for v in g["meta"])
+    assert (K, small) == (sketch.K, sketch.SMALL)
+    img, od, _ = make_inputs(600, B, H, H)
+    eps = make_noise(700, (B, 1, H, H))
+    main, shape, _, _ = build_nets(pb)
+    main.train(); shape.train()
+    main.zero_grad(); main.set_noise([eps])
+    out, _, _, ins, dom = main.update(img.to(DEV), od.to(DEV), two_stage_inputs=img.to(DEV), two_step=True)
+    (F.binary_cross_entropy(torch.sigmoid(out), od.to(DEV)) + ins + dom).backward()
+
+    def check(module, call):
+        names = [str(n) for n in g[call + "_names"]]
+        params = dict(module.named_parameters())
+        yard2 = g[call + "_yard2"]
+        num_h = den = 0.0
+        num_c = np.zeros(3)
+        bad, worst = [], (0.0, 0.0, "")
+        for i, k in enumerate(names):
+            if is_prebn_bias(k):
+                continue
+            n, n2 = g["%s_%d_n2" % (call, i)]
+            fp = {"n": int(n), "norm2": float(n2), "data": g["%s_%d_fp" % (call, i)]}
+            p = params[k]
+            assert p.grad is not None, k
+            d2 = sketch.distance2(p.grad, fp, 7000 + i)
+            h, c = (d2 / (n2 + 1e-60)) ** 0.5, (float(yard2[i].max()) / (n2 + 1e-60)) ** 0.5
+            slack = 1.0 if n <= small else 1.15
+            if h > slack * (CAL * c + 5e-4):
+                bad.append((h, c, k))
+            worst = max(worst, (h / max(c, 1e-30), h, k))
+            num_h += d2; den += n2; num_c += yard2[i]
+        for k, p in params.items():           # tensors the oracle's graph does not reach must carry no gradient here either
+            if k not in names and not is_prebn_bias(k):
+                assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+        tot_h, tot_c = (num_h / den) ** 0.5, (float(num_c.max()) / den) ** 0.5
+        print(f"[offline {tag} {call}] all gradients: HIP {tot_h:.3e} vs the farthest of three CPU-fp32 draws {tot_c:.3e} from the fp64 oracle "
+              f"(ratio {tot_h / max(tot_c, 1e-30):.2f}); worst tensor ratio {worst[0]:.2f} ({worst[2]}: {worst[1]:.3e})")
+        assert not bad, f"{call}: {len(bad)} tensors beyond {CAL:.0f}x + 5e-4: {sorted(bad, reverse=True)[:4]}"
+        assert tot_h <= 1.15 * (CAL * tot_c + 2e-4), (tot_h, tot_c)
+    check(main, "A")
+    shape.zero_grad(); main.zero_grad()
+    kd, ins_t, _, _, dom_s = shape.update(main, img.to(DEV), od.to(DEV), two_stage_inputs=img.to(DEV), two_step=True)
+    (kd + ins_t + dom_s).backward()
+    check(shape, "B")
+
+
 @pytest.mark.parametrize("B,pb,H", [(3, 1, 32), (6, 2, 32), (6, 2, 64), (6, 2, 256), (32, 10, 256), (3, 1, 512)])
 def test_gradients_calibrated(B, pb, H):
     """Every parameter gradient of call A (seg net + teacher + WT loss) and call B (student) against the oracle
@@ -445,6 +508,9 @@ def test_gradients_calibrated(B, pb, H):
     configs[2]: 8192-workgroup launches, the weight gradient's unit / segment split, statistics folded by the stand-alone finalize
     beyond 2048 workgroups and by the launches' last workgroups below), [3-1-512] the per-image geometry of configs[4].  At
     256x256 and 512x512 the per-tensor band is fixed (strict: every tensor, no probes)."""
+    if (B >= 32 or H >= 512) and not FULL_ORACLE:
+        pytest.skip("5 / 2 minutes of live CPU oracle: run by WTPSE_FULL_ORACLE=1; the default suite holds the same HIP gradients against "
+                    "the same oracle evaluated offline (test_gradients_vs_offline_oracle)")
     img, od, _ = make_inputs(600, B, H, H)
     eps = make_noise(700, (B, 1, H, H))
     main, shape, _, _ = build_nets(pb)

@@ -57,6 +57,7 @@ struct ConvArgs {
   int pro_relu;        // bit0: ReLU on in0 after the affine, bit1: on in1
   int relu_out;
   int tiles_x, tiles_y;
+  int xcd_tiles;       // > 0: tiles per XCD — workgroup b works on tile (b % 8) * xcd_tiles + b / 8 (see conv_fwd_k); 0: tile = b
 };
 
 // Phase stamps for tools/probe/conv_stamps.py (never compiled into libwtpse_hip.so): thread 0 of every workgroup
@@ -122,7 +123,13 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
   float* Ws = smem + XS_SZ;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int bx = blockIdx.x;
+  // Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one: MI355X_MICROARCH.md) and every XCD has its own L2, so
+  // with tile = b the eight neighbours of a tile sit on eight different L2s and each fetches the shared halo (and the partial lines
+  // at its tile's edges) through the fabric again: the HBM-bound 16-channel kernel read 2.75 x its input (rocprofv3 FETCH_SIZE,
+  // calibrated on a copy: profiles/r04_*).  With xcd_tiles set, the workgroups of one XCD walk a contiguous range of tiles — the ~128
+  // that are resident together are a block of neighbouring tiles whose halos meet in that XCD's L2.  Placement only: any mapping is correct.
+  const int tile = a.xcd_tiles > 0 ? (int)(blockIdx.x & 7u) * a.xcd_tiles + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  int bx = tile;
   const int tx = bx % a.tiles_x;
   bx /= a.tiles_x;
   const int ty = bx % a.tiles_y;
@@ -461,7 +468,7 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
       for (int r = 0; r < 4; ++r) gs[((lane >> 4) * 4 + r) * 16 + (lane & 15)] = g[r];
       __syncthreads();
       const float* g0 = smem + 4 * 16 * 65;
-      a.gram[(size_t)blockIdx.x * 256 + tid] = g0[tid] + g0[256 + tid] + g0[512 + tid] + g0[768 + tid];
+      a.gram[(size_t)tile * 256 + tid] = g0[tid] + g0[256 + tid] + g0[512 + tid] + g0[768 + tid];
       __syncthreads();   // before the statistics (if any) reuse smem
     }
   }
@@ -582,9 +589,9 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
       const float s = red[tid] + red[CB * 2 + tid] + red[2 * CB * 2 + tid] + red[3 * CB * 2 + tid];
       if (BNB) {
         const int c = cout0 + crel;
-        if (c >= a.bn_c0 && c < a.bn_c1) pub_store(a.stats + ((size_t)blockIdx.x * Cbn + c - a.bn_c0) * 2 + (tid & 1), s);
+        if (c >= a.bn_c0 && c < a.bn_c1) pub_store(a.stats + ((size_t)tile * Cbn + c - a.bn_c0) * 2 + (tid & 1), s);
       } else if (cout0 + crel < a.Cout) {
-        pub_store(a.stats + ((size_t)blockIdx.x * a.Cout + cout0 + crel) * 2 + (tid & 1), s);
+        pub_store(a.stats + ((size_t)tile * a.Cout + cout0 + crel) * 2 + (tid & 1), s);
       }
     }
   }
@@ -592,8 +599,8 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
   tk.old = 0u;
   tk.armed = 0;
   if (defer) {
-    if constexpr (BNB) tk = bnb_tail_begin<CB>(a.tail, a.bn_c0, a.bn_c1, cout0, (int)blockIdx.x, (int)blockIdx.y, tid);
-    else tk = bnf_tail_begin(a.ftail, (int)blockIdx.x, (int)blockIdx.y, tid);
+    if constexpr (BNB) tk = bnb_tail_begin<CB>(a.tail, a.bn_c0, a.bn_c1, cout0, tile, (int)blockIdx.y, tid);
+    else tk = bnf_tail_begin(a.ftail, tile, (int)blockIdx.y, tid);
   }
   if (defer) {
 #pragma unroll
@@ -608,10 +615,10 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
         for (int nt = 0; nt < NT; ++nt) buf_store(rs_o, pvo[nt], soff, fmaxf(acc[mt][nt][r], relu_lo));
       }
     if constexpr (BNB)
-      bnb_tail<CB>(tk, a.tail, a.stats, a.bn_mean, a.bn_c0, a.bn_c1, cout0, (int)blockIdx.x, (int)blockIdx.y, tid,
+      bnb_tail<CB>(tk, a.tail, a.stats, a.bn_mean, a.bn_c0, a.bn_c1, cout0, tile, (int)blockIdx.y, tid,
                    reinterpret_cast<double*>(red), reinterpret_cast<int*>(red + 4 * CB));
     else
-      bnf_tail<CB>(tk, a.ftail, a.stats, a.Cout, cout0, (int)blockIdx.x, (int)blockIdx.y, tid, reinterpret_cast<double*>(red),
+      bnf_tail<CB>(tk, a.ftail, a.stats, a.Cout, cout0, tile, (int)blockIdx.y, tid, reinterpret_cast<double*>(red),
                    reinterpret_cast<int*>(red + 4 * CB));
   }
   STAMP(61);
@@ -626,6 +633,9 @@ static int launch_fwd(const ConvArgs& a, hipStream_t st) {
   args.tiles_x = ceil_div(a.W, TW);
   args.tiles_y = ceil_div(a.H, TH);
   dim3 grid((unsigned)(a.B * args.tiles_x * args.tiles_y), (unsigned)ceil_div(a.CoutP, CB));
+  // XCD-aware tile order for the HBM-bound 16-channel x3 kernel (MODE 3; WTPSE_C16_XCD=0: tile = workgroup index)
+  static const bool xcd_on = [] { const char* e = getenv("WTPSE_C16_XCD"); return !(e && e[0] == '0'); }();
+  args.xcd_tiles = (MODE == 3 && xcd_on && grid.x % 8 == 0 && grid.x >= 64) ? (int)(grid.x / 8) : 0;
   const bool in_launch = tail_in_launch((long long)grid.x * grid.y);     // else: the stand-alone finalize kernel behind the launch
   if (!in_launch) args.tail.tickets = args.ftail.tickets = nullptr;
   if (args.tail.tickets) bnb_tail_geometry(args.tail, (int)grid.x, a.Cout, (double)a.B * a.H * a.W);
