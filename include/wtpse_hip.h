@@ -250,6 +250,11 @@ int wtpse_maxpool2_bwd_bnb(const float* x, const float* pro, int relu, const flo
 /* bilinear x2, align_corners=False; H, W are the INPUT sizes. */
 int wtpse_upsample2x_fwd(const float* x, const float* pro, int relu, float* out, int B, int C, int H, int W, void* stream);
 int wtpse_upsample2x_bwd(const float* dout, float* dx, int accumulate, int B, int C, int H, int W, void* stream);
+/* ... of a gradient that is the second half of a BatchNorm backward and never written out: dout = k1[c] * g + k2[c] * bn_y + k3[c],
+ * bn_coef [C][3] as wtpse_dgrad_bnb_coef leaves it (the expression of wtpse_bn_bwd_apply_coef, same bits); g, bn_y [B][C][2H][2W].
+ * W % 4 == 0, 16-byte aligned tensors. */
+int wtpse_upsample2x_bwd_bn(const float* g, const float* bn_y, const float* bn_coef, float* dx, int B, int C, int H, int W,
+                            void* stream);
 /* The same with the train-mode BatchNorm statistics of the OUTPUT: stats [wtpse_upsample2x_stats_blocks(B,H,W)][C][2]
  * per-workgroup (sum, sum of squares), the layout wtpse_bn_finalize takes.  Used where the 1x1 conv of a ConvU block
  * (algorithms.py:949-951: upsample -> conv2 -> bn2) runs in front of the upsampling instead (the two commute). W even. */

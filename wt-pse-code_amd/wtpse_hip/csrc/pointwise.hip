@@ -277,8 +277,12 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_k(const float* __restrict_
 
 // plane-per-blockIdx.y form, 4 consecutive dx of one row per thread (W % 4 == 0): the 4 x 10 window of dout comes in
 // as 2 x 16-byte + 2 scalar loads per row; per output the same loops and summation order as the scalar kernel
+// BN: dout is not materialised — it is the second half of a BatchNorm backward, dout = fmaf(k1, g, fmaf(k2, y, k3)) per channel
+// (bn_bwd_apply_k's expression, bn.hip: the same bits) with g = `dout`, y = `bn_y`, (k1, k2, k3) = `bn_coef`[C][3]
+template <bool BN>
 __global__ __launch_bounds__(256) void upsample2x_bwd_v_k(const float* __restrict__ dout, float* __restrict__ dx, int accumulate,
-                                                          int BC, int H, int W) {
+                                                          int BC, int H, int W, const float* __restrict__ bn_y,
+                                                          const float* __restrict__ bn_coef, int C) {
   const int Ho = 2 * H, Wo = 2 * W, W4 = W / 4;
   const int j = blockIdx.x * 256 + threadIdx.x;   // over H*(W/4)
   if (j >= H * W4) return;
@@ -286,6 +290,11 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_v_k(const float* __restric
   const int xb = 4 * k;            // first dx column; dout columns 2*xb-1 .. 2*xb+8
   for (int bc = blockIdx.y; bc < BC; bc += gridDim.y) {
     const float* src = dout + (size_t)bc * Ho * Wo;
+    float k1 = 1.f, k2 = 0.f, k3 = 0.f;
+    if (BN) {
+      const int c = bc % C;
+      k1 = bn_coef[3 * c]; k2 = bn_coef[3 * c + 1]; k3 = bn_coef[3 * c + 2];
+    }
     float g[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int dy = -1; dy <= 2; ++dy) {
@@ -299,6 +308,15 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_v_k(const float* __restric
       w[0] = xb > 0 ? row[-1] : 0.f;
       w[1] = q0.x; w[2] = q0.y; w[3] = q0.z; w[4] = q0.w; w[5] = q1.x; w[6] = q1.y; w[7] = q1.z; w[8] = q1.w;
       w[9] = 2 * xb + 8 < Wo ? row[8] : 0.f;
+      if (BN) {
+        const float* yrow = bn_y + (size_t)bc * Ho * Wo + (size_t)yo * Wo + 2 * xb;
+        const float4 y0 = *reinterpret_cast<const float4*>(yrow), y1 = *reinterpret_cast<const float4*>(yrow + 4);
+        const float v[10] = {xb > 0 ? yrow[-1] : 0.f, y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w, 2 * xb + 8 < Wo ? yrow[8] : 0.f};
+#pragma unroll
+        for (int t = 0; t < 10; ++t) w[t] = fmaf(k1, w[t], fmaf(k2, v[t], k3));
+        if (xb == 0) w[0] = 0.f;                    // outside the map: no gradient (not k3)
+        if (2 * xb + 8 >= Wo) w[9] = 0.f;
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int xx = xb + e;
@@ -742,9 +760,17 @@ extern "C" int wtpse_upsample2x_bwd(const float* dout, float* dx, int accumulate
   WTPSE_REQUIRE(dout && dx && B > 0 && C > 0 && H > 0 && W > 0);
   long long total = (long long)B * C * H * W;
   if (W % 4 == 0 && (((uintptr_t)dout | (uintptr_t)dx) & 15) == 0)
-    hipLaunchKernelGGL(upsample2x_bwd_v_k, PLANE_GRID(H * (W / 4), B * C), dim3(256), 0, ST, dout, dx, accumulate, B * C, H, W);
+    hipLaunchKernelGGL(upsample2x_bwd_v_k<false>, PLANE_GRID(H * (W / 4), B * C), dim3(256), 0, ST, dout, dx, accumulate, B * C, H, W,
+                       nullptr, nullptr, C);
   else
     hipLaunchKernelGGL(upsample2x_bwd_k, GRID1(total), dim3(256), 0, ST, dout, dx, accumulate, H, W, total);
+  return wtpse_status();
+}
+extern "C" int wtpse_upsample2x_bwd_bn(const float* g, const float* bn_y, const float* bn_coef, float* dx, int B, int C, int H, int W,
+                                       void* stream) {
+  WTPSE_REQUIRE(g && bn_y && bn_coef && dx && B > 0 && C > 0 && H > 0 && W > 0 && W % 4 == 0);
+  WTPSE_REQUIRE((((uintptr_t)g | (uintptr_t)bn_y | (uintptr_t)dx) & 15) == 0);
+  hipLaunchKernelGGL(upsample2x_bwd_v_k<true>, PLANE_GRID(H * (W / 4), B * C), dim3(256), 0, ST, g, dx, 0, B * C, H, W, bn_y, bn_coef, C);
   return wtpse_status();
 }
 extern "C" int wtpse_resize_bilinear(const float* x, float* out, int B, int C, int H, int W, int Ho, int Wo, void* stream) {

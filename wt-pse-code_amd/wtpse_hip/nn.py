@@ -683,9 +683,18 @@ def convbn_fwd(conv, bn, a0, a1, relu, training, want_tape=True):
     return z, t
 
 
+# The second half of a BatchNorm backward (dy = k1 g + k2 y + k3 per channel, from the coefficients the producing launch folded)
+# formed by the CONSUMER of dy as it loads, instead of by an elementwise pass of its own (3 HBM passes over the layer's map).
+# WTPSE_BN_IN=0: the stand-alone apply pass (wtpse_bn_bwd_apply_coef) everywhere.
+BN_IN = os.environ.get("WTPSE_BN_IN", "1") != "0"
+_PROBE_SKIP_APPLY = os.environ.get("WTPSE_PROBE_SKIP_BN_APPLY", "0") == "1"
+
+
 def _bn_bwd(bn, t, dz, root):
     """BatchNorm (+ReLU) backward of a convbn / upbn tape: dz = gradient wrt the activated output, plain or PreBN."""
     if isinstance(dz, PreBN):
+        if _PROBE_SKIP_APPLY and dz.coef is not None:
+            return dz.g                     # timing probe only (wrong numbers): the step without the apply pass
         if dz.coef is not None:
             return ops.bn_bwd_apply_coef(dz.g, t.y, dz.coef)
         return ops.bn_bwd_from_stats(dz.g, t.y, dz.stats, bn.weight, t.mean, t.invstd, root.gview(bn.weight), root.gview(bn.bias))
@@ -782,8 +791,10 @@ def upbn_fwd(conv, bn, a0, training, want_tape=True):
 def upbn_bwd(conv, bn, t, dz, below=None):
     """-> gradient wrt the (activated, low-resolution) conv input (a PreBN if `below`, the tape of the layer it came from)."""
     root = conv._root
-    dy = _bn_bwd(bn, t, dz, root)
-    dzl = ops.upsample2x_bwd(dy)
+    if BN_IN and isinstance(dz, PreBN) and dz.coef is not None and dz.g.shape[3] % 8 == 0:
+        dzl = ops.upsample2x_bwd_bn(dz.g, t.y, dz.coef)       # the apply pass on load: dy is never written
+    else:
+        dzl = ops.upsample2x_bwd(_bn_bwd(bn, t, dz, root))
     _wgrad_side(conv, dzl, t.a0, None)                         # bias in front of a train-mode BatchNorm: see convbn_bwd
     return _dgrad(conv, dzl, below0=below)[0]
 

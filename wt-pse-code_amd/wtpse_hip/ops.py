@@ -467,6 +467,16 @@ def upsample2x_bwd(dout):
     return dx
 
 
+def upsample2x_bwd_bn(g, bn_y, coef):
+    """upsample2x_bwd of dout = coef[:,0] * g + coef[:,1] * bn_y + coef[:,2] formed on load (no apply pass, dout never written)."""
+    _chk(g, "g"); _chk(bn_y, "bn_y"); _chk(coef, "coef")
+    B, C, Ho, Wo = g.shape
+    assert bn_y.shape == g.shape and coef.shape == (C, 3) and Wo % 8 == 0, (g.shape, bn_y.shape, coef.shape)
+    dx = torch.empty((B, C, Ho // 2, Wo // 2), dtype=torch.float32, device=g.device)
+    lib().call("wtpse_upsample2x_bwd_bn", ptr(g), ptr(bn_y), ptr(coef), ptr(dx), B, C, Ho // 2, Wo // 2, stream_ptr())
+    return dx
+
+
 def resize_bilinear(x, size):
     _chk(x, "x")
     B, C, H, W = x.shape
