@@ -82,7 +82,7 @@ def check_grads_vs_checksums(module, g, prefix, min_seen, kink_probe=None):
     (every entry within 8 % of the tensor's mean |grad| — at most one per tensor up to 3x that — pooled median within 1 %).  It is coarse on purpose: the
     32x32 fixtures reach 2x2 feature maps (BatchNorm over 12-28 values) and sit on kinks (ReLU, max-pool argmax,
     |G_ij|), so the reference's own fp32 gradients are only good to 0.3-6 % against an fp64 run of the same graph
-    (measured with tools/diag_grads.py).  The tight, self-calibrating gradient check is test_gradients_calibrated."""
+    (measured with tests/diag_grads.py).  The tight, self-calibrating gradient check is test_gradients_calibrated."""
     seen, pooled, band, kinked = 0, [], None, 0
     for k, p in module.named_parameters():
         key = prefix + k
