@@ -61,6 +61,12 @@ int wtpse_conv_x3_stats_blocks(int B, int H, int W, int Cout);   /* rows of `sta
  * on < 0 only queries (environment: WTPSE_X3R=0|1|2).  Returns the previous setting.  The two kernels give bitwise the same
  * results (tests/test_conv_x3_gpu.py::test_x3r_equals_x3); the choice is by measurement (profiles/r04_microbench_x3.txt). */
 int wtpse_x3r_enable(int on);
+/* Order in which the workgroups of the x3 convolutions take their (tile, output-channel block) pairs: on = 1 (default) XCD-aware —
+ * the hardware deals consecutive workgroups to the 8 XCDs in turn; each XCD is given a contiguous range of tiles and runs a tile's
+ * output-channel blocks back to back, so that a tile's input (and the halo it shares with its neighbours) is fetched into ONE L2
+ * once; 0 = dispatch order (tile fastest); on < 0 only queries (environment: WTPSE_X3_XCD=0|1).  Returns the previous setting.
+ * Same workgroups, bitwise the same results (tests/test_conv_x3_gpu.py::test_xcd_order_equals_dispatch_order). */
+int wtpse_x3_xcd(int on);
 /* bf16 terms per fp32 operand in the x3 kernels (wtpse_conv_fwd_x3 and the data gradients on it, wtpse_conv_wgrad_r): 3 (default) =
  * the fp32-accuracy arithmetic above; 1 = the `bf16` mode of BASELINE.json configs[1]: operands rounded to bf16 (nearest even), ONE
  * bf16 MFMA product per multiply, fp32 accumulation — outside the 1e-4 parity bar by construction (tests/test_bf16_mode_gpu.py

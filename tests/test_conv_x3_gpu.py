@@ -472,11 +472,8 @@ X3R_CASES = [
 ]
 
 
-@pytest.mark.parametrize("case", X3R_CASES)
-def test_x3r_equals_x3(case):
-    """conv_x3r_k (weights fed from registers, double-buffered input tile; the default for 3x3) against conv_x3_k (weights staged in
-    LDS): same products in the same order on every accumulator, so every output — result, BatchNorm partials, masked data gradient,
-    BatchNorm-backward epilogue — must be BITWISE equal.  All other x3 tests run the default kernel against stock PyTorch."""
+def _x3_case_runner(case):
+    """-> (ops, run): run() launches every kind of 3x3 x3 convolution on the case's operands and returns all outputs."""
     o = ops()
     B, C0, C1, Co, H, W = case
     dev = DEV
@@ -509,6 +506,15 @@ def test_x3r_equals_x3(case):
         torch.cuda.synchronize()
         return outs
 
+    return o, run
+
+
+@pytest.mark.parametrize("case", X3R_CASES)
+def test_x3r_equals_x3(case):
+    """conv_x3r_k (weights fed from registers, double-buffered input tile; the default for 3x3) against conv_x3_k (weights staged in
+    LDS): same products in the same order on every accumulator, so every output — result, BatchNorm partials, masked data gradient,
+    BatchNorm-backward epilogue — must be BITWISE equal.  All other x3 tests run the default kernel against stock PyTorch."""
+    o, run = _x3_case_runner(case)
     assert o.lib().query("wtpse_x3r_enable", 2) == 1, "conv_x3r_k on the 64-channel blocks must be the default"
     try:
         new = run()                              # mode 2: conv_x3r_k on every 3x3 launch, also the shapes it is not the default for
@@ -517,4 +523,21 @@ def test_x3r_equals_x3(case):
     finally:
         o.lib().query("wtpse_x3r_enable", 1)
     for i, (a_, b_) in enumerate(zip(new, old)):
+        assert torch.equal(a_, b_), "output %d differs: max |d| = %g" % (i, float((a_ - b_).abs().max()))
+
+
+@pytest.mark.parametrize("case", X3R_CASES + [(32, 64, 64, 128, 64, 64), (32, 32, 0, 32, 128, 128)])
+def test_xcd_order_equals_dispatch_order(case):
+    """The XCD-aware workgroup order (ConvX3Args::xcd_tiles: each XCD a contiguous range of tiles, a tile's output-channel blocks back
+    to back) against plain dispatch order: the same workgroups compute the same things, the BatchNorm tails fold the same partials
+    in the same order — every output bitwise equal.  The two large cases are launches of the benchmark's step (8192 / 4096 tiles)."""
+    o, run = _x3_case_runner(case)
+    assert o.lib().query("wtpse_x3_xcd", 0) == 1, "the XCD-aware order must be the default"
+    try:
+        plain = run()
+        o.lib().query("wtpse_x3_xcd", 1)
+        xcd = run()
+    finally:
+        o.lib().query("wtpse_x3_xcd", 1)
+    for i, (a_, b_) in enumerate(zip(xcd, plain)):
         assert torch.equal(a_, b_), "output %d differs: max |d| = %g" % (i, float((a_ - b_).abs().max()))

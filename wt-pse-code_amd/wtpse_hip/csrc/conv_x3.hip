@@ -59,7 +59,23 @@ struct ConvX3Args {
   int Cout, CoutP, Csplit;    // CoutP: multiple of 32
   int pro_relu, relu_out;
   int tiles_x, tiles_y;
+  // XCD-aware workgroup order (launch_x3): dispatch slot L = blockIdx.y * gridDim.x + blockIdx.x goes to XCD L % 8 (round robin);
+  // with xcd_tiles = gridDim.x / 8 > 0 XCD q works through the tiles [q * xcd_tiles, (q + 1) * xcd_tiles), the output-channel blocks
+  // of a tile in consecutive slots — one L2 then holds a tile's input for all the blocks that read it and for the neighbours that
+  // share its halo, instead of every XCD fetching every tile once per block (measured: x3_conv HBM reads 205 -> see DESIGN.md)
+  int xcd_tiles;
 };
+
+// (tile index, output-channel block) of this workgroup
+__device__ __forceinline__ void x3_block_ids(const ConvX3Args& a, int& tile, int& cblk) {
+  tile = blockIdx.x;
+  cblk = blockIdx.y;
+  if (a.xcd_tiles > 0) {
+    const int L = blockIdx.y * gridDim.x + blockIdx.x, s = L >> 3;
+    cblk = s % (int)gridDim.y;
+    tile = (L & 7) * a.xcd_tiles + s / (int)gridDim.y;
+  }
+}
 
 template <class F, int... I>
 __device__ __forceinline__ void x3_static_for_impl(F&& f, std::integer_sequence<int, I...>) {
@@ -103,7 +119,7 @@ __device__ __forceinline__ void split3_pair(float a, float b, unsigned& p0, unsi
 // (4 / WM)-wave pixel split; conv_x3_k: 1, every wave holds all CB channels of its pixels).
 template <int MT, int NT, int TWL, int EPI, bool RED_ALIASES, int WM = 1>
 __device__ __forceinline__ void x3_epilogue(const ConvX3Args& a, f32x16 (&acc)[MT][NT], int b, int ty, int tx, int cout0, int tid,
-                                            float* red, const float* bias_s, int stats_row, bool live) {
+                                            float* red, const float* bias_s, int stats_row, int cblk, bool live) {
   constexpr int PW = 4 / WM;
   constexpr int TW = 1 << TWL, TH = (PW * 32 * NT) / TW;
   constexpr int CBW = 32 * MT, CB = CBW * WM, NACC = 16;
@@ -283,8 +299,8 @@ __device__ __forceinline__ void x3_epilogue(const ConvX3Args& a, f32x16 (&acc)[M
   tk.old = 0u;
   tk.armed = 0;
   if (defer) {
-    if constexpr (BNB) tk = bnb_tail_begin<CB>(a.tail, a.bn_c0, a.bn_c1, cout0, stats_row, (int)blockIdx.y, tid);
-    else tk = bnf_tail_begin(a.ftail, stats_row, (int)blockIdx.y, tid);
+    if constexpr (BNB) tk = bnb_tail_begin<CB>(a.tail, a.bn_c0, a.bn_c1, cout0, stats_row, cblk, tid);
+    else tk = bnf_tail_begin(a.ftail, stats_row, cblk, tid);
   }
   if (defer) {
 #pragma unroll
@@ -299,10 +315,10 @@ __device__ __forceinline__ void x3_epilogue(const ConvX3Args& a, f32x16 (&acc)[M
         for (int nt = 0; nt < NT; ++nt) buf_store(rs_o, pvo[nt], soff, fmaxf(acc[mt][nt][r], relu_lo));
       }
     if constexpr (BNB)
-      bnb_tail<CB>(tk, a.tail, a.stats, a.bn_mean, a.bn_c0, a.bn_c1, cout0, stats_row, (int)blockIdx.y, tid,
+      bnb_tail<CB>(tk, a.tail, a.stats, a.bn_mean, a.bn_c0, a.bn_c1, cout0, stats_row, cblk, tid,
                    reinterpret_cast<double*>(red), reinterpret_cast<int*>(red + 4 * CB));
     else
-      bnf_tail<CB>(tk, a.ftail, a.stats, a.Cout, cout0, stats_row, (int)blockIdx.y, tid, reinterpret_cast<double*>(red),
+      bnf_tail<CB>(tk, a.ftail, a.stats, a.Cout, cout0, stats_row, cblk, tid, reinterpret_cast<double*>(red),
                    reinterpret_cast<int*>(red + 4 * CB));
   }
 }
@@ -337,12 +353,14 @@ __global__ __launch_bounds__(256, 2) void conv_x3_k(ConvX3Args a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r32 = lane & 31, h = lane >> 5;
-  int bx = blockIdx.x;
+  int tile, cblk;
+  x3_block_ids(a, tile, cblk);
+  int bx = tile;
   const int tx = bx % a.tiles_x;
   bx /= a.tiles_x;
   const int ty = bx % a.tiles_y;
   const int b = bx / a.tiles_y;
-  const int cout0 = blockIdx.y * CB;
+  const int cout0 = cblk * CB;
   const int HW = a.H * a.W;
   if (tid < CB) bias_s[tid] = (a.bias && cout0 + tid < a.Cout) ? a.bias[cout0 + tid] : 0.f;
   if (EPI == 2 && tid < CB) {                     // (scale, shift, mean) of the BatchNorm'd output channels; (0, 1, 0) elsewhere
@@ -609,7 +627,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_k(ConvX3Args a) {
   }
 
   XSTAMP(60);
-  x3_epilogue<MT, NT, TWL, EPI, true>(a, acc, b, ty, tx, cout0, tid, reinterpret_cast<float*>(smem), bias_s, (int)blockIdx.x, true);
+  x3_epilogue<MT, NT, TWL, EPI, true>(a, acc, b, ty, tx, cout0, tid, reinterpret_cast<float*>(smem), bias_s, tile, cblk, true);
   XSTAMP(61);
   XSTAMPV(59, __builtin_amdgcn_s_memrealtime());
   XSTAMPV(62, (unsigned long long)nchunks);
@@ -674,12 +692,14 @@ __global__ __launch_bounds__(256, 2) void conv_x3r_k(ConvX3Args a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cw = __builtin_amdgcn_readfirstlane(wave % WM), pw = __builtin_amdgcn_readfirstlane(wave / WM);
   const int r32 = lane & 31, h = lane >> 5;
-  int bx = blockIdx.x;
+  int tile, cblk;
+  x3_block_ids(a, tile, cblk);
+  int bx = tile;
   const int tx = bx % a.tiles_x;
   bx /= a.tiles_x;
   const int ty = bx % a.tiles_y;
   const int b = bx / a.tiles_y;
-  const int cout0 = blockIdx.y * CB;
+  const int cout0 = cblk * CB;
   const int HW = a.H * a.W;
   if (tid < CB) bias_s[tid] = (a.bias && cout0 + tid < a.Cout) ? a.bias[cout0 + tid] : 0.f;
   if (EPI == 2 && tid < CB) {
@@ -904,7 +924,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3r_k(ConvX3Args a) {
     }
   }
 
-  x3_epilogue<MT, NT, TWL, EPI, true, WM>(a, acc, b, ty, tx, cout0, tid, reinterpret_cast<float*>(smem), bias_s, (int)blockIdx.x, true);
+  x3_epilogue<MT, NT, TWL, EPI, true, WM>(a, acc, b, ty, tx, cout0, tid, reinterpret_cast<float*>(smem), bias_s, tile, cblk, true);
   RCLK(3);
 }
 
@@ -982,6 +1002,15 @@ extern "C" int wtpse_x3_terms(int terms) {
   return was;
 }
 
+// XCD-aware workgroup order of the x3 convolutions (ConvX3Args::xcd_tiles); WTPSE_X3_XCD=0 / wtpse_x3_xcd(0): dispatch order.
+// Same workgroups, same results — a pure A/B of the order.
+static int g_x3_xcd = [] { const char* e = getenv("WTPSE_X3_XCD"); return (e && e[0] == '0') ? 0 : 1; }();
+extern "C" int wtpse_x3_xcd(int on) {
+  const int was = g_x3_xcd;
+  if (on >= 0) g_x3_xcd = on ? 1 : 0;
+  return was;
+}
+
 template <int KS, int MT, int EPI, int TERMS = 3>
 static int launch_x3(const ConvX3Args& a, hipStream_t st) {
   ConvX3Args args = a;
@@ -991,6 +1020,7 @@ static int launch_x3(const ConvX3Args& a, hipStream_t st) {
   args.tiles_x = ceil_div(a.W, TW);
   args.tiles_y = ceil_div(a.H, TH);
   dim3 grid((unsigned)(a.B * args.tiles_x * args.tiles_y), (unsigned)ceil_div(a.CoutP, 32 * MT));
+  args.xcd_tiles = (g_x3_xcd && grid.x % 8 == 0 && (long long)grid.x * grid.y >= 64) ? (int)grid.x / 8 : 0;
   const bool in_launch = tail_in_launch((long long)grid.x * grid.y);     // else: the stand-alone finalize kernel behind the launch
   if (!in_launch) args.tail.tickets = args.ftail.tickets = nullptr;
   if (args.tail.tickets) bnb_tail_geometry(args.tail, (int)grid.x, a.Cout, (double)a.B * a.H * a.W);

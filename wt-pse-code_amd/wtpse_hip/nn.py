@@ -687,14 +687,9 @@ def convbn_fwd(conv, bn, a0, a1, relu, training, want_tape=True):
 # formed by the CONSUMER of dy as it loads, instead of by an elementwise pass of its own (3 HBM passes over the layer's map).
 # WTPSE_BN_IN=0: the stand-alone apply pass (wtpse_bn_bwd_apply_coef) everywhere.
 BN_IN = os.environ.get("WTPSE_BN_IN", "1") != "0"
-_PROBE_SKIP_APPLY = os.environ.get("WTPSE_PROBE_SKIP_BN_APPLY", "0") == "1"
-
-
 def _bn_bwd(bn, t, dz, root):
     """BatchNorm (+ReLU) backward of a convbn / upbn tape: dz = gradient wrt the activated output, plain or PreBN."""
     if isinstance(dz, PreBN):
-        if _PROBE_SKIP_APPLY and dz.coef is not None:
-            return dz.g                     # timing probe only (wrong numbers): the step without the apply pass
         if dz.coef is not None:
             return ops.bn_bwd_apply_coef(dz.g, t.y, dz.coef)
         return ops.bn_bwd_from_stats(dz.g, t.y, dz.stats, bn.weight, t.mean, t.invstd, root.gview(bn.weight), root.gview(bn.bias))
