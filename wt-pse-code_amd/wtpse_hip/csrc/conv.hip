@@ -128,13 +128,19 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
   // at its tile's edges) through the fabric again: the HBM-bound 16-channel kernel read 2.75 x its input (rocprofv3 FETCH_SIZE,
   // calibrated on a copy: profiles/r04_*).  With xcd_tiles set, the workgroups of one XCD walk a contiguous range of tiles — the ~128
   // that are resident together are a block of neighbouring tiles whose halos meet in that XCD's L2.  Placement only: any mapping is correct.
-  const int tile = a.xcd_tiles > 0 ? (int)(blockIdx.x & 7u) * a.xcd_tiles + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  // (Launches with several output-channel blocks: a tile's blocks in consecutive slots of the same XCD, as in conv_x3.hip.)
+  int tile = (int)blockIdx.x, cblk = (int)blockIdx.y;
+  if (a.xcd_tiles > 0) {
+    const int L = (int)(blockIdx.y * gridDim.x + blockIdx.x), sl = L >> 3;
+    cblk = sl % (int)gridDim.y;
+    tile = (L & 7) * a.xcd_tiles + sl / (int)gridDim.y;
+  }
   int bx = tile;
   const int tx = bx % a.tiles_x;
   bx /= a.tiles_x;
   const int ty = bx % a.tiles_y;
   const int b = bx / a.tiles_y;
-  const int cout0 = blockIdx.y * CB;
+  const int cout0 = cblk * CB;
   const int HW = a.H * a.W;
   if (tid < CB) bias_s[tid] = (a.bias && cout0 + tid < a.Cout) ? a.bias[cout0 + tid] : 0.f;
   if (BNB && tid < CB) {
@@ -599,8 +605,8 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
   tk.old = 0u;
   tk.armed = 0;
   if (defer) {
-    if constexpr (BNB) tk = bnb_tail_begin<CB>(a.tail, a.bn_c0, a.bn_c1, cout0, tile, (int)blockIdx.y, tid);
-    else tk = bnf_tail_begin(a.ftail, tile, (int)blockIdx.y, tid);
+    if constexpr (BNB) tk = bnb_tail_begin<CB>(a.tail, a.bn_c0, a.bn_c1, cout0, tile, cblk, tid);
+    else tk = bnf_tail_begin(a.ftail, tile, cblk, tid);
   }
   if (defer) {
 #pragma unroll
@@ -615,10 +621,10 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
         for (int nt = 0; nt < NT; ++nt) buf_store(rs_o, pvo[nt], soff, fmaxf(acc[mt][nt][r], relu_lo));
       }
     if constexpr (BNB)
-      bnb_tail<CB>(tk, a.tail, a.stats, a.bn_mean, a.bn_c0, a.bn_c1, cout0, tile, (int)blockIdx.y, tid,
+      bnb_tail<CB>(tk, a.tail, a.stats, a.bn_mean, a.bn_c0, a.bn_c1, cout0, tile, cblk, tid,
                    reinterpret_cast<double*>(red), reinterpret_cast<int*>(red + 4 * CB));
     else
-      bnf_tail<CB>(tk, a.ftail, a.stats, a.Cout, cout0, tile, (int)blockIdx.y, tid, reinterpret_cast<double*>(red),
+      bnf_tail<CB>(tk, a.ftail, a.stats, a.Cout, cout0, tile, cblk, tid, reinterpret_cast<double*>(red),
                    reinterpret_cast<int*>(red + 4 * CB));
   }
   STAMP(61);
@@ -633,9 +639,9 @@ static int launch_fwd(const ConvArgs& a, hipStream_t st) {
   args.tiles_x = ceil_div(a.W, TW);
   args.tiles_y = ceil_div(a.H, TH);
   dim3 grid((unsigned)(a.B * args.tiles_x * args.tiles_y), (unsigned)ceil_div(a.CoutP, CB));
-  // XCD-aware tile order for the HBM-bound 16-channel x3 kernel (MODE 3; WTPSE_C16_XCD=0: tile = workgroup index)
+  // XCD-aware tile order (WTPSE_C16_XCD=0: dispatch order): first for the HBM-bound 16-channel x3 kernel (MODE 3), then every mode
   static const bool xcd_on = [] { const char* e = getenv("WTPSE_C16_XCD"); return !(e && e[0] == '0'); }();
-  args.xcd_tiles = (MODE == 3 && xcd_on && grid.x % 8 == 0 && grid.x >= 64) ? (int)(grid.x / 8) : 0;
+  args.xcd_tiles = (xcd_on && grid.x % 8 == 0 && (long long)grid.x * grid.y >= 64) ? (int)(grid.x / 8) : 0;
   const bool in_launch = tail_in_launch((long long)grid.x * grid.y);     // else: the stand-alone finalize kernel behind the launch
   if (!in_launch) args.tail.tickets = args.ftail.tickets = nullptr;
   if (args.tail.tickets) bnb_tail_geometry(args.tail, (int)grid.x, a.Cout, (double)a.B * a.H * a.W);
