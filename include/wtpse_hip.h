@@ -55,7 +55,7 @@ int wtpse_conv_fwd_gram(const float* in0, int C0, const float* wpacked, const fl
  * wtpse_pack_conv_weights_x3 — desc as for wtpse_pack_conv_weights with offsets {xf_off, xd_off} in unsigned shorts; per
  * conv and direction ceil16(K) * ceil32(rows) * taps * 3 unsigned shorts (forward: rows = Cout, K = Cin; data gradient:
  * rows = Cin, K = Cout), layout [K chunk 16][row block 32][tap][term 3][k half 2][row 32][8 k]. */
-int wtpse_conv_x3_stats_blocks(int B, int H, int W, int Cout);   /* rows of `stats` for wtpse_conv_fwd_x3 */
+int wtpse_conv_x3_stats_blocks(int B, int H, int W, int Cout, int ksize);   /* rows of `stats` for wtpse_conv_fwd_x3 (the tiling depends on the kernel size) */
 /* Which 3x3 launches of the x3 entry points run conv_x3r_k (weights fed from registers, input tile double-buffered in LDS) instead
  * of conv_x3_k (weights staged through LDS): on = 1 (default) the launches with 64-channel output blocks, 2 all of them, 0 none;
  * on < 0 only queries (environment: WTPSE_X3R=0|1|2).  Returns the previous setting.  The two kernels give bitwise the same

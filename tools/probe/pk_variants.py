@@ -39,7 +39,7 @@ def main():
         packed = torch.zeros(2 * xf, dtype=torch.int16, device=dev)
         desc = torch.tensor([0, C, C, 9, 0, xf, 0, 0], dtype=torch.int32, device=dev)
         assert dll.wtpse_pack_conv_weights_x3(vp(w.data_ptr()), vp(desc.data_ptr()), 1, vp(packed.data_ptr()), None) == 0
-        nblk = dll.wtpse_conv_x3_stats_blocks(B, H, W, C)
+        nblk = dll.wtpse_conv_x3_stats_blocks(B, H, W, C, 3)
         ref = None
         bad_launches, bad_elems, lanes = 0, 0, {}
         wrong_vs_fwd = 0

@@ -57,7 +57,7 @@ def main():
     stamps = torch.zeros(nwg * 64, dtype=torch.int64, device=dev)
 
     want_stats, want_pro = os.environ.get("STATS", "0") != "0", os.environ.get("PRO", "0") != "0"     # as the forward pass runs it
-    nrows = dll.wtpse_conv_x3_stats_blocks(B, hw, hw, cout)
+    nrows = dll.wtpse_conv_x3_stats_blocks(B, hw, hw, cout, 3)
     stats_t = torch.zeros(nrows * cout * 2, device=dev) if want_stats else None
     pro_t = torch.stack([torch.rand(cin, device=dev) + 0.5, torch.randn(cin, device=dev) * 0.1], 1).contiguous() if want_pro else None
 

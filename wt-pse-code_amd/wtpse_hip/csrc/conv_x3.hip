@@ -1011,12 +1011,13 @@ extern "C" int wtpse_x3_xcd(int on) {
   return was;
 }
 
+// half: the 64-channel blocks on 128-pixel tiles (x3_half below) — conv_x3r_k<2, 1, 2, ...>
 template <int KS, int MT, int EPI, int TERMS = 3>
-static int launch_x3(const ConvX3Args& a, hipStream_t st) {
+static int launch_x3(const ConvX3Args& a, hipStream_t st, bool half = false) {
   ConvX3Args args = a;
   const bool narrow = a.W <= 16;
   const bool small = MT == 1 && x3_small_tiles(a.B, a.H, a.W, a.CoutP, false);
-  const int TW = narrow ? 16 : 32, TH = (small ? 128 : 256) / TW;
+  const int TW = narrow ? 16 : 32, TH = ((small || half) ? 128 : 256) / TW;
   args.tiles_x = ceil_div(a.W, TW);
   args.tiles_y = ceil_div(a.H, TH);
   dim3 grid((unsigned)(a.B * args.tiles_x * args.tiles_y), (unsigned)ceil_div(a.CoutP, 32 * MT));
@@ -1029,7 +1030,12 @@ static int launch_x3(const ConvX3Args& a, hipStream_t st) {
   // gradients), 2 = everywhere (32-channel blocks run 8-20 % SLOWER on it: half the MFMAs per converted input element), 0 = nowhere
   if (KS == 3 && TERMS == 3 && (g_x3r == 2 || (g_x3r == 1 && MT == 2))) {
     if constexpr (KS == 3 && TERMS == 3) {
-      if (small) {
+      if (half) {
+        if constexpr (MT == 2) {
+          if (narrow) hipLaunchKernelGGL((conv_x3r_k<2, 1, 2, 4, EPI>), grid, dim3(256), 0, st, args);
+          else hipLaunchKernelGGL((conv_x3r_k<2, 1, 2, 5, EPI>), grid, dim3(256), 0, st, args);
+        }
+      } else if (small) {
         if constexpr (MT == 1) hipLaunchKernelGGL((conv_x3r_k<1, 1, 1, 4, EPI>), grid, dim3(256), 0, st, args);
       } else if (MT == 2) {
 #ifdef WTPSE_PROBE
@@ -1075,10 +1081,24 @@ static bool x3_mt2(int B, int H, int W, int CoutP) {
   return mt2;
 }
 
+// Mid-sized launches (3x3, output channels a multiple of 64, too few 256-pixel tiles for the 64-channel blocks to give every CU two
+// workgroups): instead of falling back to the 32-channel blocks — which convert every input element for half as many MFMAs — the
+// 64-channel blocks of conv_x3r_k on 128-PIXEL tiles (2 x 2 waves of 32 channels x 64 pixels), if that yields at least
+// g_x3_half_min workgroups.  WTPSE_X3_HALF=0: off; WTPSE_X3_HALF_MIN: the threshold (default 256 = one per CU: measured on the 16x16
+// maps of down4 at B=32, 256 such workgroups beat 512 of the 32-channel blocks on 128-pixel tiles by 11-13 %; forward of down3 /
+// up2.conv1 -8..-10 %: profiles/r04_microbench_x3.txt).
+static int g_x3_half_min = [] { const char* e = getenv("WTPSE_X3_HALF"); if (e && e[0] == '0') return 0;
+                                const char* m = getenv("WTPSE_X3_HALF_MIN"); const int v = m ? atoi(m) : 256; return v > 0 ? v : 256; }();
+static bool x3_half(int B, int H, int W, int CoutP, int ksize) {
+  if (ksize != 3 || g_x3_half_min == 0 || g_x3r == 0 || g_x3_terms != 3 || CoutP % 64 != 0 || x3_mt2(B, H, W, CoutP)) return false;
+  const int TW = W <= 16 ? 16 : 32, TH = 128 / TW;
+  return B * ceil_div(W, TW) * ceil_div(H, TH) * (CoutP / 64) >= g_x3_half_min;
+}
+
 // workgroups along x of a wtpse_conv_fwd_x3 launch = rows of its `stats` partials
-extern "C" int wtpse_conv_x3_stats_blocks(int B, int H, int W, int Cout) {
+extern "C" int wtpse_conv_x3_stats_blocks(int B, int H, int W, int Cout, int ksize) {
   const int CoutP = (Cout + 31) & ~31;
-  const bool small = x3_small_tiles(B, H, W, CoutP, x3_mt2(B, H, W, CoutP));
+  const bool small = x3_half(B, H, W, CoutP, ksize) || x3_small_tiles(B, H, W, CoutP, x3_mt2(B, H, W, CoutP));
   const int TW = W <= 16 ? 16 : 32, TH = (small ? 128 : 256) / TW;
   return B * ceil_div(W, TW) * ceil_div(H, TH);
 }
@@ -1118,6 +1138,8 @@ static int conv_x3_impl(const float* in0, int C0, const float* in1, int C1, cons
   WTPSE_REQUIRE(a.CinP <= (mt2 ? 512 : 256));            // prologue coefficients staged in LDS (conv_x3_k: PRO_MAX)
 #define X3T(KS, M, T) (bnb ? launch_x3<KS, M, 2, T>(a, st) : mask_ref ? launch_x3<KS, M, 1, T>(a, st) : launch_x3<KS, M, 0, T>(a, st))
 #define X3(KS, M) (g_x3_terms == 1 ? X3T(KS, M, 1) : X3T(KS, M, 3))
+  if (ksize == 3 && x3_half(B, H, W, a.CoutP, 3))
+    return bnb ? launch_x3<3, 2, 2, 3>(a, st, true) : mask_ref ? launch_x3<3, 2, 1, 3>(a, st, true) : launch_x3<3, 2, 0, 3>(a, st, true);
   if (ksize == 3) return mt2 ? X3(3, 2) : X3(3, 1);
   return mt2 ? X3(1, 2) : X3(1, 1);
 #undef X3

@@ -128,7 +128,7 @@ def conv_fwd_x3(in0, in1, wpacked_ptr, bias, cout, ksize, pro0=None, pro_relu=0,
         out1 = torch.empty((B, cout - csplit, H, W), dtype=torch.float32, device=in0.device)
     stats = None
     if want_stats:
-        nblk = L.query("wtpse_conv_x3_stats_blocks", B, H, W, cout)
+        nblk = L.query("wtpse_conv_x3_stats_blocks", B, H, W, cout, int(ksize))
         stats = torch.empty((nblk, cout, 2), dtype=torch.float32, device=in0.device)
     L.call("wtpse_conv_fwd_x3", ptr(in0), C0, ptr(in1), C1, wpacked_ptr, ptr(bias), ptr(pro0), ptr(pro1), int(pro_relu), ptr(out0),
            ptr(out1), csplit, ptr(stats), B, H, W, cout, ksize, int(relu_out), ptr(mask_ref), stream_ptr())
@@ -180,7 +180,7 @@ def dgrad_bnb(dy, wpacked_ptr, layout, cout, ksize, bn_y, bn_ss, bn_mean, bn_rel
         out0 = torch.empty((B, csplit, H, W), dtype=torch.float32, device=dy.device)
         out1 = torch.empty((B, cout - csplit, H, W), dtype=torch.float32, device=dy.device)
     assert bn_y.shape == (B, c1 - c0, H, W), (bn_y.shape, (B, c1 - c0, H, W))
-    nblk = L.query("wtpse_conv_x3_stats_blocks", B, H, W, cout) if layout == 1 else L.query("wtpse_conv_stats_blocks", B, H, W)
+    nblk = L.query("wtpse_conv_x3_stats_blocks", B, H, W, cout, int(ksize)) if layout == 1 else L.query("wtpse_conv_stats_blocks", B, H, W)
     stats = torch.empty((nblk, c1 - c0, 2), dtype=torch.float32, device=dy.device)
     if tail is not None:
         gamma, invstd, dgamma, dbeta = tail
@@ -278,7 +278,7 @@ def conv_fwd_bnf(in0, in1, wpacked_ptr, layout, bias, cout, ksize, pro0, pro_rel
     L = lib()
     dev = in0.device
     out = torch.empty((B, cout, H, W), dtype=torch.float32, device=dev)
-    nblk = L.query("wtpse_conv_x3_stats_blocks", B, H, W, cout) if layout == 1 else L.query("wtpse_conv_stats_blocks", B, H, W)
+    nblk = L.query("wtpse_conv_x3_stats_blocks", B, H, W, cout, int(ksize)) if layout == 1 else L.query("wtpse_conv_stats_blocks", B, H, W)
     stats = torch.empty((nblk, cout, 2), dtype=torch.float32, device=dev)
     ss = torch.empty((cout, 2), dtype=torch.float32, device=dev)
     mean = torch.empty((cout,), dtype=torch.float32, device=dev)
