@@ -161,6 +161,10 @@ def test_conv_x3_wgrad(case):
     (2, 48, 0, 16, 33, 32, True),     # 1 x 1 fragments, three cin blocks, bias
     (24, 32, 32, 64, 32, 64, False),  # several units per wave
     (40, 16, 0, 16, 64, 64, True),    # row segments (more waves than columns) and several units per wave
+    (4, 32, 0, 32, 16, 16, False),    # W = 16: two images side by side per 32-pixel step
+    (5, 64, 64, 128, 16, 16, False),  # ... an odd batch (the last pair is a single image), concat
+    (3, 16, 0, 16, 7, 16, True),      # ... 16 x 16 blocks with bias, odd height and batch
+    (32, 128, 0, 256, 16, 16, False), # ... down4.conv1 at the benchmark's batch
 ])
 def test_conv_wgrad_r(case):
     """The register-resident x3 weight gradient (csrc/wgrad_r.hip) against the fp64 gradient of stock conv2d, at the tolerance

@@ -46,6 +46,10 @@ struct WgradRArgs {
   int units;       // B * strips * nseg
   int wpp;         // waves per (cout block, cin block) pair (multiple of 4)
   int nci;         // cin blocks
+  // twin: W == 16 — a 32-pixel k-step is row y of TWO consecutive images side by side (lane groups 0, 1: image b, columns 0-7 / 8-15;
+  // groups 2, 3: image b + 1): the same rows, vertical taps and strip-end logic (both strip ends are image edges: zero), and the pixel
+  // that crosses from group 1 to group 2 (the seam between the images) is zero as well.  strips = 1, units over image PAIRS.
+  int twin;
 };
 
 template <int I> using IC = std::integral_constant<int, I>;
@@ -155,32 +159,39 @@ __global__ __launch_bounds__((64 * WgradRGeom<MF, NF>::NW), 1) void wgrad_r_k(Wg
     }
   }
   const int src_up = (lane + 16) & 63, src_dn = (lane - 16) & 63;
+  // twin: nothing crosses the seam between the two images — lane group 2 hands no pixel 0 down to group 1, group 1 no pixel 7 up to group 2
+  const unsigned seam_r = (a.twin && g == 2) ? 0u : ~0u, seam_l = (a.twin && g == 1) ? 0u : ~0u;
 
   for (int u = u0; u < u1; ++u) {
     // unit -> (image, row segment, 32-pixel strip), strips fastest: the four waves of a workgroup then walk down four adjacent
     // strips in step, i.e. read 512 contiguous bytes of every channel row between them (DRAM pages, L2 lines)
     const int strip = u % a.strips;
     const int bs = u / a.strips;
-    const int seg = bs % a.nseg, b = bs / a.nseg;
+    const int seg = bs % a.nseg, b = (bs / a.nseg) << a.twin;
+    const unsigned nimg = (a.twin && b + 1 < a.B) ? 2u : 1u;      // images behind the descriptors (an odd batch ends on a single one)
+    const bool lane_live = (unsigned)(a.twin ? g >> 1 : 0) < nimg;     // false: this lane's image is the odd batch's missing twin
     const int x0 = strip * 32;
     const int y0 = seg * a.rseg, y1 = min(a.H, y0 + a.rseg);
     const int rfirst = max(y0 - 1, 0), rlast = min(y1, a.H - 1);
-    const __amdgpu_buffer_rsrc_t rsy = make_rsrc(a.dy + (size_t)b * a.Cout * HW, (unsigned)a.Cout * HW * 4u);
-    const __amdgpu_buffer_rsrc_t rsb = AFF ? make_rsrc(a.bn_y + (size_t)b * a.Cout * HW, (unsigned)a.Cout * HW * 4u) : rsy;
-    const __amdgpu_buffer_rsrc_t rsx0 = make_rsrc(a.x0 + (size_t)b * a.C0 * HW, (unsigned)a.C0 * HW * 4u);
-    const __amdgpu_buffer_rsrc_t rsx1 = a.x1 ? make_rsrc(a.x1 + (size_t)b * a.C1 * HW, (unsigned)a.C1 * HW * 4u) : rsx0;
+    const __amdgpu_buffer_rsrc_t rsy = make_rsrc(a.dy + (size_t)b * a.Cout * HW, nimg * (unsigned)a.Cout * HW * 4u);
+    const __amdgpu_buffer_rsrc_t rsb = AFF ? make_rsrc(a.bn_y + (size_t)b * a.Cout * HW, nimg * (unsigned)a.Cout * HW * 4u) : rsy;
+    const __amdgpu_buffer_rsrc_t rsx0 = make_rsrc(a.x0 + (size_t)b * a.C0 * HW, nimg * (unsigned)a.C0 * HW * 4u);
+    const __amdgpu_buffer_rsrc_t rsx1 = a.x1 ? make_rsrc(a.x1 + (size_t)b * a.C1 * HW, nimg * (unsigned)a.C1 * HW * 4u) : rsx0;
     // byte offsets of this lane's 8 pixels in row 0
     unsigned ybase[MF], xbase[NF], ebase[NF];
     bool evalid;
     {
       // edge pixel of this lane: lane group 0 fetches the pixel right of the strip (x0 + 32), lane group 3 the one left of it
       const int ex = g == 0 ? x0 + 32 : x0 - 1;
-      evalid = (g == 0 || g == 3) && ex >= 0 && ex < a.W;
+      evalid = !a.twin && (g == 0 || g == 3) && ex >= 0 && ex < a.W;
+      const unsigned col = a.twin ? 8u * (g & 1) : (unsigned)(x0 + 8 * g);      // this lane's first pixel in its row
+      const unsigned img = a.twin ? (unsigned)(g >> 1) : 0u;                      // ... and its image behind the descriptor
+      // (an image of the odd batch's missing twin lies beyond num_records: its lanes read zeros)
 #pragma unroll
-      for (int m = 0; m < MF; ++m) ybase[m] = ((unsigned)(cout0 + 16 * m + c16) * HW + x0 + 8 * g) * 4u;
+      for (int m = 0; m < MF; ++m) ybase[m] = ((unsigned)(cout0 + 16 * m + c16) * HW + col + img * (unsigned)a.Cout * HW) * 4u;
 #pragma unroll
       for (int n = 0; n < NF; ++n) {
-        xbase[n] = ((unsigned)xch[n] * HW + x0 + 8 * g) * 4u;
+        xbase[n] = ((unsigned)xch[n] * HW + col + img * (unsigned)(xfirst[n] ? a.C0 : a.C1) * HW) * 4u;
         ebase[n] = evalid ? ((unsigned)xch[n] * HW + ex) * 4u : BUF_OOB;
       }
     }
@@ -222,7 +233,7 @@ __global__ __launch_bounds__((64 * WgradRGeom<MF, NF>::NW), 1) void wgrad_r_k(Wg
       const unsigned yo = yv ? (unsigned)y * W4 : 0u, ym = yv ? 0u : BUF_OOB;
       if (AFF) {
 #pragma unroll
-        for (int m = 0; m < MF; ++m) ak3v[S][m] = yv ? ak3[m] : 0.f;
+        for (int m = 0; m < MF; ++m) ak3v[S][m] = (yv && lane_live) ? ak3[m] : 0.f;
       }
 #pragma unroll
       for (int m = 0; m < MF; ++m) {
@@ -301,8 +312,8 @@ __global__ __launch_bounds__((64 * WgradRGeom<MF, NF>::NW), 1) void wgrad_r_k(Wg
           const u32x4v d = xb[XS][n][t];
           // pixel 8 of this lane's group = pixel 0 of the next group (lane + 16); for the last group the strip's right edge,
           // which lane group 0 holds.  Pixel -1 = pixel 7 of the previous group (lane - 16); for group 0 the left edge (group 3).
-          const unsigned sup_r = g == 0 ? eq[XS][n][t] : d[0];
-          const unsigned sup_l = g == 3 ? (eq[XS][n][t] << 16) : d[3];
+          const unsigned sup_r = (g == 0 ? eq[XS][n][t] : d[0]) & seam_r;
+          const unsigned sup_l = (g == 3 ? (eq[XS][n][t] << 16) : d[3]) & seam_l;
           const unsigned nb_r = (unsigned)__builtin_amdgcn_ds_bpermute(src_up * 4, (int)sup_r);
           const unsigned nb_l = (unsigned)__builtin_amdgcn_ds_bpermute(src_dn * 4, (int)sup_l);
           xs[1][t] = d;
@@ -442,13 +453,18 @@ struct WgradRPlan {
   int mf, nf, nw, pairs, nci, wpp, nseg, rseg, units, strips;
 };
 
+// W == 16 (the deepest level's maps): two images side by side per 32-pixel k-step (WgradRArgs::twin).  WTPSE_WGRAD_R_TWIN=0: those
+// layers stay on the LDS kernel (conv_wgrad_x3_k).
+static const bool g_wgrad_r_twin = [] { const char* e = getenv("WTPSE_WGRAD_R_TWIN"); return !(e && e[0] == '0'); }();
+static bool wgrad_r_width_ok(int W) { return W % 32 == 0 || (W == 16 && g_wgrad_r_twin); }
+
 static bool wgrad_r_plan(int B, int H, int W, int Cin, int Cout, WgradRPlan& p) {
-  if (W % 32 != 0 || H < 1 || Cin % 16 != 0 || Cout % 16 != 0) return false;
+  if (!wgrad_r_width_ok(W) || H < 1 || Cin % 16 != 0 || Cout % 16 != 0) return false;
   p.mf = Cout % 32 == 0 ? 2 : 1;
   p.nf = Cin % 32 == 0 ? 2 : 1;
   p.nci = Cin / (16 * p.nf);
   p.pairs = (Cout / (16 * p.mf)) * p.nci;
-  p.strips = W / 32;
+  p.strips = W == 16 ? 1 : W / 32;
   // waves: one per SIMD for the blocks of two or four fragments (more than 256 registers), two per SIMD for the 16 x 16 blocks
   p.nw = (p.mf * p.nf >= 2) ? 4 : 8;
   // tuning override, read once per process (the slab count the host sizes its scratch with must agree with the launch)
@@ -457,7 +473,7 @@ static bool wgrad_r_plan(int B, int H, int W, int Cin, int Cout, WgradRPlan& p) 
   if (target_override >= 64 && p.mf * p.nf >= 2) target = target_override;
   int wpp = (target / p.pairs) / p.nw * p.nw;
   if (wpp < p.nw) wpp = p.nw;
-  const int cols = B * p.strips;                          // (image, strip) columns of H rows
+  const int cols = (W == 16 ? (B + 1) / 2 : B) * p.strips;    // (image [pair], strip) columns of H rows
   int nseg = 1;
   if (cols < wpp) nseg = ceil_div(wpp, cols);
   if (nseg > H) nseg = H;
@@ -470,7 +486,7 @@ static bool wgrad_r_plan(int B, int H, int W, int Cin, int Cout, WgradRPlan& p) 
 }
 
 extern "C" int wtpse_wgrad_r_supported(int Cin, int Cout, int ksize, int C0, int W) {
-  return ksize == 3 && Cin % 16 == 0 && Cout % 16 == 0 && C0 % 16 == 0 && W % 32 == 0;
+  return ksize == 3 && Cin % 16 == 0 && Cout % 16 == 0 && C0 % 16 == 0 && wgrad_r_width_ok(W);
 }
 
 // slabs of a wtpse_conv_wgrad_r launch: `slab` holds that many [Cout][Cin][9] partial gradients, `dbias_slab` as many [Cout]
@@ -504,7 +520,7 @@ static int wgrad_r_impl(const float* dy, const float* x0, int C0, const float* x
   a.dy = dy; a.x0 = x0; a.x1 = x1; a.pro0 = pro0; a.pro1 = pro1; a.slab = slab; a.slab_b = dbias_slab;
   a.bn_y = bn_y; a.bn_coef = bn_coef;
   a.B = B; a.H = H; a.W = W; a.C0 = C0; a.C1 = C1; a.Cin = Cin; a.Cout = Cout; a.pro_relu = pro_relu;
-  a.strips = p.strips; a.nseg = p.nseg; a.rseg = p.rseg; a.units = p.units; a.wpp = p.wpp; a.nci = p.nci;
+  a.strips = p.strips; a.nseg = p.nseg; a.rseg = p.rseg; a.units = p.units; a.wpp = p.wpp; a.nci = p.nci; a.twin = W == 16 ? 1 : 0;
   const bool pro = pro0 != nullptr || pro1 != nullptr || pro_relu != 0;
   const bool bias = dbias != nullptr, aff = bn_y != nullptr;
   dim3 grid((unsigned)(p.pairs * (p.wpp / p.nw)));

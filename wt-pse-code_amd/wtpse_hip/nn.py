@@ -628,7 +628,7 @@ def _wgrad(layer, dy, a0, a1=None, with_bias=True):
     a1 = as_act(a1) if a1 is not None else None
     dw = root.gview(layer.weight)
     db = root.gview(layer.bias) if with_bias else None
-    # 3x3 layers on maps that are a multiple of 32 pixels wide: the x3 weight gradient with register-resident operands
+    # 3x3 layers on maps that are a multiple of 32 pixels (or exactly 16) wide: the x3 weight gradient with register-resident operands
     # (csrc/wgrad_r.hip; bias gradient only in its 16 x 16-channel form: the DeepWT layers)
     if (X3 and X3_WGRAD and WGRAD_R and layer.k == 3 and
             ops.wgrad_r_supported(layer.cin, layer.cout, 3, a0.t.shape[1] if a1 is not None else 16, a0.t.shape[3]) and
