@@ -56,20 +56,6 @@ int wtpse_conv_fwd_gram(const float* in0, int C0, const float* wpacked, const fl
  * conv and direction ceil16(K) * ceil32(rows) * taps * 3 unsigned shorts (forward: rows = Cout, K = Cin; data gradient:
  * rows = Cin, K = Cout), layout [K chunk 16][row block 32][tap][term 3][k half 2][row 32][8 k]. */
 int wtpse_conv_x3_stats_blocks(int B, int H, int W, int Cout, int ksize);   /* rows of `stats` for wtpse_conv_fwd_x3 (the tiling depends on the kernel size) */
-/* 3x3 data gradients whose operand dY is the UN-APPLIED second half of a BatchNorm backward: dY = k1[c] * g + k2[c] * in_y + k3[c] formed
- * on load by conv_x3r_k (in_coef [C][3] = (k1, k2, k3) as wtpse_dgrad_bnb_coef leaves it; g, in_y [B][C][H][W]; bitwise the values
- * wtpse_bn_bwd_apply_coef would have written), so that pass never runs for the layer — its weight gradient takes the same triple
- * (wtpse_conv_wgrad_r_bn).  Only where wtpse_x3_bnin_supported(B, H, W, Cout, 3) (64-row blocks of conv_x3r_k: Cout % 64 == 0 and
- * enough tiles).  _in: plain / split outputs as wtpse_conv_fwd_x3; _in_bnb_coef: with the BatchNorm-backward epilogue and coefficient
- * fold of the layer the gradient flows into, arguments as wtpse_dgrad_bnb_coef (layout 1). */
-int wtpse_x3_bnin_supported(int B, int H, int W, int Cout, int ksize);
-int wtpse_dgrad_x3_in(const float* g, const float* in_y, const float* in_coef, int C, const unsigned short* wpacked, float* out0,
-                      float* out1, int Csplit, int B, int H, int W, int Cout, void* stream);
-int wtpse_dgrad_x3_in_bnb_coef(const float* g, const float* in_y, const float* in_coef, int C, const unsigned short* wpacked,
-                               float* out0, float* out1, int Csplit, const float* bn_y, const float* bn_ss, const float* bn_mean,
-                               int bn_relu, int bn_c0, int bn_c1, float* stats, const float* gamma, const float* invstd, float* coef,
-                               float* dgamma, float* dbeta, int accumulate, double* partial2, unsigned* tickets, int B, int H, int W,
-                               int Cout, void* stream);
 /* Which 3x3 launches of the x3 entry points run conv_x3r_k (weights fed from registers, input tile double-buffered in LDS) instead
  * of conv_x3_k (weights staged through LDS): on = 1 (default) the launches with 64-channel output blocks, 2 all of them, 0 none;
  * on < 0 only queries (environment: WTPSE_X3R=0|1|2).  Returns the previous setting.  The two kernels give bitwise the same

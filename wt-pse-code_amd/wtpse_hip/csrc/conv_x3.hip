@@ -42,11 +42,6 @@ struct ConvX3Args {
   const float* bias;
   const float* pro0;
   const float* pro1;
-  // BNIN (conv_x3r_k): in0 is not the tensor to convolve but g, the masked gradient a BatchNorm-backward epilogue left; the operand is
-  // dy = k1[c] * g + k2[c] * in_y + k3[c] (in_coef [C0][3] = (k1, k2, k3), in_y [B][C0][H][W]) formed on load — the expression of
-  // bn_bwd_apply_k (bn.hip), the same bits — so the apply pass and its 3 HBM passes never run.  Single input, no prologue.
-  const float* in_y;
-  const float* in_coef;
   float* out0;
   float* out1;
   float* stats;
@@ -666,7 +661,7 @@ __device__ int g_x3r_stagger = 0;
 // ABL (tools/probe/x3r_abl.py only; 0 in the library): pieces of the main loop left out, to price them — 1 conversion VALU, 2 LDS
 // stores, 4 weight-fragment loads, 8 input-fragment reads, 16 the chunk barrier, 32 the input tile's global loads.  Results are
 // garbage with any bit set.
-template <int WM, int MT, int NT, int TWL, int EPI, int ABL = 0, bool BNIN = false>
+template <int WM, int MT, int NT, int TWL, int EPI, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void conv_x3r_k(ConvX3Args a) {
   constexpr int KS = 3, TAPS = 9, PAD = 1;
   constexpr int PW = 4 / WM;                       // waves along the pixels
@@ -683,8 +678,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3r_k(ConvX3Args a) {
   static_assert(MAIN_U4 * 4 >= PW * CB * 2 + 4 * CB + 4, "epilogue scratch aliases the operand images");
   constexpr int DUMP_U4 = MAIN_U4 + CB / 4 + (EPI == 2 ? CB : 0);
   __shared__ u32x4v smem[DUMP_U4 + 64];
-  __shared__ float2 pro_s[PRO_MAX];                // BNIN: (k1, k3)
-  __shared__ float pro2_s[BNIN ? PRO_MAX : 1];     // BNIN: k2
+  __shared__ float2 pro_s[PRO_MAX];
   u32x4v* Xs = smem;
   float* bias_s = reinterpret_cast<float*>(smem + MAIN_U4);
 
@@ -721,10 +715,6 @@ __global__ __launch_bounds__(256, 2) void conv_x3r_k(ConvX3Args a) {
     const float* pro = first ? a.pro0 : a.pro1;
     const int cl = first ? c : c - a.C0;
     const bool live = c < a.C0 + a.C1;
-    if constexpr (BNIN) {
-      pro_s[c] = live ? make_float2(a.in_coef[3 * c], a.in_coef[3 * c + 2]) : make_float2(0.f, 0.f);
-      pro2_s[c] = live ? a.in_coef[3 * c + 1] : 0.f;
-    } else
     pro_s[c] = !live ? make_float2(0.f, 0.f) : (pro ? make_float2(pro[2 * cl], pro[2 * cl + 1]) : make_float2(1.f, 0.f));
   }
 
@@ -768,10 +758,8 @@ __global__ __launch_bounds__(256, 2) void conv_x3r_k(ConvX3Args a) {
   const int cb32 = cout0 / 32 + cw * MT;
 
   float xv[NIT][8];
-  float yv[BNIN ? NIT : 1][8];                     // BNIN: the layer's raw conv output at the same positions
   const float* const xb0 = a.in0 + (size_t)b * a.C0 * HW;
   const float* const xb1 = a.in1 ? a.in1 + (size_t)b * a.C1 * HW : xb0;
-  const float* const yb0 = BNIN ? a.in_y + (size_t)b * a.C0 * HW : xb0;
   auto issue_x = [&](int c0) __attribute__((always_inline)) {
     const bool first = c0 < a.C0;
     // (a select between two ready-made descriptors came out as a VECTOR value here — every load then sat in a readfirstlane
@@ -787,17 +775,6 @@ __global__ __launch_bounds__(256, 2) void conv_x3r_k(ConvX3Args a) {
 #pragma unroll
       for (int i = 0; i < NIT; ++i) xv[i][j] = buf_load(rs, voff[i], soff);
     }
-    if constexpr (BNIN) {
-      const unsigned long long py = (unsigned long long)yb0;
-      const unsigned ylo = __builtin_amdgcn_readfirstlane((unsigned)py), yhi = __builtin_amdgcn_readfirstlane((unsigned)(py >> 32));
-      const __amdgpu_buffer_rsrc_t ry = make_rsrc((const void*)(((unsigned long long)yhi << 32) | ylo), (unsigned)cn * HW * 4u);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const unsigned soff = (unsigned)min(cbase + j, cn) * (unsigned)HW * 4u;
-#pragma unroll
-        for (int i = 0; i < NIT; ++i) yv[i][j] = buf_load(ry, voff[i], soff);
-      }
-    }
   };
   // one item = 8 channels of one halo position: prologue (affine, ReLU; zero padding AFTER it), split, three 16-byte LDS stores
   u32x4v tq[3];
@@ -806,15 +783,10 @@ __global__ __launch_bounds__(256, 2) void conv_x3r_k(ConvX3Args a) {
     const bool relu = (c0 < a.C0) ? (a.pro_relu & 1) : (a.pro_relu & 2);
     const int cg = min(c0 + ihalf[i] * 8 + 2 * j, PRO_MAX - 2);
     const float2 p0 = pro_s[cg], p1 = pro_s[cg + 1];
-    if constexpr (BNIN) {        // dy = fmaf(k1, g, fmaf(k2, y, k3)): bn_bwd_apply_k's expression
-      v0 = fmaf(p0.x, v0, fmaf(pro2_s[cg], yv[i][2 * j], p0.y));
-      v1 = fmaf(p1.x, v1, fmaf(pro2_s[cg + 1], yv[i][2 * j + 1], p1.y));
-    } else {
-      v0 = fmaf(v0, p0.x, p0.y);
-      v1 = fmaf(v1, p1.x, p1.y);
-      v0 = relu ? fmaxf(v0, 0.f) : v0;
-      v1 = relu ? fmaxf(v1, 0.f) : v1;
-    }
+    v0 = fmaf(v0, p0.x, p0.y);
+    v1 = fmaf(v1, p1.x, p1.y);
+    v0 = relu ? fmaxf(v0, 0.f) : v0;
+    v1 = relu ? fmaxf(v1, 0.f) : v1;
     v0 = iin[i] ? v0 : 0.f;
     v1 = iin[i] ? v1 : 0.f;
     unsigned q0, q1, q2;
@@ -1058,19 +1030,7 @@ static int launch_x3(const ConvX3Args& a, hipStream_t st, bool half = false) {
   // gradients), 2 = everywhere (32-channel blocks run 8-20 % SLOWER on it: half the MFMAs per converted input element), 0 = nowhere
   if (KS == 3 && TERMS == 3 && (g_x3r == 2 || (g_x3r == 1 && MT == 2))) {
     if constexpr (KS == 3 && TERMS == 3) {
-      if (args.in_y) {            // BNIN: the 64-channel blocks of conv_x3r_k only (wtpse_x3_bnin_supported); data gradients: EPI 0 / 2
-        if constexpr (MT == 2 && EPI != 1) {
-          if (half) {
-            if (narrow) hipLaunchKernelGGL((conv_x3r_k<2, 1, 2, 4, EPI, 0, true>), grid, dim3(256), 0, st, args);
-            else hipLaunchKernelGGL((conv_x3r_k<2, 1, 2, 5, EPI, 0, true>), grid, dim3(256), 0, st, args);
-          } else {
-            if (narrow) hipLaunchKernelGGL((conv_x3r_k<2, 1, 4, 4, EPI, 0, true>), grid, dim3(256), 0, st, args);
-            else hipLaunchKernelGGL((conv_x3r_k<2, 1, 4, 5, EPI, 0, true>), grid, dim3(256), 0, st, args);
-          }
-        } else {
-          return WTPSE_EINVAL;
-        }
-      } else if (half) {
+      if (half) {
         if constexpr (MT == 2) {
           if (narrow) hipLaunchKernelGGL((conv_x3r_k<2, 1, 2, 4, EPI>), grid, dim3(256), 0, st, args);
           else hipLaunchKernelGGL((conv_x3r_k<2, 1, 2, 5, EPI>), grid, dim3(256), 0, st, args);
@@ -1135,14 +1095,6 @@ static bool x3_half(int B, int H, int W, int CoutP, int ksize) {
   return B * ceil_div(W, TW) * ceil_div(H, TH) * (CoutP / 64) >= g_x3_half_min;
 }
 
-// Can a 3x3 launch with `Cout` output rows (a data gradient: the layer's input channels) form its operand from (g, y, coef) on load
-// (ConvX3Args::in_y)?  Only conv_x3r_k's 64-channel blocks carry that loader: full or half tiling, x3 arithmetic.
-extern "C" int wtpse_x3_bnin_supported(int B, int H, int W, int Cout, int ksize) {
-  const int CoutP = (Cout + 31) & ~31;
-  if (ksize != 3 || g_x3r == 0 || g_x3_terms != 3 || CoutP % 64 != 0) return 0;
-  return (x3_mt2(B, H, W, CoutP) || x3_half(B, H, W, CoutP, 3)) ? 1 : 0;
-}
-
 // workgroups along x of a wtpse_conv_fwd_x3 launch = rows of its `stats` partials
 extern "C" int wtpse_conv_x3_stats_blocks(int B, int H, int W, int Cout, int ksize) {
   const int CoutP = (Cout + 31) & ~31;
@@ -1155,12 +1107,8 @@ static int conv_x3_impl(const float* in0, int C0, const float* in1, int C1, cons
                         const float* bias, const float* pro0, const float* pro1, int pro_relu, float* out0, float* out1,
                         int Csplit, float* stats, int B, int H, int W, int Cout, int ksize, int relu_out,
                         const float* mask_ref, const float* bn_ss, const float* bn_mean, int bn_relu, int bn_c0, int bn_c1,
-                        void* stream, BnbTail tail = bnb_tail_none(), BnfTail ftail = bnf_tail_none(), const float* in_y = nullptr,
-                        const float* in_coef = nullptr) {
+                        void* stream, BnbTail tail = bnb_tail_none(), BnfTail ftail = bnf_tail_none()) {
   WTPSE_REQUIRE(in0 && wpacked && out0 && B > 0 && H > 0 && W > 0 && C0 > 0 && C1 >= 0 && Cout > 0);
-  WTPSE_REQUIRE((in_y == nullptr) == (in_coef == nullptr));
-  WTPSE_REQUIRE(!in_y || (C1 == 0 && !pro0 && !pro_relu && !bias && !relu_out && (bn_mean || !mask_ref) &&
-                          wtpse_x3_bnin_supported(B, H, W, Cout, ksize)));
   WTPSE_REQUIRE(ksize == 1 || ksize == 3);
   WTPSE_REQUIRE((C1 == 0) == (in1 == nullptr));
   WTPSE_REQUIRE(Csplit > 0 && Csplit <= Cout && ((Csplit == Cout) == (out1 == nullptr)));
@@ -1175,7 +1123,6 @@ static int conv_x3_impl(const float* in0, int C0, const float* in1, int C1, cons
 
   ConvX3Args a;
   a.in0 = in0; a.in1 = in1; a.wx = wpacked; a.bias = bias; a.pro0 = pro0; a.pro1 = pro1; a.out0 = out0; a.out1 = out1;
-  a.in_y = in_y; a.in_coef = in_coef;
   a.stats = stats; a.mask = mask_ref;
   a.bn_ss = bn_ss; a.bn_mean = bn_mean; a.bn_relu = bn_relu; a.bn_c0 = bnb ? bn_c0 : 0; a.bn_c1 = bnb ? bn_c1 : 0;
   WTPSE_REQUIRE(!tail.tickets || (bnb && tail.partial2 && tail.gamma && tail.invstd && tail.coef && tail.dgamma && tail.dbeta));
@@ -1235,31 +1182,6 @@ extern "C" int wtpse_dgrad_x3_bnb_tail(const float* dy, int C, const unsigned sh
   WTPSE_REQUIRE(bn_y && bn_ss && bn_mean && stats && tail);
   return conv_x3_impl(dy, C, nullptr, 0, wpacked, nullptr, nullptr, nullptr, 0, out0, out1, Csplit, stats, B, H, W, Cout, ksize, 0,
                       bn_y, bn_ss, bn_mean, bn_relu, bn_c0, bn_c1, stream, *tail);
-}
-
-// 3x3 data gradients whose operand dY is the un-applied second half of a BatchNorm backward: dY = k1[c] g + k2[c] in_y + k3[c] formed
-// on load (ConvX3Args::in_y; in_coef [C][3] as a wtpse_dgrad_bnb_coef launch leaves it) — wtpse_bn_bwd_apply_coef never runs for this
-// layer (its weight gradient takes the same triple: wtpse_conv_wgrad_r_bn).  Requires wtpse_x3_bnin_supported(B, H, W, Cout, 3).
-// Plain form (optionally split into two outputs) ...
-extern "C" int wtpse_dgrad_x3_in(const float* g, const float* in_y, const float* in_coef, int C, const unsigned short* wpacked,
-                                 float* out0, float* out1, int Csplit, int B, int H, int W, int Cout, void* stream) {
-  WTPSE_REQUIRE(in_y && in_coef);
-  return conv_x3_impl(g, C, nullptr, 0, wpacked, nullptr, nullptr, nullptr, 0, out0, out1, Csplit, nullptr, B, H, W, Cout, 3, 0, nullptr,
-                      nullptr, nullptr, 0, 0, 0, stream, bnb_tail_none(), bnf_tail_none(), in_y, in_coef);
-}
-// ... and with the BatchNorm-backward epilogue + coefficient fold of the layer the gradient flows into (wtpse_dgrad_bnb_coef, layout 1)
-extern "C" int wtpse_dgrad_x3_in_bnb_coef(const float* g, const float* in_y, const float* in_coef, int C, const unsigned short* wpacked,
-                                          float* out0, float* out1, int Csplit, const float* bn_y, const float* bn_ss,
-                                          const float* bn_mean, int bn_relu, int bn_c0, int bn_c1, float* stats, const float* gamma,
-                                          const float* invstd, float* coef, float* dgamma, float* dbeta, int accumulate,
-                                          double* partial2, unsigned* tickets, int B, int H, int W, int Cout, void* stream) {
-  WTPSE_REQUIRE(in_y && in_coef);
-  WTPSE_REQUIRE(bn_y && bn_ss && bn_mean && stats && gamma && invstd && coef && dgamma && dbeta && partial2 && tickets);
-  BnbTail t = bnb_tail_none();
-  t.partial2 = partial2; t.tickets = tickets; t.gamma = gamma; t.invstd = invstd; t.coef = coef; t.dgamma = dgamma; t.dbeta = dbeta;
-  t.accumulate = accumulate;
-  return conv_x3_impl(g, C, nullptr, 0, wpacked, nullptr, nullptr, nullptr, 0, out0, out1, Csplit, stats, B, H, W, Cout, 3, 0, bn_y, bn_ss,
-                      bn_mean, bn_relu, bn_c0, bn_c1, stream, t, bnf_tail_none(), in_y, in_coef);
 }
 
 // ================================================================================================

@@ -523,7 +523,7 @@ BN_FUSED_STATS = os.environ.get("WTPSE_BN_FUSED_STATS", "1") != "0"
 BN_TAIL = os.environ.get("WTPSE_BN_TAIL", "1") != "0"
 
 
-def _dgrad(layer, dy, split=None, mask_ref=None, below0=None, below1=None, bn_in=None):
+def _dgrad(layer, dy, split=None, mask_ref=None, below0=None, below1=None):
     """Data gradient; mask_ref fuses the ReLU backward of the tensor the gradient flows into (d * [ref > 0]).
     below0 / below1: tape of the conv + BatchNorm layer whose activated output the first / second returned gradient is taken
     with respect to (at most one of them): that gradient comes back as a PreBN."""
@@ -539,15 +539,11 @@ def _dgrad(layer, dy, split=None, mask_ref=None, below0=None, below1=None, bn_in
             layout, wptr = 1, root.x3_ptr(layer.xd_off)
         else:
             layout, wptr = 0, root.packed_ptr(layer.wd_off)
-        assert bn_in is None or layout == 1
         d0, d1, stats, coef = ops.dgrad_bnb(dy, wptr, layout, layer.cin, layer.k, below.y, below.ss, below.mean, below.relu, split,
-                                            below1 is not None and below0 is None, tail, bn_in)
+                                            below1 is not None and below0 is None, tail)
         if below0 is not None:
             return PreBN(d0, stats, coef), d1
         return d0, PreBN(d1, stats, coef)
-    if bn_in is not None:       # (dy is g: the operand is formed on load — _bn_in_x3 checked the path)
-        assert mask_ref is None and layer.xd_off >= 0
-        return ops.dgrad_x3_in(dy, bn_in[0], bn_in[1], root.x3_ptr(layer.xd_off), layer.cin, split)
     if layer.x16d_off >= 0 and split is None:
         return ops.conv16_x3(dy, root.x3_ptr(layer.x16d_off), None, layer.cin, mask_ref=mask_ref)[0], None
     if layer.xd_off >= 0:
@@ -604,19 +600,19 @@ def note_join(root, stream):
         j.append(stream)
 
 
-def _wgrad_side(layer, dy, a0, a1=None, bn_in=None):
+def _wgrad_side(layer, dy, a0, a1=None):
     """_wgrad(..., with_bias=False) on the side stream.  dy must not be written again by the caller (it is a fresh
     BatchNorm-backward result in both callers)."""
     root = layer._root
     if not WGRAD_SIDE_STREAM:
-        return _wgrad(layer, dy, a0, a1, with_bias=False, bn_in=bn_in)
+        return _wgrad(layer, dy, a0, a1, with_bias=False)
     main = torch.cuda.current_stream()
     side = _side_stream(dy.device)
     stream_wait(side, main)
     with torch.cuda.stream(side):
-        _wgrad(layer, dy, a0, a1, with_bias=False, bn_in=bn_in)
+        _wgrad(layer, dy, a0, a1, with_bias=False)
     a0 = as_act(a0)
-    for t in (dy, a0.t, a0.pro) + ((as_act(a1).t, as_act(a1).pro) if a1 is not None else ()) + (tuple(bn_in) if bn_in is not None else ()):
+    for t in (dy, a0.t, a0.pro) + ((as_act(a1).t, as_act(a1).pro) if a1 is not None else ()):
         if t is not None:
             t.record_stream(side)       # the caching allocator must not hand these out again before the side stream is done
     # (Under stream capture the allocator keeps record_stream'ed blocks out of circulation until the capture ends.  Holding the
@@ -626,18 +622,12 @@ def _wgrad_side(layer, dy, a0, a1=None, bn_in=None):
     note_join(root, side)
 
 
-def _wgrad(layer, dy, a0, a1=None, with_bias=True, bn_in=None):
-    """bn_in = (y, coef): dy is g, the weight gradient forms dY = k1 g + k2 y + k3 on load (wgrad_r_k's fused form; _bn_in_x3)."""
+def _wgrad(layer, dy, a0, a1=None, with_bias=True):
     root = layer._root
     a0 = as_act(a0)
     a1 = as_act(a1) if a1 is not None else None
     dw = root.gview(layer.weight)
     db = root.gview(layer.bias) if with_bias else None
-    if bn_in is not None:
-        assert db is None
-        ops.conv_wgrad_r_bn(dy, bn_in[0], bn_in[1], a0.t, a1.t if a1 is not None else None, dw, a0.pro, _relu_bits(a0, a1), False,
-                            a1.pro if a1 is not None else None)
-        return
     # 3x3 layers on maps that are a multiple of 32 pixels (or exactly 16) wide: the x3 weight gradient with register-resident operands
     # (csrc/wgrad_r.hip; bias gradient only in its 16 x 16-channel form: the DeepWT layers)
     if (X3 and X3_WGRAD and WGRAD_R and layer.k == 3 and
@@ -708,38 +698,10 @@ def _bn_bwd(bn, t, dz, root):
     return ops.bn_bwd(dz, t.y, t.ss, t.relu, bn.weight, t.mean, t.invstd, root.gview(bn.weight), root.gview(bn.bias))
 
 
-# ... and, OPT-IN (WTPSE_BN_IN_X3=1), by BOTH consumers of a conv + BatchNorm layer's dy where the data gradient runs conv_x3r_k's 64-row
-# blocks and the weight gradient wgrad_r_k: bitwise the same gradients (tests/test_bn_in_gpu.py) and measured SLOWER — the step without
-# these apply passes would run 2.6 % faster, but conv_x3r_k's second loader costs 8-29 us per launch (its conversion pieces sit between
-# the MFMA groups and are not free) where the apply pass costs 9-70 us, and the fused weight gradient 3-26 us more: 565 vs 583 images/s
-# with it everywhere, 580 vs 583 on the 128x128 / 256x256 maps only (tools/probe/bnin_time.py).  Off by default.
-BN_IN_X3 = BN_IN and os.environ.get("WTPSE_BN_IN_X3", "0") == "1"
-BN_IN_X3_MIN_HW = int(os.environ.get("WTPSE_BN_IN_X3_MIN_HW", "0"))     # only on maps of at least that many pixels
-
-
-def _bn_in_x3(conv, t, dz, need_dx, below0, below1):
-    if not (BN_IN_X3 and need_dx and isinstance(dz, PreBN) and dz.coef is not None and conv.k == 3 and conv.xd_off >= 0):
-        return False
-    if not (BN_TAIL or (below0 is None and below1 is None)):
-        return False
-    B, _, H, W = dz.g.shape
-    if H * W < BN_IN_X3_MIN_HW:
-        return False
-    c0 = t.a0.t.shape[1] if t.a1 is not None else 16
-    return (X3 and X3_WGRAD and WGRAD_R and ops.wgrad_r_supported(conv.cin, conv.cout, 3, c0, W)
-            and ops.x3_bnin_supported(B, H, W, conv.cin))
-
-
 def convbn_bwd(conv, bn, t, dz, need_dx=True, below0=None, below1=None):
     """dz: gradient wrt the activated output (plain or PreBN).  -> (dx0, dx1): gradients wrt the inputs AS LOADED (activated);
     below0 / below1: see _dgrad."""
     root = conv._root
-    if _bn_in_x3(conv, t, dz, need_dx, below0, below1):
-        # both consumers form dy = k1 g + k2 y + k3 as they load: the weight gradient (wgrad_r_k's fused form, on its side stream) and
-        # the data gradient (conv_x3r_k's second loader) — no apply pass, dy is never written
-        _wgrad_side(conv, dz.g, t.a0, t.a1, bn_in=(t.y, dz.coef))
-        split = t.a0.t.shape[1] if t.a1 is not None else None
-        return _dgrad(conv, dz.g, split, below0=below0, below1=below1, bn_in=(t.y, dz.coef))
     dy = _bn_bwd(bn, t, dz, root)
     # the conv bias in front of a train-mode BatchNorm has an exactly-zero gradient (sum of dy over the batch
     # vanishes); the reference carries rounding noise there (SURVEY.md Appendix A). It is left at 0.

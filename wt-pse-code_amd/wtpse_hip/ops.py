@@ -159,31 +159,7 @@ def _tickets(n, device):
     return st[0].data_ptr() + 4 * off
 
 
-def x3_bnin_supported(B, H, W, rows, ksize=3):
-    """Can the 3x3 x3 data gradient with `rows` output channels form dY = k1 g + k2 y + k3 on load (wtpse_dgrad_x3_in*)?"""
-    return bool(lib().query("wtpse_x3_bnin_supported", int(B), int(H), int(W), int(rows), int(ksize)))
-
-
-def dgrad_x3_in(g, in_y, in_coef, wpacked_ptr, cout, split=None):
-    """3x3 x3 data gradient of dY = in_coef[:,0] * g + in_coef[:,1] * in_y + in_coef[:,2], formed on load (no apply pass).
-    -> (out0, out1 or None)."""
-    _chk(g, "g"); _chk(in_y, "in_y"); _chk(in_coef, "in_coef")
-    B, C, H, W = g.shape
-    assert in_y.shape == g.shape and in_coef.shape == (C, 3), (g.shape, in_y.shape, in_coef.shape)
-    if split is None:
-        csplit = cout
-        out0 = torch.empty((B, cout, H, W), dtype=torch.float32, device=g.device)
-        out1 = None
-    else:
-        csplit = int(split)
-        out0 = torch.empty((B, csplit, H, W), dtype=torch.float32, device=g.device)
-        out1 = torch.empty((B, cout - csplit, H, W), dtype=torch.float32, device=g.device)
-    lib().call("wtpse_dgrad_x3_in", ptr(g), ptr(in_y), ptr(in_coef), C, wpacked_ptr, ptr(out0), ptr(out1), csplit, B, H, W, cout,
-               stream_ptr())
-    return out0, out1
-
-
-def dgrad_bnb(dy, wpacked_ptr, layout, cout, ksize, bn_y, bn_ss, bn_mean, bn_relu, split=None, bn_second=False, tail=None, bn_in=None):
+def dgrad_bnb(dy, wpacked_ptr, layout, cout, ksize, bn_y, bn_ss, bn_mean, bn_relu, split=None, bn_second=False, tail=None):
     """Data gradient (`wpacked_ptr`: the layer's data-gradient weights; layout 0 fp32, 1 x3, 2 the 16-channel x3 fragments) whose
     epilogue masks the result with the ReLU of the conv + BatchNorm layer it flows into and forms that layer's BatchNorm-backward
     reductions (include/wtpse_hip.h, wtpse_dgrad_bnb).  With a split the BatchNorm'd tensor is out0, or out1 if `bn_second`.
@@ -211,19 +187,10 @@ def dgrad_bnb(dy, wpacked_ptr, layout, cout, ksize, bn_y, bn_ss, bn_mean, bn_rel
         coef = torch.empty((c1 - c0, 3), dtype=torch.float32, device=dy.device)
         partial2 = torch.empty(L.query("wtpse_bnb_tail_partial2", nblk, cout), dtype=torch.float64, device=dy.device)
         tickets = _tickets(L.query("wtpse_bnb_tail_tickets", nblk, cout), dy.device)
-        if bn_in is not None:       # dy is g; (in_y, in_coef): the operand is formed on load
-            in_y, in_coef = bn_in
-            _chk(in_y, "in_y"); _chk(in_coef, "in_coef")
-            assert layout == 1 and ksize == 3 and in_y.shape == dy.shape and in_coef.shape == (C, 3)
-            L.call("wtpse_dgrad_x3_in_bnb_coef", ptr(dy), ptr(in_y), ptr(in_coef), C, wpacked_ptr, ptr(out0), ptr(out1), csplit,
-                   ptr(bn_y), ptr(bn_ss), ptr(bn_mean), int(bool(bn_relu)), c0, c1, ptr(stats), ptr(gamma), ptr(invstd), ptr(coef),
-                   ptr(dgamma), ptr(dbeta), 0, ptr(partial2), tickets, B, H, W, cout, stream_ptr())
-            return out0, out1, stats, coef
         L.call("wtpse_dgrad_bnb_coef", ptr(dy), C, wpacked_ptr, layout, ptr(out0), ptr(out1), csplit, ptr(bn_y), ptr(bn_ss),
                ptr(bn_mean), int(bool(bn_relu)), c0, c1, ptr(stats), ptr(gamma), ptr(invstd), ptr(coef), ptr(dgamma), ptr(dbeta), 0,
                ptr(partial2), tickets, B, H, W, cout, ksize, stream_ptr())
         return out0, out1, stats, coef
-    assert bn_in is None, "bn_in needs the coefficient tail"
     if layout == 2:
         L.call("wtpse_conv16_x3", ptr(dy), C, wpacked_ptr, 0, 0, 0, ptr(out0), ptr(stats), 0, ptr(bn_y), ptr(bn_ss), ptr(bn_mean),
                int(bool(bn_relu)), B, H, W, cout, 0, stream_ptr())
