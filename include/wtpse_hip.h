@@ -154,8 +154,8 @@ int wtpse_conv_wgrad_x3(const float* dy, const float* x0, int C0, const float* x
 /* The 3x3 weight gradient in the x3 arithmetic with register-resident operands (csrc/wgrad_r.hip: every lane loads its own
  * 8-pixel fragments from global memory, splits them into bf16 triples and feeds v_mfma_f32_16x16x32_bf16 from registers; the
  * horizontal taps are lane shifts, the vertical ones a 3-row ring of registers; no LDS in the main loop).  Maps whose width is a
- * multiple of 32 — or exactly 16 wide (two images side by side per 32-pixel step) —, Cin / Cout multiples of 16 (C0 % 16 == 0 for a
- * concat): wtpse_wgrad_r_supported().  With bias gradient
+ * multiple of 32, Cin / Cout multiples of 16 (C0 % 16 == 0 for a concat) — or exactly 16 wide with Cin / Cout multiples of 32 (two images
+ * side by side per 32-pixel step; no bias gradient, not the _bn form) —: wtpse_wgrad_r_supported().  With bias gradient
  * (dbias / dbias_slab NULL: skip).  slab: [nslab][Cout*Cin*9], dbias_slab: [nslab][Cout], nslab = wtpse_wgrad_r_slabs(...). */
 int wtpse_wgrad_r_supported(int Cin, int Cout, int ksize, int C0, int W);
 int wtpse_wgrad_r_slabs(int B, int H, int W, int Cin, int Cout);

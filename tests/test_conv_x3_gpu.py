@@ -163,7 +163,7 @@ def test_conv_x3_wgrad(case):
     (40, 16, 0, 16, 64, 64, True),    # row segments (more waves than columns) and several units per wave
     (4, 32, 0, 32, 16, 16, False),    # W = 16: two images side by side per 32-pixel step
     (5, 64, 64, 128, 16, 16, False),  # ... an odd batch (the last pair is a single image), concat
-    (3, 16, 0, 16, 7, 16, True),      # ... 16 x 16 blocks with bias, odd height and batch
+    (3, 32, 0, 64, 7, 16, False),     # ... odd height and batch
     (32, 128, 0, 256, 16, 16, False), # ... down4.conv1 at the benchmark's batch
 ])
 def test_conv_wgrad_r(case):
@@ -200,17 +200,18 @@ def test_conv_wgrad_r(case):
     assert e3 <= 2.0 * e32 + 2e-8, (e3, e32)
     o.conv_wgrad_r(*args, dw, db, accumulate=True, **kw)
     close(dw, 2 * ref64, rtol=2e-4, atol=4e-5 * max(scale, 1.0), what="wgrad r accumulate")
-    # dY as the un-applied second half of a BatchNorm backward: dY = k1 * g + k2 * y + k3 formed on load
-    gg, yy = rnd(B, Co, H, W, seed=17), rnd(B, Co, H, W, seed=18)
-    coef = torch.stack([rnd(Co, seed=19) * 0.3 + 1.0, rnd(Co, seed=20) * 0.2, rnd(Co, seed=21) * 0.1], 1).contiguous()
-    dyl = coef[:, 0].view(1, -1, 1, 1) * gg + coef[:, 1].view(1, -1, 1, 1) * yy + coef[:, 2].view(1, -1, 1, 1)
-    w.grad = None
-    F.conv2d(act.double(), w.double(), None, padding=1).backward(dyl.double())
-    o.conv_wgrad_r_bn(gg.to(DEV), yy.to(DEV), coef.to(DEV), args[1], args[2], dw, **kw)
-    close(dw, w.grad.double(), rtol=2e-4, atol=2e-5 * max(float(w.grad.abs().max()), 1.0), what="wgrad r, BatchNorm-apply on load")
-    dwp = torch.empty_like(dw)
-    o.conv_wgrad_r(dyl.to(DEV), args[1], args[2], dwp, None, **kw)
-    close(dw, dwp, rtol=2e-5, atol=2e-6 * max(float(w.grad.abs().max()), 1.0), what="fused vs materialised dY")
+    if W != 16:      # (the two-images-per-step form of the 16-wide maps takes a materialised dY only)
+        # dY as the un-applied second half of a BatchNorm backward: dY = k1 * g + k2 * y + k3 formed on load
+        gg, yy = rnd(B, Co, H, W, seed=17), rnd(B, Co, H, W, seed=18)
+        coef = torch.stack([rnd(Co, seed=19) * 0.3 + 1.0, rnd(Co, seed=20) * 0.2, rnd(Co, seed=21) * 0.1], 1).contiguous()
+        dyl = coef[:, 0].view(1, -1, 1, 1) * gg + coef[:, 1].view(1, -1, 1, 1) * yy + coef[:, 2].view(1, -1, 1, 1)
+        w.grad = None
+        F.conv2d(act.double(), w.double(), None, padding=1).backward(dyl.double())
+        o.conv_wgrad_r_bn(gg.to(DEV), yy.to(DEV), coef.to(DEV), args[1], args[2], dw, **kw)
+        close(dw, w.grad.double(), rtol=2e-4, atol=2e-5 * max(float(w.grad.abs().max()), 1.0), what="wgrad r, BatchNorm-apply on load")
+        dwp = torch.empty_like(dw)
+        o.conv_wgrad_r(dyl.to(DEV), args[1], args[2], dwp, None, **kw)
+        close(dw, dwp, rtol=2e-5, atol=2e-6 * max(float(w.grad.abs().max()), 1.0), what="fused vs materialised dY")
     # without a prologue (a dense input), no bias
     F.conv2d(xin.double(), w.double(), None, padding=1)
     w.grad = None

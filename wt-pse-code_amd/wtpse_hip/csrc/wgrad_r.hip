@@ -95,7 +95,9 @@ __device__ __forceinline__ f32x4 mfma16x32(u32x4v a, u32x4v b, f32x4 c) {
 template <int MF, int NF> struct WgradRGeom { static constexpr int NW = (MF * NF >= 2) ? 4 : 8; };
 
 // TERMS: bf16 terms per fp32 operand — 3 (x3 arithmetic, six products per multiply) or 1 (bf16 mode: wtpse_x3_terms, conv_x3.hip)
-template <int MF, int NF, bool PRO, bool BIAS, bool AFF = false, int TERMS = 3>
+// TWIN: W == 16, two images per 32-pixel step (WgradRArgs::twin) — a template flag: the seam masks and per-lane image offsets cost the
+// row step ~10 % when they were run-time selects in every instantiation (the step is bound by its vector-instruction count)
+template <int MF, int NF, bool PRO, bool BIAS, bool AFF = false, int TERMS = 3, bool TWIN = false>
 __global__ __launch_bounds__((64 * WgradRGeom<MF, NF>::NW), 1) void wgrad_r_k(WgradRArgs a) {
   static_assert(TERMS == 3 || TERMS == 1, "three bf16 terms or one");
   constexpr int NT = 9, NW = WgradRGeom<MF, NF>::NW;
@@ -160,16 +162,16 @@ __global__ __launch_bounds__((64 * WgradRGeom<MF, NF>::NW), 1) void wgrad_r_k(Wg
   }
   const int src_up = (lane + 16) & 63, src_dn = (lane - 16) & 63;
   // twin: nothing crosses the seam between the two images — lane group 2 hands no pixel 0 down to group 1, group 1 no pixel 7 up to group 2
-  const unsigned seam_r = (a.twin && g == 2) ? 0u : ~0u, seam_l = (a.twin && g == 1) ? 0u : ~0u;
+  const unsigned seam_r = (TWIN && g == 2) ? 0u : ~0u, seam_l = (TWIN && g == 1) ? 0u : ~0u;
 
   for (int u = u0; u < u1; ++u) {
     // unit -> (image, row segment, 32-pixel strip), strips fastest: the four waves of a workgroup then walk down four adjacent
     // strips in step, i.e. read 512 contiguous bytes of every channel row between them (DRAM pages, L2 lines)
     const int strip = u % a.strips;
     const int bs = u / a.strips;
-    const int seg = bs % a.nseg, b = (bs / a.nseg) << a.twin;
-    const unsigned nimg = (a.twin && b + 1 < a.B) ? 2u : 1u;      // images behind the descriptors (an odd batch ends on a single one)
-    const bool lane_live = (unsigned)(a.twin ? g >> 1 : 0) < nimg;     // false: this lane's image is the odd batch's missing twin
+    const int seg = bs % a.nseg, b = (bs / a.nseg) << (TWIN ? 1 : 0);
+    const unsigned nimg = (TWIN && b + 1 < a.B) ? 2u : 1u;      // images behind the descriptors (an odd batch ends on a single one)
+    const bool lane_live = (unsigned)(TWIN ? g >> 1 : 0) < nimg;     // false: this lane's image is the odd batch's missing twin
     const int x0 = strip * 32;
     const int y0 = seg * a.rseg, y1 = min(a.H, y0 + a.rseg);
     const int rfirst = max(y0 - 1, 0), rlast = min(y1, a.H - 1);
@@ -183,9 +185,9 @@ __global__ __launch_bounds__((64 * WgradRGeom<MF, NF>::NW), 1) void wgrad_r_k(Wg
     {
       // edge pixel of this lane: lane group 0 fetches the pixel right of the strip (x0 + 32), lane group 3 the one left of it
       const int ex = g == 0 ? x0 + 32 : x0 - 1;
-      evalid = !a.twin && (g == 0 || g == 3) && ex >= 0 && ex < a.W;
-      const unsigned col = a.twin ? 8u * (g & 1) : (unsigned)(x0 + 8 * g);      // this lane's first pixel in its row
-      const unsigned img = a.twin ? (unsigned)(g >> 1) : 0u;                      // ... and its image behind the descriptor
+      evalid = !TWIN && (g == 0 || g == 3) && ex >= 0 && ex < a.W;
+      const unsigned col = TWIN ? 8u * (g & 1) : (unsigned)(x0 + 8 * g);      // this lane's first pixel in its row
+      const unsigned img = TWIN ? (unsigned)(g >> 1) : 0u;                      // ... and its image behind the descriptor
       // (an image of the odd batch's missing twin lies beyond num_records: its lanes read zeros)
 #pragma unroll
       for (int m = 0; m < MF; ++m) ybase[m] = ((unsigned)(cout0 + 16 * m + c16) * HW + col + img * (unsigned)a.Cout * HW) * 4u;
@@ -486,6 +488,7 @@ static bool wgrad_r_plan(int B, int H, int W, int Cin, int Cout, WgradRPlan& p) 
 }
 
 extern "C" int wtpse_wgrad_r_supported(int Cin, int Cout, int ksize, int C0, int W) {
+  if (W == 16 && (Cin % 32 != 0 || Cout % 32 != 0)) return 0;      // TWIN is instantiated for the 32 x 32 blocks only (the deepest level)
   return ksize == 3 && Cin % 16 == 0 && Cout % 16 == 0 && C0 % 16 == 0 && wgrad_r_width_ok(W);
 }
 
@@ -536,6 +539,16 @@ static int wgrad_r_impl(const float* dy, const float* x0, int C0, const float* x
 #define WR_LAUNCH1(M, N) do { \
     if (pro) hipLaunchKernelGGL((wgrad_r_k<M, N, true, false, false, 1>), grid, blk, 0, st, a); \
     else hipLaunchKernelGGL((wgrad_r_k<M, N, false, false, false, 1>), grid, blk, 0, st, a); } while (0)
+  if (a.twin) {        // 16-pixel-wide maps: 32 x 32 blocks, no bias gradient, dY materialised
+    WTPSE_REQUIRE(p.mf == 2 && p.nf == 2 && !bias && !aff);
+    if (g_x3_terms == 1) {
+      if (pro) hipLaunchKernelGGL((wgrad_r_k<2, 2, true, false, false, 1, true>), grid, blk, 0, st, a);
+      else hipLaunchKernelGGL((wgrad_r_k<2, 2, false, false, false, 1, true>), grid, blk, 0, st, a);
+    } else {
+      if (pro) hipLaunchKernelGGL((wgrad_r_k<2, 2, true, false, false, 3, true>), grid, blk, 0, st, a);
+      else hipLaunchKernelGGL((wgrad_r_k<2, 2, false, false, false, 3, true>), grid, blk, 0, st, a);
+    }
+  } else
   if (g_x3_terms == 1 && !aff && p.mf * p.nf >= 2) {
     if (p.mf == 2 && p.nf == 2) WR_LAUNCH1(2, 2);
     else if (p.mf == 2) WR_LAUNCH1(2, 1);
