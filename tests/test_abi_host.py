@@ -30,6 +30,21 @@ def test_library_exports_every_declared_symbol():
     assert L.query("wtpse_conv_stats_blocks", 32, 256, 256) == 32 * 32 * 8
     assert L.query("wtpse_wgrad_ksplit", 32, 256, 256, 32, 32) == 512
     assert L.query("wtpse_wt_split", 32, 65536, 0) >= 1
+    # launch geometry of the x3 convolutions at the benchmark's batch (rows of the statistics partials = tiles):
+    # 256-pixel tiles where 64-channel blocks give two workgroups per CU ...
+    assert L.query("wtpse_conv_x3_stats_blocks", 32, 128, 128, 64, 3) == 32 * 4 * 16       # up3.conv3: 8 x 32 tiles
+    # ... 128-pixel tiles for the mid-sized launches (conv_x3r_k's 64-channel blocks on half tiles) and for the deepest level ...
+    assert L.query("wtpse_conv_x3_stats_blocks", 32, 32, 32, 128, 3) == 32 * 1 * 8         # down3.conv2: 4 x 32 tiles
+    assert L.query("wtpse_conv_x3_stats_blocks", 32, 16, 16, 256, 3) == 32 * 1 * 2         # down4.conv2: 8 x 16 tiles
+    # ... but not for 1x1 convolutions (conv_x3_k only) nor for 32-channel layers with enough tiles
+    assert L.query("wtpse_conv_x3_stats_blocks", 32, 32, 32, 128, 1) == 32 * 1 * 4
+    assert L.query("wtpse_conv_x3_stats_blocks", 32, 256, 256, 32, 3) == 32 * 8 * 32
+    # the register-resident weight gradient: maps a multiple of 32 wide, or 16 wide with 32-channel multiples (two images per step)
+    assert L.query("wtpse_wgrad_r_supported", 64, 64, 3, 16, 64) == 1
+    assert L.query("wtpse_wgrad_r_supported", 256, 256, 3, 16, 16) == 1
+    assert L.query("wtpse_wgrad_r_supported", 16, 16, 3, 16, 16) == 0
+    assert L.query("wtpse_wgrad_r_supported", 64, 64, 3, 16, 24) == 0
+    assert L.query("wtpse_wgrad_r_slabs", 32, 16, 16, 256, 256) >= 1
     # argument validation happens before any launch
     assert L.raw("wtpse_conv_fwd")(0, 16, 0, 0, 0, 0, 0, 0, 0, 0, 0, 16, 0, 1, 8, 8, 16, 3, 0, 0, 0) == -1
 
