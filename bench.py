@@ -84,6 +84,39 @@ def build_nets(hp, pb, dev, seed=1):
     return model_od, mks(), model_oc, mks()
 
 
+def aux_seg_only(B, H, dev, steps, warmup):
+    """BASELINE.json configs[1] — "seg-net only (no DWT loss), bf16" — measured after the headline run: call A with whitening and
+    shape prior off, backward, Adam (`--workload seg`), with fp32 results (x3 arithmetic) and in the bf16 mode (`--dtype bf16`:
+    one bf16 term per operand in the MFMA-bound layers; outside the 1e-4 parity bar by construction)."""
+    from wtpse_hip import ops
+    from wtpse_hip.step import TrainStep
+    from wtpse_hip.synth import make_batch, default_hparams
+    hp = default_hparams(False)
+    image, target_od, target_oc = make_batch(B, H, H, dev, seed=1)
+    out = {"workload": "BASELINE.json configs[1]: segmentation net only (whitening and shape prior off), 3x%dx%d, batch %d" % (H, H, B),
+           "step": "call A + backward + Adam (Trainer.py:766-808)"}
+    for name, terms in (("f32", 3), ("bf16", 1)):
+        was = ops.lib().query("wtpse_x3_terms", terms)
+        try:
+            ts = TrainStep(*build_nets(hp, B // 3, dev), hp, dp=None, graph="plan")
+            for _ in range(2 + warmup):
+                ts.step(image, target_od, target_oc)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                res = ts.step(image, target_od, target_oc)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            assert all(float(v) == float(v) for v in res.values()), "NaN loss in the seg-only run"
+            out[name] = {"value": B * steps / dt, "unit": "images/s", "ms_per_step": 1e3 * dt / steps, "steps": steps,
+                         "conv_tflops_end_to_end": B * steps / dt * seg_gflop_per_image(H) / 1e3}
+            del ts
+        finally:
+            ops.lib().query("wtpse_x3_terms", was)
+    out["bf16"]["dtype_note"] = "one bf16 term per operand, one MFMA product, fp32 accumulation; NOT within the 1e-4 parity bar"
+    return out
+
+
 def time_kernel(fn, reps=20):
     """Average duration (ms) of one launch from HIP events on the stream the kernels run on.  `fn`: a callable, or a LIST of
     callables on different operand sets that the launches rotate through — the HBM-bound kernels are timed on >= 4 sets with a
@@ -717,6 +750,10 @@ def main():
                                      "achieved_level_sum": w["gbs"], "bytes_level_sum": w["bytes_per_launch"],
                                      "note": "stand-alone micro-benchmark: the reference has no wavelet transform — not part of WT-PSE, "
                                              "parity unpinned (SURVEY.md 8f-4)"} for w in kr["dwt"]]
+        if world == 1 and full and args.dtype == "f32" and not args.no_kernel_roofline and (B, H) == (32, 256):
+            # BASELINE.json configs[1] beside the headline (configs[2]): the segmentation net alone, fp32 results and the bf16 mode
+            log("configs[1] (seg-net only): fp32 results, bf16 mode")
+            line["configs1_seg_only"] = aux_seg_only(B, H, dev, args.steps, args.warmup)
         if world == 1 and not args.no_cpu_baseline:
             log("cpu baseline")
             line["cpu_baseline"] = cpu_baseline(H, full, args.cpu_baseline_full)
