@@ -33,11 +33,6 @@ struct HeadArgs {
 
 #define HEAD_MAXNC 4
 
-__device__ __forceinline__ float head_act(float v, const float* pro, int c, int relu) {
-  if (pro) v = fmaf(v, pro[2 * c], pro[2 * c + 1]);
-  return relu ? fmaxf(v, 0.f) : v;
-}
-
 template <bool L3>
 __global__ __launch_bounds__(256, 2) void head_fwd_k(HeadArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, u = lane >> 5, n = lane & 31;
@@ -60,6 +55,16 @@ __global__ __launch_bounds__(256, 2) void head_fwd_k(HeadArgs a) {
       for (int r = 0; r < 4; ++r) w3r[j][r] = j < a.nc ? a.w3[j * 8 + 4 * u + r] : 0.f;
     }
   }
+  // the prologue's coefficients of this lane's 16 input channels, once: read through `a.pro` inside the loop they were re-loaded for every
+  // 32-pixel block (the compiler cannot prove that the stores to h1 / h2 / y leave them alone) — 32 loads and their waits per block, as
+  // expensive as the block's 32 MFMAs (ablation: 165 -> 113 us without the prologue, 113 without the MFMAs)
+  float psc[16], psh[16];
+  const bool has_pro = a.pro != nullptr, pro_relu = a.pro_relu != 0;
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    psc[s] = has_pro ? a.pro[2 * (2 * s + u)] : 1.f;
+    psh[s] = has_pro ? a.pro[2 * (2 * s + u) + 1] : 0.f;
+  }
   // the next block's input is fetched while this block runs through its two dependent MFMA chains
   const int stride = gridDim.x * 4;
   float xn[16];
@@ -75,7 +80,10 @@ __global__ __launch_bounds__(256, 2) void head_fwd_k(HeadArgs a) {
     const int b = blk / bpi, p = (blk - b * bpi) * 32 + n;
     float xv[16];
 #pragma unroll
-    for (int s = 0; s < 16; ++s) xv[s] = head_act(xn[s], a.pro, 2 * s + u, a.pro_relu);
+    for (int s = 0; s < 16; ++s) {
+      const float v = has_pro ? fmaf(xn[s], psc[s], psh[s]) : xn[s];
+      xv[s] = pro_relu ? fmaxf(v, 0.f) : v;
+    }
     fetch(blk + stride);
     f32x16 acc1;
 #pragma unroll
@@ -147,6 +155,11 @@ __global__ __launch_bounds__(256, 2) void head_bwd_k(HeadArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) w3r[j][r] = j < a.nc ? a.w3[j * 8 + 4 * u + r] : 0.f;
   }
+  // the prologue's coefficients, once (see head_fwd_k) — through LDS here: this kernel has no 32 registers to spare (it spilled with them)
+  __shared__ float2 pro_sh[32];
+  const bool has_pro = a.pro != nullptr, pro_relu = a.pro_relu != 0;
+  if (threadIdx.x < 32) pro_sh[threadIdx.x] = has_pro ? make_float2(a.pro[2 * threadIdx.x], a.pro[2 * threadIdx.x + 1]) : make_float2(1.f, 0.f);
+  __syncthreads();
   f32x16 accW1, accW2;
 #pragma unroll
   for (int r = 0; r < 16; ++r) accW1[r] = accW2[r] = 0.f;
@@ -194,7 +207,11 @@ __global__ __launch_bounds__(256, 2) void head_bwd_k(HeadArgs a) {
       for (int r = 0; r < 4; ++r) d2[r] = a.dy[((size_t)b * 8 + 4 * u + r) * HW + p];
     }
 #pragma unroll
-    for (int s = 0; s < 16; ++s) xv[s] = head_act(xv[s], a.pro, 2 * s + u, a.pro_relu);
+    for (int s = 0; s < 16; ++s) {
+      const float2 pc = pro_sh[2 * s + u];
+      const float v = has_pro ? fmaf(xv[s], pc.x, pc.y) : xv[s];
+      xv[s] = pro_relu ? fmaxf(v, 0.f) : v;
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) sb2[r] += d2[r];
     // dh1 = (W2^T dh2) * [h1 > 0]
