@@ -192,9 +192,11 @@ __device__ __forceinline__ float up_w(int d, int n, int k) {  // weight of sourc
   return (i0 == k ? 1.f - l1 : 0.f) + (i1 == k ? l1 : 0.f);
 }
 
-// 4 consecutive outputs of one row per thread (W even): 2 x 4 input loads, one 16-byte store; bitwise the same
-// expression tree as the scalar kernel / ATen (weights 0.25/0.75, (1,0) at the clamped first column and row);
-// one plane per blockIdx.y, 32-bit index arithmetic
+// 4 consecutive outputs of TWO rows per thread (W even): the output rows 2p + 1 and 2p + 2 interpolate between the same input rows p and
+// p + 1 (weights 0.25 / 0.75), so one thread takes the pair — 2 x 4 input loads and the index arithmetic once for two 16-byte stores
+// (one row per thread: 3.0 TB/s; p runs over -1 .. H - 1: the first pair holds output row 0 only, the last one row 2H - 1 only).
+// Per output bitwise the expression tree of the scalar kernel / ATen (weights from up_src; (1, 0) at the clamped first column and row);
+// one plane per blockIdx.y, 32-bit index arithmetic.
 // stats (optional): [B * gridDim.x][C][2] per-workgroup (sum, sum of squares) of the OUTPUT, the train-mode BatchNorm
 // statistics of a 1x1 conv that was moved in front of the upsampling (see convu_fwd in nn.py)
 __global__ __launch_bounds__(256) void upsample2x_fwd4_v_k(const float* __restrict__ x, const float* __restrict__ pro, int relu,
@@ -202,14 +204,18 @@ __global__ __launch_bounds__(256) void upsample2x_fwd4_v_k(const float* __restri
                                                            int H, int W) {
   __shared__ float sh4[4];
   const int Ho = 2 * H, Wo = 2 * W, W2 = W / 2;
-  const int jj = blockIdx.x * 256 + threadIdx.x;   // over Ho*(Wo/4)
-  const bool valid = jj < Ho * W2;
+  const int jj = blockIdx.x * 256 + threadIdx.x;   // over (H + 1) * (Wo / 4)
+  const bool valid = jj < (H + 1) * W2;
   if (!valid && !stats) return;
   const int j = valid ? jj : 0;
-  const int k = j % W2, yo = j / W2;
-  int y0, y1;
-  float ly;
-  up_src(yo, H, y0, y1, ly);
+  const int k = j % W2, p = j / W2 - 1;
+  const int ya = 2 * p + 1, yb = 2 * p + 2;        // this thread's output rows
+  const bool va = valid && ya >= 0, vb = valid && yb < Ho;
+  int t0, t1;
+  float la = 0.f, lb = 0.f;
+  if (ya >= 0) up_src(ya, H, t0, t1, la);          // rows (p, min(p + 1, H - 1))
+  if (yb < Ho) up_src(yb, H, t0, t1, lb);          // rows (p, p + 1); p = -1 (output row 0): rows (0, min(1, H - 1)) with weight 0 on the second
+  const int y0 = max(p, 0), y1 = p < 0 ? min(1, H - 1) : min(p + 1, H - 1);
   const int m = 2 * k;
   const int xm1 = max(m - 1, 0), x1 = min(m + 1, W - 1), x2 = min(m + 2, W - 1);
   for (int bc = blockIdx.y; bc < BC; bc += gridDim.y) {
@@ -224,15 +230,22 @@ __global__ __launch_bounds__(256) void upsample2x_fwd4_v_k(const float* __restri
     ha[1] = 0.75f * a[1] + 0.25f * a[2]; hb[1] = 0.75f * b[1] + 0.25f * b[2];
     ha[2] = 0.25f * a[1] + 0.75f * a[2]; hb[2] = 0.25f * b[1] + 0.75f * b[2];
     ha[3] = 0.75f * a[2] + 0.25f * a[3]; hb[3] = 0.75f * b[2] + 0.25f * b[3];
-    float4 o;
-    o.x = (1.f - ly) * ha[0] + ly * hb[0];
-    o.y = (1.f - ly) * ha[1] + ly * hb[1];
-    o.z = (1.f - ly) * ha[2] + ly * hb[2];
-    o.w = (1.f - ly) * ha[3] + ly * hb[3];
-    if (valid) *reinterpret_cast<float4*>(out + (size_t)bc * Ho * Wo + (size_t)yo * Wo + 4 * k) = o;
+    float4 oa, ob;
+    oa.x = (1.f - la) * ha[0] + la * hb[0];
+    oa.y = (1.f - la) * ha[1] + la * hb[1];
+    oa.z = (1.f - la) * ha[2] + la * hb[2];
+    oa.w = (1.f - la) * ha[3] + la * hb[3];
+    ob.x = (1.f - lb) * ha[0] + lb * hb[0];
+    ob.y = (1.f - lb) * ha[1] + lb * hb[1];
+    ob.z = (1.f - lb) * ha[2] + lb * hb[2];
+    ob.w = (1.f - lb) * ha[3] + lb * hb[3];
+    float* ob0 = out + (size_t)bc * Ho * Wo + 4 * k;
+    if (va) *reinterpret_cast<float4*>(ob0 + (size_t)ya * Wo) = oa;
+    if (vb) *reinterpret_cast<float4*>(ob0 + (size_t)yb * Wo) = ob;
     if (stats) {
-      float s1 = valid ? (o.x + o.y) + (o.z + o.w) : 0.f;
-      float s2 = valid ? (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w) : 0.f;
+      float s1 = (va ? (oa.x + oa.y) + (oa.z + oa.w) : 0.f) + (vb ? (ob.x + ob.y) + (ob.z + ob.w) : 0.f);
+      float s2 = (va ? (oa.x * oa.x + oa.y * oa.y) + (oa.z * oa.z + oa.w * oa.w) : 0.f) +
+                 (vb ? (ob.x * ob.x + ob.y * ob.y) + (ob.z * ob.z + ob.w * ob.w) : 0.f);
       s1 = block_sum(s1, sh4);
       s2 = block_sum(s2, sh4);
       if (threadIdx.x == 0) {
@@ -744,16 +757,16 @@ extern "C" int wtpse_upsample2x_fwd(const float* x, const float* pro, int relu, 
   WTPSE_REQUIRE(x && out && B > 0 && C > 0 && H > 0 && W > 0);
   long long total = (long long)B * C * H * W * 4;
   if (W % 2 == 0 && W >= 2 && (((uintptr_t)out) & 15) == 0)
-    hipLaunchKernelGGL(upsample2x_fwd4_v_k, PLANE_GRID(2 * H * (W / 2), B * C), dim3(256), 0, ST, x, pro, relu, out, nullptr, B * C, C, H, W);
+    hipLaunchKernelGGL(upsample2x_fwd4_v_k, PLANE_GRID((H + 1) * (W / 2), B * C), dim3(256), 0, ST, x, pro, relu, out, nullptr, B * C, C, H, W);
   else
     hipLaunchKernelGGL(upsample2x_fwd_k, GRID1(total), dim3(256), 0, ST, x, pro, relu, out, C, H, W, total);
   return wtpse_status();
 }
-extern "C" int wtpse_upsample2x_stats_blocks(int B, int H, int W) { return B * ((2 * H * (W / 2) + 255) / 256); }
+extern "C" int wtpse_upsample2x_stats_blocks(int B, int H, int W) { return B * (((H + 1) * (W / 2) + 255) / 256); }
 extern "C" int wtpse_upsample2x_fwd_stats(const float* x, float* out, float* stats, int B, int C, int H, int W, void* stream) {
   WTPSE_REQUIRE(x && out && stats && B > 0 && C > 0 && H > 0 && W >= 2 && W % 2 == 0 && (((uintptr_t)out) & 15) == 0);
   WTPSE_REQUIRE(B * C < 32768);   // one plane per blockIdx.y: the statistics rows are indexed by gridDim.x
-  hipLaunchKernelGGL(upsample2x_fwd4_v_k, PLANE_GRID(2 * H * (W / 2), B * C), dim3(256), 0, ST, x, nullptr, 0, out, stats, B * C, C, H, W);
+  hipLaunchKernelGGL(upsample2x_fwd4_v_k, PLANE_GRID((H + 1) * (W / 2), B * C), dim3(256), 0, ST, x, nullptr, 0, out, stats, B * C, C, H, W);
   return wtpse_status();
 }
 extern "C" int wtpse_upsample2x_bwd(const float* dout, float* dx, int accumulate, int B, int C, int H, int W, void* stream) {
