@@ -253,9 +253,36 @@ def dominant_kernel_share():
                 fam[name] = fam.get(name, 0.0) + float(r["TotalDurationNs"])
                 break
     top = max(fam, key=fam.get)
+    steps = sum(int(r["Calls"]) for r in rows if r["Name"].startswith("adam_k")) / 4.0     # four Adam launches per step
     return {"profile": os.path.relpath(files[-1], ROOT), "family": top, "percent": 100.0 * fam[top] / tot,
             "families_percent": {k: round(100.0 * v / tot, 1) for k, v in sorted(fam.items(), key=lambda kv: -kv[1])},
-            "kernel": top}
+            "kernel": top, "steps_in_profile": steps, "family_ms_per_step": (fam[top] / steps / 1e6) if steps else None,
+            "all_kernels_ms_per_step": (tot / steps / 1e6) if steps else None}
+
+
+# U-Net passes of one full iteration on the x3 forward / data-gradient family (calls A-D, Trainer.py:766-914; dead teacher
+# backward of calls B/D skipped): A and C = main + teacher forward and data gradient (4 each), B and D = teacher + student forward,
+# student data gradient (3 each); weight-gradient passes: A/C 2 each, B/D 1 each
+X3_FWD_PASSES, X3_DGRAD_PASSES, X3_WGRAD_PASSES = 8, 6, 6
+
+
+def in_step_fraction(dom, un, B):
+    """The leading family's rate INSIDE the step, from the committed back-to-back (single-stream) rocprofv3 summary: the FLOPs one
+    step issues on that family (per-layer table of this run: which layers run on the x3 kernels, forward / data gradient counted
+    separately) / the family's summed kernel time per step in that profile.  Not measured by this run."""
+    if not dom or not dom.get("family_ms_per_step"):
+        return None
+    rows = un["layers"]
+    f = sum(r["flop"] for r in rows if r["fwd_path"] == "x3")
+    g = sum(r["flop"] for r in rows if r["dgrad_path"] == "x3" and "dgrad_ms" in r)
+    w = sum(r["flop"] for r in rows if r["fwd_path"] == "x3" and " k3 " in r["layer"])
+    if dom["family"] == "x3_wgrad":
+        flop = X3_WGRAD_PASSES * w
+    else:
+        flop = X3_FWD_PASSES * f + X3_DGRAD_PASSES * g
+    tf = flop / dom["family_ms_per_step"] / 1e9
+    return {"tflops": tf, "frac": tf / MFMA_X3_PEAK_TF, "gflop_per_step_on_family": flop / 1e9, "batch": B,
+            "family_ms_per_step": dom["family_ms_per_step"], "profile": dom["profile"]}
 
 
 def kernel_rooflines(B, H, dev):
@@ -509,6 +536,104 @@ def cpu_baseline(H, full, full_protocol=False):
                             "after 3 warm-up (%.1f ms)" % (H, H, 1e3 * tw[len(tw) // 2])}}
 
 
+def _rnd(v, n=5):
+    """floats to n significant digits (the stdout line is for a parser, not for reading noise)"""
+    if isinstance(v, float):
+        return float("%.*g" % (n, v))
+    if isinstance(v, dict):
+        return {k: _rnd(x, n) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_rnd(x, n) for x in v]
+    return v
+
+
+COMPACT_LIMIT = 8192
+
+
+def compact_line(line):
+    """The ONE stdout line of the contract, kept small enough for the driver's parser (round 4's line was 31 KB and
+    `BENCH_r04.json.parsed` came back null): the contract's keys, `roofline` (dominant kernel family: live isolated-launch rate,
+    the in-step rate from the committed profile, the whole step, PMC traffic against algorithmic bytes), the two WT-loss lines with
+    their rate against this box's own streaming copy, `cpu_baseline`.  Per-layer tables and every other roofline object go to the
+    detail file / stderr (`emit`)."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "roi_presteps", "host_enqueue_ms_per_step", "conv_tflops_end_to_end", "gflop_per_image")
+    out = {k: line[k] for k in keep if k in line}
+    if "degenerate_roi" in line:
+        out["degenerate_roi_images_per_s"] = line["degenerate_roi"]["value"]
+    r = line.get("roofline")
+    copy16 = (line.get("roofline_copy_w16") or {}).get("achieved")
+    if r:
+        tr = r.get("traffic") or {}
+        dom = r.get("dominant_in_profile") or {}
+        ins = r.get("in_step") or {}
+        out["roofline"] = {
+            "bound": r["bound"], "kernel": "conv_x3r_k + conv_x3_k (x3 forward + data gradient family)" if "forward + data" in r["kernel"]
+            else "wgrad_r_k (x3 weight gradient family)",
+            "achieved": r["achieved"], "peak": r["peak"], "unit": r["unit"], "frac": r["frac"],
+            "achieved_what": "FLOP-weighted over every launch of one U-Net on this family, isolated launches, HIP events (this run)",
+            "in_step_frac": r.get("in_step_frac"), "in_step_tflops": ins.get("tflops"), "in_step_family_ms_per_step": ins.get("family_ms_per_step"),
+            "in_step_source": (dom.get("profile") and "committed %s (back-to-back kernels), not this run" % dom["profile"]),
+            "family_percent_of_step_kernel_time": dom.get("percent"),
+            "step_frac": r.get("step_frac"), "best_layers_frac": r.get("best_layers_frac"),
+            "traffic": tr.get("hbm_bytes"), "traffic_read": tr.get("hbm_read_bytes"), "traffic_write": tr.get("hbm_write_bytes"),
+            "traffic_algorithmic": (r.get("traffic_algorithmic") or {}).get("hbm_bytes"),
+            "traffic_source": "committed profiles/pmc_traffic.json (rocprofv3 --pmc, separate passes, copy-kernel calibrated), same library" if tr else r.get("traffic_source"),
+            "peak_note": r.get("peak_note")}
+    for k in ("roofline_wt_fwd", "roofline_wt_bwd", "roofline_c16_fwd", "roofline_x3_wgrad"):
+        w = line.get(k)
+        if not w:
+            continue
+        o = {"bound": w["bound"], "achieved": w["achieved"], "peak": w["peak"], "unit": w["unit"], "frac": w["frac"],
+             "ms_per_launch": w.get("ms_per_launch"), "traffic": (w.get("traffic") or {}).get("hbm_bytes")}
+        if w["bound"] == "hbm":
+            o["algorithmic_bytes"] = w.get("bytes_per_launch")
+            o["frac_of_copy"] = (w["achieved"] / copy16) if copy16 else None
+        if "fused_in_step" in w:
+            o["fused_in_step_loss_cost_ms"] = w["fused_in_step"]["loss_cost_ms"]
+        out[k] = o
+    if copy16:
+        out["copy_yardstick_gbs"] = copy16
+    s1 = line.get("configs1_seg_only")
+    if s1:
+        out["configs1_seg_only"] = {k: {"value": s1[k]["value"], "ms_per_step": s1[k]["ms_per_step"]} for k in ("f32", "bf16") if k in s1}
+    c = line.get("cpu_baseline")
+    if c:
+        out["cpu_baseline"] = {"value": c["value"], "unit": c["unit"], "cores": c["cores"], "kind": c["kind"], "sample": c["sample"],
+                               "cpu_model": (c.get("host") or {}).get("cpu_model"),
+                               "physical_cores_on_host": (c.get("host") or {}).get("physical_cores_on_host"),
+                               "b30_images_per_s": (c.get("b30") or {}).get("value"),
+                               "wt_loss_fwd_gbs": (c.get("wt_loss_fwd") or {}).get("value")}
+    out["detail"] = line.get("detail_file")
+    return _rnd(out)
+
+
+def emit(line, args):
+    """Full record -> a side file (gpurun_out/ on the GPU box, else $TMPDIR) and stderr; compact record -> the ONE stdout line."""
+    full = json.dumps(line)
+    name = "bench_detail_n%d_%s%s.json" % (line["n_gpus"], args.workload, "" if args.dtype == "f32" else "_" + args.dtype)
+    for d in (os.path.join(ROOT, "gpurun_out"), os.environ.get("TMPDIR", "/tmp")):
+        try:
+            os.makedirs(d, exist_ok=True)
+            with open(os.path.join(d, name), "w") as f:
+                f.write(full + "\n")
+            line["detail_file"] = os.path.relpath(os.path.join(d, name), ROOT) if d.startswith(ROOT) else os.path.join(d, name)
+            break
+        except OSError:
+            continue
+    print("[bench detail] " + full, file=sys.stderr, flush=True)
+    log("timed region (repeated behind the detail record): %.3f s for %d steps = %.1f %s" %
+        (line["ms_per_step"] * line["steps"] / 1e3, line["steps"], line["value"], line["unit"]))
+    small = json.dumps(compact_line(line))
+    if len(small) >= COMPACT_LIMIT:          # never hand the driver a line it cannot parse: drop the optional objects
+        c = compact_line(line)
+        for k in ("configs1_seg_only", "roofline_x3_wgrad", "roofline_c16_fwd", "copy_yardstick_gbs", "degenerate_roi_images_per_s"):
+            c.pop(k, None)
+        small = json.dumps(c)
+    assert len(small) < COMPACT_LIMIT, "bench line too long for the driver's parser: %d bytes" % len(small)
+    print(small, flush=True)
+
+
 def _x3_on():
     from wtpse_hip import nn as E
     return bool(E.X3)
@@ -711,6 +836,9 @@ def main():
                          "step_frac": (line["conv_tflops_end_to_end"] / MFMA_X3_PEAK_TF) if line["conv_tflops_end_to_end"] else None,
                          "step_frac_note": "conv_tflops_end_to_end (224.5 GFLOP of necessary convolution work per image x images/s) / the x3 bound: "
                                            "the whole step, every kernel and every gap included"})
+            ins = in_step_fraction(dom, un, B) if (B, H) == (32, 256) and full and args.dtype == "f32" else None
+            head["in_step_frac"] = ins["frac"] if ins else None
+            head["in_step"] = ins
             line["roofline"] = dict(head, dominant_in_profile=dom)
             line["roofline_unet_layers"] = {"what": "every convolution of one U-Net as the step launches it (B=%d): FLOP-weighted TFLOP/s over the "
                                                     "layers on the x3 kernels, per direction, and the per-layer rows" % B,
@@ -758,7 +886,7 @@ def main():
             log("cpu baseline")
             line["cpu_baseline"] = cpu_baseline(H, full, args.cpu_baseline_full)
             log("done")
-        print(json.dumps(line))
+        emit(line, args)
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
