@@ -31,9 +31,16 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3     # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak
-# the x3 kernels form one fp32 product from 6 bf16 MFMA products: their bound is the dense bf16 MFMA peak (16x the fp32-input
-# rate, MI355X_MICROARCH.md "Matrix cores": ~2.5 PFLOP/s) / 6
-MFMA_X3_PEAK_TF = 16.0 * 157.3 / 6.0
+# the x3 kernels form one fp32 product from several 16-bit MFMA products: their bound is the dense bf16 / fp16 MFMA peak (16x the
+# fp32-input rate, MI355X_MICROARCH.md "Matrix cores": ~2.5 PFLOP/s; the two formats run at the same rate) / the number of products
+# — 6 in the x3 arithmetic (three bf16 terms per operand, rounds 2-4), 3 in x2h (two fp16 terms, the default since round 5), 1 in
+# the bf16 mode.  Set in main() from the library's setting (wtpse_x3_terms).
+X3_PRODUCTS = {3: 6, 2: 3, 1: 1}
+X3_NAME = {3: "x3 (3 bf16 terms per fp32 operand, 6 bf16 MFMA products per multiply, fp32 accumulation)",
+           2: "x2h (2 fp16 terms per fp32 operand — power-of-two operand scaling —, 3 fp16 MFMA products per multiply, fp32 accumulation)",
+           1: "bf16 mode (operands rounded to one bf16 term, one MFMA product, fp32 accumulation)"}
+MFMA_X3_PEAK_TF = 16.0 * 157.3 / 3.0
+X3_TERMS = 2
 GFLOP_PER_IMAGE = 224.5      # SURVEY.md §8d / BASELINE.md §5: necessary conv FLOPs of one full iteration at 256x256
 
 
@@ -95,7 +102,7 @@ def aux_seg_only(B, H, dev, steps, warmup):
     image, target_od, target_oc = make_batch(B, H, H, dev, seed=1)
     out = {"workload": "BASELINE.json configs[1]: segmentation net only (whitening and shape prior off), 3x%dx%d, batch %d" % (H, H, B),
            "step": "call A + backward + Adam (Trainer.py:766-808)"}
-    for name, terms in (("f32", 3), ("bf16", 1)):
+    for name, terms in (("f32", ops.x3_terms()), ("bf16", 1)):
         was = ops.lib().query("wtpse_x3_terms", terms)
         try:
             ts = TrainStep(*build_nets(hp, B // 3, dev), hp, dp=None, graph="plan")
@@ -324,7 +331,7 @@ def kernel_rooflines(B, H, dev):
         ms = time_kernel(lambda: E._wgrad(layer, dy, a0, a1, with_bias=False))
         wg.append({"layer": tag, "ms": ms, "tflops": fl / ms / 1e9, "flop": fl})
         del x0, x1, dy, net
-    x3 = "x3 (3 bf16 terms per fp32 operand, 6 bf16 MFMAs per product, fp32 accumulate)" if E.X3 else "fp32-input MFMA (WTPSE_X3=0)"
+    x3 = X3_NAME[X3_TERMS] if E.X3 else "fp32-input MFMA (WTPSE_X3=0)"
 
     def agg(rows, kernel):
         tot_ms, tot_fl = sum(r["ms"] for r in rows), sum(r["flop"] for r in rows)
@@ -687,11 +694,12 @@ def main():
         from wtpse_hip.dp import DataParallel
         dp = DataParallel(world, rank, dev, bn_sync=bool(args.bn_sync))
 
+    from wtpse_hip import ops as _ops
     if args.dtype == "bf16":
-        from wtpse_hip import ops as _ops
         _ops.lib().query("wtpse_x3_terms", 1)
-        global MFMA_X3_PEAK_TF
-        MFMA_X3_PEAK_TF = 16.0 * 157.3          # one MFMA product per multiply: the full dense bf16 peak is the bound
+    global MFMA_X3_PEAK_TF, X3_TERMS
+    X3_TERMS = _ops.x3_terms()
+    MFMA_X3_PEAK_TF = 16.0 * 157.3 / X3_PRODUCTS[X3_TERMS]
     if args.kernels_only:
         kr = kernel_rooflines(args.batch, args.size, dev)
         print(json.dumps(kr))
@@ -780,8 +788,8 @@ def main():
             "dtype": ("bf16 (layers with > 16 output channels: operands rounded to one bf16 term, one MFMA product, fp32 accumulation; the "
                       "16-channel layers, the 1x1 heads, BatchNorm and Adam in fp32) — NOT within the 1e-4 parity bar"
                       if args.dtype == "bf16" else
-                      "f32 (layers with > 16 output channels: fp32 operands as 3 bf16 terms, 6 bf16 MFMA products, fp32 accumulation; "
-                      "the rest fp32-input MFMA)" if _x3_on() else "f32"), "data": "synthetic",
+                      "f32 (layers with > 16 output channels: %s; the rest fp32-input MFMA / x3 on 16x16x32)" % X3_NAME[X3_TERMS]
+                      if _x3_on() else "f32"), "data": "synthetic",
             "config": {"workload": (("BASELINE.json configs[2]: full WT-PSE (seg+shape nets + WT loss)" if H == 256 else
                                      "BASELINE.json configs[4] per-GPU share: full WT-PSE at high resolution") if full else
                                     "BASELINE.json configs[1]: seg-net only") + ", 3x%dx%d, batch %d per GPU" % (H, H, B),
@@ -814,8 +822,7 @@ def main():
                                              "LDS-fed MFMA loop reaches ~250 TFLOP/s x3-equivalent, a register-fed 16x16x32 loop ~320 "
                                              "(profiles/r03_mfma_peak.txt, tools/probe/mfma_peak.hip)",
                         "frac_of_fp32_mfma_peak": r["tflops"] / MFMA_F32_PEAK_TF,
-                        "peak_note": ("bf16 dense MFMA peak (16 x 157.3): one product per multiply in the bf16 mode" if args.dtype == "bf16" else
-                                      "bf16 dense MFMA peak (16 x 157.3) / 6 products per fp32 multiply; fp32-input MFMA peak 157.3"),
+                        "peak_note": "dense 16-bit MFMA peak (16 x 157.3 = 2516.8) / %d product(s) per fp32 multiply; fp32-input MFMA peak 157.3" % X3_PRODUCTS[X3_TERMS],
                         "ms_per_launch": r["ms"], "flop_per_launch": r["flop_per_launch"], "launches": r.get("launches")}
             if dom:
                 dom["source"] = "committed profile %s, not measured by this run" % dom["profile"]

@@ -53,8 +53,9 @@ int wtpse_conv_fwd_gram(const float* in0, int C0, const float* wpacked, const fl
  * the launch uses 64-channel row blocks: Cout % 64 == 0 and at least 512 of them) — the per-channel prologue coefficients are
  * staged in LDS; anything else fails with WTPSE_ERR_ARG.  `wpacked`: the weights pre-split by
  * wtpse_pack_conv_weights_x3 — desc as for wtpse_pack_conv_weights with offsets {xf_off, xd_off} in unsigned shorts; per
- * conv and direction ceil16(K) * ceil32(rows) * taps * 3 unsigned shorts (forward: rows = Cout, K = Cin; data gradient:
- * rows = Cin, K = Cout), layout [K chunk 16][row block 32][tap][term 3][k half 2][row 32][8 k]. */
+ * conv and direction 8 + ceil16(K) * ceil32(rows) * taps * 3 unsigned shorts (forward: rows = Cout, K = Cin; data gradient:
+ * rows = Cin, K = Cout): a 16-byte header (float {1 / scale, scale}: the layer's power-of-two weight scale, 1 unless
+ * wtpse_x3_terms() == 2), then [K chunk 16][row block 32][tap][term slot 3][k half 2][row 32][8 k]. */
 int wtpse_conv_x3_stats_blocks(int B, int H, int W, int Cout, int ksize);   /* rows of `stats` for wtpse_conv_fwd_x3 (the tiling depends on the kernel size) */
 /* Which 3x3 launches of the x3 entry points run conv_x3r_k (weights fed from registers, input tile double-buffered in LDS) instead
  * of conv_x3_k (weights staged through LDS): on = 1 (default) the launches with 64-channel output blocks, 2 all of them, 0 none;
@@ -67,16 +68,36 @@ int wtpse_x3r_enable(int on);
  * once; 0 = dispatch order (tile fastest); on < 0 only queries (environment: WTPSE_X3_XCD=0|1).  Returns the previous setting.
  * Same workgroups, bitwise the same results (tests/test_conv_x3_gpu.py::test_xcd_order_equals_dispatch_order). */
 int wtpse_x3_xcd(int on);
-/* bf16 terms per fp32 operand in the x3 kernels (wtpse_conv_fwd_x3 and the data gradients on it, wtpse_conv_wgrad_r): 3 (default) =
- * the fp32-accuracy arithmetic above; 1 = the `bf16` mode of BASELINE.json configs[1]: operands rounded to bf16 (nearest even), ONE
- * bf16 MFMA product per multiply, fp32 accumulation — outside the 1e-4 parity bar by construction (tests/test_bf16_mode_gpu.py
- * states its tolerance).  The weight gradients of the 16-pixel-wide maps (wtpse_conv_wgrad_x3) and the 16-channel layers
- * (wtpse_conv16_x3) keep three terms.  Environment: WTPSE_X3_TERMS=1.  Other values only query; returns the previous setting. */
+/* Arithmetic of the x3 kernels (wtpse_conv_fwd_x3 and the data gradients on it, wtpse_conv_wgrad_r), by the number of 16-bit terms
+ * an fp32 operand is split into:
+ *   3 = "x3": three bf16 terms, six MFMA products per multiply (round 2);
+ *   2 = "x2h" (default since round 5): TWO fp16 terms (11 + 11 significant bits, each rounded to nearest even, the remainder exact
+ *       in fp32), THREE products a0 b1 + a1 b0 + a0 b0 on v_mfma_f32_*_f16, fp32 accumulation — half the MFMAs of x3 at the same
+ *       measured accuracy (tests/test_conv_x3_gpu.py: against fp64 beside x3 and the fp32-input MFMA).  fp16 has 5 exponent bits, so
+ *       every operand tensor is multiplied by a power of two as it is loaded (exact) and the result scaled back: weights per layer
+ *       (from the layer's largest magnitude, found by wtpse_pack_conv_weights_x3), forward activations by 2^4 (full precision for
+ *       2^-7 <= |x| < 2^12, absolute error 2^-29 below, saturation — not overflow — above), gradients by the power of two that brings
+ *       `in_amax` — the tensor's amax table (wtpse_amax below), left by the tensor's producer
+ *       (wtpse_bn_bwd_apply_coef, wtpse_upsample2x_bwd[_bn], ...) or by wtpse_amax — into [2^14, 2^15).  in_amax = NULL: the tensor is
+ *       treated like a forward activation (fixed 2^4: right for O(1) data, NOT for real gradients);
+ *   1 = the `bf16` mode of BASELINE.json configs[1]: operands rounded to ONE bf16 term, one product — outside the 1e-4 parity bar by
+ *       construction (tests/test_bf16_mode_gpu.py states its tolerance).
+ * The weight gradients of the 16-pixel-wide maps (wtpse_conv_wgrad_x3) stay on x3.  Packed weights are in the format of the setting
+ * at the time they were packed: re-pack after a change (wtpse_hip/nn.py does).  Environment: WTPSE_X3_TERMS=1|2|3.  Other values only
+ * query; returns the previous setting.  A recorded launch plan (wtpse_plan_*) remembers the setting it was recorded under and
+ * refuses to replay under another one. */
 int wtpse_x3_terms(int terms);
+/* An "amax table" carries the largest magnitude of a gradient tensor from its producer to the x2h kernels that consume it: 256
+ * unsigneds (1 KB, 16-byte aligned) holding float bits of non-negative values in 16 shards, one per 64-byte line (workgroups fold their
+ * maximum into shard (index % 16) with one atomic max; consumers take the maximum over the shards).  Producers with an `amax` argument
+ * (wtpse_bn_bwd*, wtpse_upsample2x_bwd*) fill the table of the gradient they write when amax != NULL: the table must be ZERO on entry.
+ * wtpse_amax zeroes and fills the table of an existing tensor (one extra pass: the slow way). */
+int wtpse_amax(const float* x, long long n, unsigned* amax_table, void* stream);
 int wtpse_pack_conv_weights_x3(const float* params, const int* desc, int n_desc, unsigned short* packed, void* stream);
 int wtpse_conv_fwd_x3(const float* in0, int C0, const float* in1, int C1, const unsigned short* wpacked, const float* bias,
                       const float* pro0, const float* pro1, int pro_relu, float* out0, float* out1, int Csplit, float* stats,
-                      int B, int H, int W, int Cout, int ksize, int relu_out, const float* mask_ref, void* stream);
+                      int B, int H, int W, int Cout, int ksize, int relu_out, const float* mask_ref, const unsigned* in_amax,
+                      void* stream);
 
 /* The 16-channel 3x3 layers (inc, DeepWT, the teacher's inc: algorithms.py:897-917,1091-1117,398-413) in the x3 arithmetic on
  * v_mfma_f32_16x16x32_bf16 (csrc/conv.hip, MODE 3): Cout <= 16, C0 <= 16, one input.  wx16: the layer's register-resident weight
@@ -104,7 +125,7 @@ int wtpse_dgrad_bnb(const float* dy, int C, const float* wpacked, float* out0, f
                     int Cout, int ksize, void* stream);
 int wtpse_dgrad_x3_bnb(const float* dy, int C, const unsigned short* wpacked, float* out0, float* out1, int Csplit,
                        const float* bn_y, const float* bn_ss, const float* bn_mean, int bn_relu, int bn_c0, int bn_c1, float* stats,
-                       int B, int H, int W, int Cout, int ksize, void* stream);
+                       int B, int H, int W, int Cout, int ksize, const unsigned* in_amax, void* stream);
 
 /* A forward convolution in front of a train-mode BatchNorm (algorithms.py:883-889: conv -> bn) whose launch forms the
  * (sum, sum^2) partials of its output in `stats` AND finishes them — wtpse_bn_finalize's work, done by the workgroups that arrive
@@ -133,7 +154,7 @@ int wtpse_dgrad_bnb_coef(const float* dy, int C, const void* wpacked, int layout
                          const float* bn_y, const float* bn_ss, const float* bn_mean, int bn_relu, int bn_c0, int bn_c1,
                          float* stats, const float* gamma, const float* invstd, float* coef, float* dgamma, float* dbeta,
                          int accumulate, double* partial2, unsigned* tickets, int B, int H, int W, int Cout, int ksize,
-                         void* stream);
+                         const unsigned* in_amax, void* stream);      /* in_amax: of dy, used by layout 1 (see wtpse_x3_terms) */
 
 /* dW[Cout][C0+C1][k][k] (+)= sum dY * X, dbias (+)= sum dY (dbias/dbias_slab NULL: skip).  slab: [ksplit][Cout*Cin*k*k],
  * dbias_slab: [ksplit][Cout], ksplit = wtpse_wgrad_ksplit(...).  x inputs take the same prologue as the forward. */
@@ -156,12 +177,14 @@ int wtpse_conv_wgrad_x3(const float* dy, const float* x0, int C0, const float* x
  * horizontal taps are lane shifts, the vertical ones a 3-row ring of registers; no LDS in the main loop).  Maps whose width is a
  * multiple of 32, Cin / Cout multiples of 16 (C0 % 16 == 0 for a concat) — or exactly 16 wide with Cin / Cout multiples of 32 (two images
  * side by side per 32-pixel step; no bias gradient, not the _bn form) —: wtpse_wgrad_r_supported().  With bias gradient
- * (dbias / dbias_slab NULL: skip).  slab: [nslab][Cout*Cin*9], dbias_slab: [nslab][Cout], nslab = wtpse_wgrad_r_slabs(...). */
+ * (dbias / dbias_slab NULL: skip).  slab: [nslab][Cout*Cin*9], dbias_slab: [nslab][Cout], nslab = wtpse_wgrad_r_slabs(...).
+ * Arithmetic by wtpse_x3_terms(); with 2 (x2h) dY is scaled from dy_amax (NULL: like a forward activation), X by 2^4; the _bn
+ * form below stays on three bf16 terms. */
 int wtpse_wgrad_r_supported(int Cin, int Cout, int ksize, int C0, int W);
 int wtpse_wgrad_r_slabs(int B, int H, int W, int Cin, int Cout);
 int wtpse_conv_wgrad_r(const float* dy, const float* x0, int C0, const float* x1, int C1, const float* pro0,
                        const float* pro1, int pro_relu, float* slab, float* dbias_slab, int nslab, float* dw, float* dbias,
-                       int accumulate, int B, int H, int W, int Cout, void* stream);
+                       int accumulate, int B, int H, int W, int Cout, const unsigned* dy_amax, void* stream);    /* dy_amax: wtpse_x3_terms */
 
 /* wtpse_conv_wgrad_r with dY given as the un-applied second half of a BatchNorm backward (wtpse_bn_bwd_coef):
  * dY = k1[c] * g + k2[c] * bn_y + k3[c], bn_coef [Cout][3] = (k1, k2, k3): the BatchNorm-apply pass of the backward
@@ -184,7 +207,7 @@ int wtpse_affine_act(const float* y, const float* scale_shift, int relu, float* 
 /* dz (grad wrt z = act(bn(y))) -> dgamma, dbeta, dy.  partial: [wtpse_bn_bwd_nsplit][C][2], coef: [C][3]. */
 int wtpse_bn_bwd(const float* dz, const float* y, const float* scale_shift, int relu, const float* gamma,
                  const float* save_mean, const float* save_invstd, float* partial, float* coef, float* dgamma,
-                 float* dbeta, int accumulate, float* dy, int B, int C, int HW, void* stream);
+                 float* dbeta, int accumulate, float* dy, int B, int C, int HW, unsigned* amax, void* stream);
 int wtpse_bn_bwd_nsplit(int B, int C, int HW);
 /* Synchronised BatchNorm (data parallel, statistics over the global batch): the backward in two halves around the
  * caller's all-reduce of sums[C][2].  dgamma/dbeta receive this rank's share; dy uses the global sums and count. */
@@ -193,13 +216,13 @@ int wtpse_bn_bwd_reduce(const float* dz, const float* y, const float* scale_shif
 int wtpse_bn_bwd_apply(const float* dz, const float* y, const float* scale_shift, int relu, const float* gamma,
                        const float* save_mean, const float* save_invstd, const float* sums_local, const float* sums_global,
                        long long count_global, float* coef, float* dgamma, float* dbeta, int accumulate, float* dy, int B,
-                       int C, int HW, void* stream);
+                       int C, int HW, unsigned* amax, void* stream);
 /* second half of a BatchNorm backward whose reductions came out of a data gradient's epilogue (wtpse_dgrad_bnb /
  * wtpse_dgrad_x3_bnb): g = the already-masked incoming gradient, stats_partial [nblk][C][2] = (sum g, sum g * (y - mean))
  * per workgroup; dgamma / dbeta (+)=, dy = k1 * g + k2 * y + k3.  coef: [C][3] scratch. */
 int wtpse_bn_bwd_from_stats(const float* g, const float* y, const float* stats_partial, int nblk, const float* gamma,
                             const float* save_mean, const float* save_invstd, float* coef, float* dgamma, float* dbeta,
-                            int accumulate, float* dy, int B, int C, int HW, void* stream);
+                            int accumulate, float* dy, int B, int C, int HW, unsigned* amax, void* stream);
 
 /* partials [nblk][C][2] = (sum g, sum g (y - mean)) -> coef [C][3], dgamma / dbeta (+)=: the first launch of
  * wtpse_bn_bwd_from_stats on its own. */
@@ -207,7 +230,7 @@ int wtpse_bn_bwd_finalize_coef(const float* stats_partial, int nblk, int C, long
                                const float* save_mean, const float* save_invstd, float* coef, float* dgamma, float* dbeta,
                                int accumulate, void* stream);
 /* dy = k1 * g + k2 * y + k3 with coef [C][3] from wtpse_dgrad_bnb_coef. */
-int wtpse_bn_bwd_apply_coef(const float* g, const float* y, const float* coef, float* dy, int B, int C, int HW, void* stream);
+int wtpse_bn_bwd_apply_coef(const float* g, const float* y, const float* coef, float* dy, int B, int C, int HW, unsigned* amax, void* stream);
 
 /* ---- WT (whitening) loss: compute_whitening_loss + compute_MMD (algorithms.py:1277-1309,59-121;
  *      shape_networks.py:561-594,240-309) ------------------------------------------------------------------------ */
@@ -256,12 +279,12 @@ int wtpse_maxpool2_bwd_bnb(const float* x, const float* pro, int relu, const flo
                            const float* mean, float* stats, int B, int C, int H, int W, void* stream);
 /* bilinear x2, align_corners=False; H, W are the INPUT sizes. */
 int wtpse_upsample2x_fwd(const float* x, const float* pro, int relu, float* out, int B, int C, int H, int W, void* stream);
-int wtpse_upsample2x_bwd(const float* dout, float* dx, int accumulate, int B, int C, int H, int W, void* stream);
+int wtpse_upsample2x_bwd(const float* dout, float* dx, int accumulate, int B, int C, int H, int W, unsigned* amax, void* stream);
 /* ... of a gradient that is the second half of a BatchNorm backward and never written out: dout = k1[c] * g + k2[c] * bn_y + k3[c],
  * bn_coef [C][3] as wtpse_dgrad_bnb_coef leaves it (the expression of wtpse_bn_bwd_apply_coef, same bits); g, bn_y [B][C][2H][2W].
  * W % 4 == 0, 16-byte aligned tensors. */
 int wtpse_upsample2x_bwd_bn(const float* g, const float* bn_y, const float* bn_coef, float* dx, int B, int C, int H, int W,
-                            void* stream);
+                            unsigned* amax, void* stream);
 /* The same with the train-mode BatchNorm statistics of the OUTPUT: stats [wtpse_upsample2x_stats_blocks(B,H,W)][C][2]
  * per-workgroup (sum, sum of squares), the layout wtpse_bn_finalize takes.  Used where the 1x1 conv of a ConvU block
  * (algorithms.py:949-951: upsample -> conv2 -> bn2) runs in front of the upsampling instead (the two commute). W even. */
@@ -376,7 +399,9 @@ int wtpse_plan_destroy(void* plan);
 int wtpse_plan_size(void* plan);
 int wtpse_plan_add_call(void* plan, int fn, const void* args, int nargs, void* stream);
 int wtpse_plan_add_wait(void* plan, void* waiter, void* waited);
-int wtpse_plan_replay(void* plan);
+int wtpse_plan_replay(void* plan);      /* -2 (WTPSE_ESTATE): wtpse_tuning_state() differs from the recording's */
+/* The run-time switches that decide tilings and the packed-weight format (wtpse_x3_terms | wtpse_x3r_enable << 4 | wtpse_x3_xcd << 8). */
+int wtpse_tuning_state(void);
 
 /* Fingerprint (hex) of the sources and of this header the library was compiled from; the binding refuses a library
  * whose fingerprint differs from the tree's (a stale .so after a signature change would otherwise go unnoticed). */

@@ -188,34 +188,46 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_k(const float* __restrict
   }
 }
 
-// dy = k1 * dz*[z>0] + k2*y + k3 ; grid = (blocks over HW, B*C)
+// dy = k1 * dz*[z>0] + k2*y + k3.  Work items = (plane bc, chunk of 1024 | 256 elements), nitems = B*C*bpp of them; the workgroups
+// walk them grid-stride (at most APPLY_MAX_WGS workgroups: each ends with ONE atomic when `amax` — the amax table of dy, common.h,
+// zero on entry — is wanted: dy is the gradient operand of the x2h convolutions that consume it).
+constexpr int APPLY_MAX_WGS = 2048;      // 8 workgroups of 256 threads per CU: one resident round
 template <bool VEC>
 __global__ __launch_bounds__(256) void bn_bwd_apply_k(const float* __restrict__ dz, const float* __restrict__ y,
                                                       const float* __restrict__ ss, int relu,
-                                                      const float* __restrict__ coef, int C, int HW, int bpp,
-                                                      float* __restrict__ dy) {
-  const int bc = blockIdx.x / bpp, blk = blockIdx.x - bc * bpp, c = bc % C;
-  const float sc = ss[2 * c], sf = ss[2 * c + 1];
-  const float k1 = coef[3 * c], k2 = coef[3 * c + 1], k3 = coef[3 * c + 2];
-  const size_t base = (size_t)bc * HW;
-  if (VEC) {
-    int p = (blk * 256 + threadIdx.x) * 4;
-    if (p >= HW) return;
-    float4 g = *reinterpret_cast<const float4*>(dz + base + p);
-    float4 v = *reinterpret_cast<const float4*>(y + base + p);
-    float4 o;
-    o.x = fmaf(k1, (relu && !(fmaf(v.x, sc, sf) > 0.f)) ? 0.f : g.x, fmaf(k2, v.x, k3));
-    o.y = fmaf(k1, (relu && !(fmaf(v.y, sc, sf) > 0.f)) ? 0.f : g.y, fmaf(k2, v.y, k3));
-    o.z = fmaf(k1, (relu && !(fmaf(v.z, sc, sf) > 0.f)) ? 0.f : g.z, fmaf(k2, v.z, k3));
-    o.w = fmaf(k1, (relu && !(fmaf(v.w, sc, sf) > 0.f)) ? 0.f : g.w, fmaf(k2, v.w, k3));
-    *reinterpret_cast<float4*>(dy + base + p) = o;
-  } else {
-    int p = blk * 256 + threadIdx.x;
-    if (p >= HW) return;
-    float g = dz[base + p], v = y[base + p];
-    if (relu && !(fmaf(v, sc, sf) > 0.f)) g = 0.f;
-    dy[base + p] = fmaf(k1, g, fmaf(k2, v, k3));
+                                                      const float* __restrict__ coef, int C, int HW, int bpp, int nitems,
+                                                      float* __restrict__ dy, unsigned* __restrict__ amax) {
+  unsigned am = 0u;
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const int bc = item / bpp, blk = item - bc * bpp, c = bc % C;
+    const float sc = ss[2 * c], sf = ss[2 * c + 1];
+    const float k1 = coef[3 * c], k2 = coef[3 * c + 1], k3 = coef[3 * c + 2];
+    const size_t base = (size_t)bc * HW;
+    if (VEC) {
+      int p = (blk * 256 + threadIdx.x) * 4;
+      if (p < HW) {
+        float4 g = *reinterpret_cast<const float4*>(dz + base + p);
+        float4 v = *reinterpret_cast<const float4*>(y + base + p);
+        float4 o;
+        o.x = fmaf(k1, (relu && !(fmaf(v.x, sc, sf) > 0.f)) ? 0.f : g.x, fmaf(k2, v.x, k3));
+        o.y = fmaf(k1, (relu && !(fmaf(v.y, sc, sf) > 0.f)) ? 0.f : g.y, fmaf(k2, v.y, k3));
+        o.z = fmaf(k1, (relu && !(fmaf(v.z, sc, sf) > 0.f)) ? 0.f : g.z, fmaf(k2, v.z, k3));
+        o.w = fmaf(k1, (relu && !(fmaf(v.w, sc, sf) > 0.f)) ? 0.f : g.w, fmaf(k2, v.w, k3));
+        *reinterpret_cast<float4*>(dy + base + p) = o;
+        am = max(am, max(max(amax_bits(o.x), amax_bits(o.y)), max(amax_bits(o.z), amax_bits(o.w))));
+      }
+    } else {
+      int p = blk * 256 + threadIdx.x;
+      if (p < HW) {
+        float g = dz[base + p], v = y[base + p];
+        if (relu && !(fmaf(v, sc, sf) > 0.f)) g = 0.f;
+        const float o = fmaf(k1, g, fmaf(k2, v, k3));
+        dy[base + p] = o;
+        am = max(am, amax_bits(o));
+      }
+    }
   }
+  if (amax) amax_publish_block(amax, am, blockIdx.x);
 }
 
 // Small maps (the 16x16 / 32x32 levels): the three launches above cost 23-30 us of mostly launch latency for a few MB.
@@ -226,7 +238,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_small_k(const float* __restrict__
                                                        const float* __restrict__ ss, int relu, const float* __restrict__ gamma,
                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
                                                        float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
-                                                       float* __restrict__ dy, int B, int C, int HW) {
+                                                       float* __restrict__ dy, int B, int C, int HW, unsigned* __restrict__ amax) {
   __shared__ double sh[2][16];
   __shared__ float kc[3];
   const int c = blockIdx.x, t = threadIdx.x;
@@ -275,6 +287,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_small_k(const float* __restrict__
   }
   __syncthreads();
   const float k1 = kc[0], k2 = kc[1], k3 = kc[2];
+  unsigned am = 0u;
   for (int e = t; e < total; e += 1024) {
     const int b = e / q, p = (e - b * q) * 4;
     const size_t off = ((size_t)b * C + c) * HW + p;
@@ -286,11 +299,25 @@ __global__ __launch_bounds__(1024) void bn_bwd_small_k(const float* __restrict__
     o.z = fmaf(k1, (relu && !(fmaf(v.z, sc, sf) > 0.f)) ? 0.f : g.z, fmaf(k2, v.z, k3));
     o.w = fmaf(k1, (relu && !(fmaf(v.w, sc, sf) > 0.f)) ? 0.f : g.w, fmaf(k2, v.w, k3));
     *reinterpret_cast<float4*>(dy + off) = o;
+    am = max(am, max(max(amax_bits(o.x), amax_bits(o.y)), max(amax_bits(o.z), amax_bits(o.w))));
   }
+  if (amax) amax_publish_block(amax, am, blockIdx.x);
 }
 
 static inline bool vec_ok(int HW, const void* a, const void* b, const void* c) {
   return HW % 4 == 0 && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & 15) == 0;
+}
+
+// the apply pass dy = k1 [masked] dz + k2 y + k3 (+ the amax table of dy, zero on entry, or null)
+static void launch_apply(const float* dz, const float* y, const float* ss, int relu, const float* coef, float* dy, int B, int C, int HW,
+                         unsigned* amax, hipStream_t st) {
+  const bool vec = vec_ok(HW, dz, y, dy);
+  const int bpp = ceil_div(HW, vec ? 1024 : 256);
+  const long long nitems = (long long)bpp * B * C;
+  // without an amax table: one item per workgroup, as rounds 1-4 launched it; with: at most APPLY_MAX_WGS workgroups walk the items
+  const int grid = (int)((amax && nitems > APPLY_MAX_WGS) ? APPLY_MAX_WGS : nitems);
+  if (vec) hipLaunchKernelGGL(bn_bwd_apply_k<true>, dim3(grid), dim3(256), 0, st, dz, y, ss, relu, coef, C, HW, bpp, (int)nitems, dy, amax);
+  else hipLaunchKernelGGL(bn_bwd_apply_k<false>, dim3(grid), dim3(256), 0, st, dz, y, ss, relu, coef, C, HW, bpp, (int)nitems, dy, amax);
 }
 
 extern "C" int wtpse_bn_finalize(const float* stats_partial, int nblk, int C, long long count, const float* gamma,
@@ -334,14 +361,14 @@ extern "C" int wtpse_bn_bwd_nsplit(int B, int C, int HW) {
 extern "C" int wtpse_bn_bwd(const float* dz, const float* y, const float* scale_shift, int relu, const float* gamma,
                             const float* save_mean, const float* save_invstd, float* partial, float* coef,
                             float* dgamma, float* dbeta, int accumulate, float* dy, int B, int C, int HW,
-                            void* stream) {
+                            unsigned* amax, void* stream) {
   WTPSE_REQUIRE(dz && y && scale_shift && gamma && save_mean && save_invstd && partial && coef && dgamma && dbeta && dy);
   WTPSE_REQUIRE(B > 0 && C > 0 && HW > 0);
   hipStream_t st = (hipStream_t)stream;
   // a channel of at most 32k elements with enough channels to occupy the chip: everything in one launch
   if ((long long)B * HW <= 32768 && C >= 96 && vec_ok(HW, dz, y, dy)) {
     hipLaunchKernelGGL(bn_bwd_small_k, dim3(C), dim3(1024), 0, st, dz, y, scale_shift, relu, gamma, save_mean, save_invstd,
-                       dgamma, dbeta, accumulate, dy, B, C, HW);
+                       dgamma, dbeta, accumulate, dy, B, C, HW, amax);
     return wtpse_status();
   }
   const int ns = wtpse_bn_bwd_nsplit(B, C, HW);
@@ -353,12 +380,7 @@ extern "C" int wtpse_bn_bwd(const float* dz, const float* y, const float* scale_
                        save_invstd, B, C, HW, partial);
   hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(C), dim3(256), 0, st, partial, ns, C, (double)B * HW, gamma, save_mean,
                      save_invstd, dgamma, dbeta, accumulate, coef, (const float*)nullptr, (float*)nullptr, 0);
-  if (vec_ok(HW, dz, y, dy))
-    hipLaunchKernelGGL(bn_bwd_apply_k<true>, dim3(ceil_div(HW, 1024) * B * C), dim3(256), 0, st, dz, y, scale_shift,
-                       relu, coef, C, HW, ceil_div(HW, 1024), dy);
-  else
-    hipLaunchKernelGGL(bn_bwd_apply_k<false>, dim3(ceil_div(HW, 256) * B * C), dim3(256), 0, st, dz, y, scale_shift,
-                       relu, coef, C, HW, ceil_div(HW, 256), dy);
+  launch_apply(dz, y, scale_shift, relu, coef, dy, B, C, HW, amax, st);
   return wtpse_status();
 }
 
@@ -385,19 +407,14 @@ extern "C" int wtpse_bn_bwd_reduce(const float* dz, const float* y, const float*
 extern "C" int wtpse_bn_bwd_apply(const float* dz, const float* y, const float* scale_shift, int relu, const float* gamma,
                                   const float* save_mean, const float* save_invstd, const float* sums_local,
                                   const float* sums_global, long long count_global, float* coef, float* dgamma,
-                                  float* dbeta, int accumulate, float* dy, int B, int C, int HW, void* stream) {
+                                  float* dbeta, int accumulate, float* dy, int B, int C, int HW, unsigned* amax, void* stream) {
   WTPSE_REQUIRE(dz && y && scale_shift && gamma && save_mean && save_invstd && sums_local && sums_global && coef && dgamma &&
                 dbeta && dy && B > 0 && C > 0 && HW > 0 && count_global > 0);
   hipStream_t st = (hipStream_t)stream;
   // sums_local viewed as a 1-slab partial: [1][C][2]
   hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(C), dim3(256), 0, st, sums_local, 1, C, (double)count_global, gamma, save_mean,
                      save_invstd, dgamma, dbeta, accumulate, coef, sums_global, (float*)nullptr, 0);
-  if (vec_ok(HW, dz, y, dy))
-    hipLaunchKernelGGL(bn_bwd_apply_k<true>, dim3(ceil_div(HW, 1024) * B * C), dim3(256), 0, st, dz, y, scale_shift,
-                       relu, coef, C, HW, ceil_div(HW, 1024), dy);
-  else
-    hipLaunchKernelGGL(bn_bwd_apply_k<false>, dim3(ceil_div(HW, 256) * B * C), dim3(256), 0, st, dz, y, scale_shift,
-                       relu, coef, C, HW, ceil_div(HW, 256), dy);
+  launch_apply(dz, y, scale_shift, relu, coef, dy, B, C, HW, amax, st);
   return wtpse_status();
 }
 
@@ -406,19 +423,14 @@ extern "C" int wtpse_bn_bwd_apply(const float* dz, const float* y, const float* 
 // per-workgroup (sum g, sum g * (y - mean)).  dgamma / dbeta, then dy = k1 * g + k2 * y + k3 in one elementwise pass.
 extern "C" int wtpse_bn_bwd_from_stats(const float* g, const float* y, const float* stats_partial, int nblk, const float* gamma,
                                        const float* save_mean, const float* save_invstd, float* coef, float* dgamma, float* dbeta,
-                                       int accumulate, float* dy, int B, int C, int HW, void* stream) {
+                                       int accumulate, float* dy, int B, int C, int HW, unsigned* amax, void* stream) {
   WTPSE_REQUIRE(g && y && stats_partial && gamma && save_mean && save_invstd && coef && dgamma && dbeta && dy);
   WTPSE_REQUIRE(nblk > 0 && B > 0 && C > 0 && HW > 0);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(C), dim3(256), 0, st, stats_partial, nblk, C, (double)B * HW, gamma, save_mean,
                      save_invstd, dgamma, dbeta, accumulate, coef, (const float*)nullptr, (float*)nullptr, 1);
   // (the scale/shift operand is only read for the ReLU mask: relu = 0 here, the coefficients stand in for it)
-  if (vec_ok(HW, g, y, dy))
-    hipLaunchKernelGGL(bn_bwd_apply_k<true>, dim3(ceil_div(HW, 1024) * B * C), dim3(256), 0, st, g, y, coef, 0, coef, C, HW,
-                       ceil_div(HW, 1024), dy);
-  else
-    hipLaunchKernelGGL(bn_bwd_apply_k<false>, dim3(ceil_div(HW, 256) * B * C), dim3(256), 0, st, g, y, coef, 0, coef, C, HW,
-                       ceil_div(HW, 256), dy);
+  launch_apply(g, y, coef, 0, coef, dy, B, C, HW, amax, st);
   return wtpse_status();
 }
 
@@ -436,14 +448,9 @@ extern "C" int wtpse_bn_bwd_finalize_coef(const float* stats_partial, int nblk, 
 // dy = k1 * g + k2 * y + k3 with the coefficients a data gradient's tail left in `coef` (wtpse_dgrad_bnb_coef): the whole
 // BatchNorm backward that remains once the reductions and their fold happened in the producing launch.
 extern "C" int wtpse_bn_bwd_apply_coef(const float* g, const float* y, const float* coef, float* dy, int B, int C, int HW,
-                                       void* stream) {
+                                       unsigned* amax, void* stream) {
   WTPSE_REQUIRE(g && y && coef && dy && B > 0 && C > 0 && HW > 0);
   hipStream_t st = (hipStream_t)stream;
-  if (vec_ok(HW, g, y, dy))
-    hipLaunchKernelGGL(bn_bwd_apply_k<true>, dim3(ceil_div(HW, 1024) * B * C), dim3(256), 0, st, g, y, coef, 0, coef, C, HW,
-                       ceil_div(HW, 1024), dy);
-  else
-    hipLaunchKernelGGL(bn_bwd_apply_k<false>, dim3(ceil_div(HW, 256) * B * C), dim3(256), 0, st, g, y, coef, 0, coef, C, HW,
-                       ceil_div(HW, 256), dy);
+  launch_apply(g, y, coef, 0, coef, dy, B, C, HW, amax, st);
   return wtpse_status();
 }

@@ -9,6 +9,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define WTPSE_OK 0
 #define WTPSE_EINVAL (-1)
+#define WTPSE_ESTATE (-2)     /* wtpse_plan_replay: the library's run-time switches differ from the ones the plan was recorded under */
 
 // Every launcher ends with this: launch errors (bad grid, missing code object) surface as a status code.
 static inline int wtpse_status() {
@@ -78,6 +79,66 @@ __device__ __forceinline__ void wt_split3_pair(float a, float b, unsigned& p0, u
 }
 __device__ __forceinline__ f32x4 wt_mfma16x32(u32x4 a, u32x4 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(wt_bf16x8, a), __builtin_bit_cast(wt_bf16x8, b), c, 0, 0, 0);
+}
+
+// ---- "x2h" helpers (two fp16 terms per fp32 operand, three products: conv_x3_kernels.h has the full description) shared by the
+// convolutions and the register-resident weight gradient
+constexpr int X3_WHDR = 8;                 // unsigned shorts of header in front of a packed block: float {1 / scale, scale}
+constexpr float X3_FWD_SCALE = 16.f;
+constexpr float X3_H_MAX = 65504.f;
+
+// The largest magnitude of a gradient tensor travels as an "amax table": AMAX_SHARDS unsigneds (float bits of non-negative values:
+// they order like their bit patterns), one per 64-byte line, zero before the tensor's producer runs.  Producers fold their workgroup's
+// maximum into shard (workgroup index % AMAX_SHARDS) with one no-return atomic max — a few thousand workgroups finishing together
+// on ONE word would queue ~12 ns each at the memory side (MI355X_MICROARCH.md, fan-in); consumers take the maximum of the shards.
+constexpr int AMAX_SHARDS = 16, AMAX_STRIDE = 16, AMAX_WORDS = AMAX_SHARDS * AMAX_STRIDE;
+__device__ __forceinline__ unsigned amax_bits(float v) { return __builtin_bit_cast(unsigned, v) & 0x7FFFFFFFu; }
+__device__ __forceinline__ unsigned amax_bits4(f32x4 v) {
+  return max(max(amax_bits(v[0]), amax_bits(v[1])), max(amax_bits(v[2]), amax_bits(v[3])));
+}
+// every thread of the workgroup calls (blockDim.x a multiple of 64, at most 1024); m: the thread's own maximum
+__device__ __forceinline__ void amax_publish_block(unsigned* table, unsigned m, unsigned shard_seed) {
+  __shared__ unsigned amax_red[16];
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+  const int nw = (int)(blockDim.x >> 6);
+  if ((threadIdx.x & 63) == 0) amax_red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < nw; ++i) m = max(m, amax_red[i]);
+    if (m) (void)__hip_atomic_fetch_max(table + (shard_seed % AMAX_SHARDS) * AMAX_STRIDE, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+// consumer side (any full wave): the maximum over the shards, wave-uniform
+__device__ __forceinline__ unsigned amax_read(const unsigned* table) {
+  unsigned v = table[(threadIdx.x & (AMAX_SHARDS - 1)) * AMAX_STRIDE];
+  for (int o = AMAX_SHARDS / 2; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o, 64));
+  return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
+
+// power of two S with amax * S in [2^14, 2^15) (amax: float bits of a non-negative value); 1 for 0 / denormal / inf / nan
+__device__ __host__ __forceinline__ float x3_scale_from_amax(unsigned bits) {
+  const int e = (int)((bits >> 23) & 0xFFu);
+  if (e == 0 || e == 255) return 1.f;
+  int se = 268 - e;                         // biased exponent of 2^(14 - (e - 127))
+  se = se > 253 ? 253 : se;
+  const unsigned sb = (unsigned)se << 23;
+  return __builtin_bit_cast(float, sb);
+}
+
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_h_rne(float a, float b) {
+  h16x2 v = {(_Float16)a, (_Float16)b};
+  return __builtin_bit_cast(unsigned, v);
+}
+// (a, b) -> two dwords holding the fp16 pairs (h0(a), h0(b)), (h1(a), h1(b)); saturating: beyond +-65504 the leading term is clamped
+// (a wrong but finite value — the scales above keep every sane tensor far from it) instead of turning into inf - inf = NaN
+__device__ __forceinline__ void split2h_pair(float a, float b, unsigned& p0, unsigned& p1) {
+  a = __builtin_amdgcn_fmed3f(a, -X3_H_MAX, X3_H_MAX);
+  b = __builtin_amdgcn_fmed3f(b, -X3_H_MAX, X3_H_MAX);
+  const h16x2 v = {(_Float16)a, (_Float16)b};
+  p0 = __builtin_bit_cast(unsigned, v);
+  p1 = pack_h_rne(a - (float)v[0], b - (float)v[1]);
 }
 
 // ---- BatchNorm-backward coefficients from the epilogue of the data gradient that produced the statistics (conv.hip, conv_x3.hip:

@@ -787,7 +787,7 @@ extern "C" int wtpse_conv16_x3(const float* in0, int C0, const unsigned short* w
 extern "C" int wtpse_dgrad_x3_bnb_tail(const float* dy, int C, const unsigned short* wpacked, float* out0, float* out1, int Csplit,
                                        const float* bn_y, const float* bn_ss, const float* bn_mean, int bn_relu, int bn_c0,
                                        int bn_c1, float* stats, const BnbTail* tail, int B, int H, int W, int Cout, int ksize,
-                                       void* stream);
+                                       const unsigned* in_amax, void* stream);
 
 extern "C" int wtpse_conv_fwd_x3_ftail(const float* in0, int C0, const float* in1, int C1, const unsigned short* wpacked,
                                        const float* bias, const float* pro0, const float* pro1, int pro_relu, float* out0,
@@ -826,7 +826,7 @@ extern "C" int wtpse_dgrad_bnb_coef(const float* dy, int C, const void* wpacked,
                                     const float* bn_y, const float* bn_ss, const float* bn_mean, int bn_relu, int bn_c0, int bn_c1,
                                     float* stats, const float* gamma, const float* invstd, float* coef, float* dgamma,
                                     float* dbeta, int accumulate, double* partial2, unsigned* tickets, int B, int H, int W,
-                                    int Cout, int ksize, void* stream) {
+                                    int Cout, int ksize, const unsigned* in_amax, void* stream) {
   WTPSE_REQUIRE(bn_y && bn_ss && bn_mean && stats && gamma && invstd && coef && dgamma && dbeta && partial2 && tickets);
   WTPSE_REQUIRE(layout >= 0 && layout <= 2);
   BnbTail t = bnb_tail_none();
@@ -834,7 +834,7 @@ extern "C" int wtpse_dgrad_bnb_coef(const float* dy, int C, const void* wpacked,
   t.accumulate = accumulate;
   if (layout == 1)
     return wtpse_dgrad_x3_bnb_tail(dy, C, static_cast<const unsigned short*>(wpacked), out0, out1, Csplit, bn_y, bn_ss, bn_mean,
-                                   bn_relu, bn_c0, bn_c1, stats, &t, B, H, W, Cout, ksize, stream);
+                                   bn_relu, bn_c0, bn_c1, stats, &t, B, H, W, Cout, ksize, in_amax, stream);
   if (layout == 2) {
     WTPSE_REQUIRE(ksize == 3 && !out1 && Csplit == Cout && bn_c0 == 0 && bn_c1 == Cout);
     return conv16_x3_impl(dy, C, static_cast<const unsigned short*>(wpacked), nullptr, nullptr, 0, out0, stats, nullptr, bn_y, bn_ss,

@@ -30,13 +30,20 @@ struct Cmd {
 };
 struct Plan {
   std::vector<Cmd> cmds;
+  int tuning;          // wtpse_tuning_state() when the plan was created: the recorded calls were sized for this tiling / weight format
 };
 }  // namespace
+
+extern "C" int wtpse_tuning_state(void);      // conv_x3.hip
 
 extern "C" int wtpse_plan_fn_count(void) { return PLAN_NFN; }
 extern "C" const char* wtpse_plan_fn_name(int id) { return (id >= 0 && id < PLAN_NFN) ? PLAN_FN_NAMES[id] : ""; }
 
-extern "C" void* wtpse_plan_create(void) { return new Plan(); }
+extern "C" void* wtpse_plan_create(void) {
+  Plan* p = new Plan();
+  p->tuning = wtpse_tuning_state();
+  return p;
+}
 
 extern "C" int wtpse_plan_destroy(void* plan) {
   Plan* p = static_cast<Plan*>(plan);
@@ -75,6 +82,9 @@ extern "C" int wtpse_plan_add_wait(void* plan, void* waiter, void* waited) {
 extern "C" int wtpse_plan_replay(void* plan) {
   Plan* p = static_cast<Plan*>(plan);
   WTPSE_REQUIRE(p);
+  // wtpse_x3_terms / wtpse_x3r_enable / wtpse_x3_xcd changed since the recording: the recorded buffer sizes may no longer fit the
+  // tiling the entry points would choose now, the packed weights may be in another format
+  if (p->tuning != wtpse_tuning_state()) return WTPSE_ESTATE;
   for (Cmd& c : p->cmds) {
     if (c.fn >= 0) {
       const int rc = PLAN_THUNKS[c.fn](c.args, c.stream);

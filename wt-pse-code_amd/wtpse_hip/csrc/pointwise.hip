@@ -295,13 +295,14 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_k(const float* __restrict_
 template <bool BN>
 __global__ __launch_bounds__(256) void upsample2x_bwd_v_k(const float* __restrict__ dout, float* __restrict__ dx, int accumulate,
                                                           int BC, int H, int W, const float* __restrict__ bn_y,
-                                                          const float* __restrict__ bn_coef, int C) {
+                                                          const float* __restrict__ bn_coef, int C, unsigned* __restrict__ amax) {
   const int Ho = 2 * H, Wo = 2 * W, W4 = W / 4;
   const int j = blockIdx.x * 256 + threadIdx.x;   // over H*(W/4)
-  if (j >= H * W4) return;
+  const bool live = j < H * W4;
   const int k = j % W4, yy = j / W4;
   const int xb = 4 * k;            // first dx column; dout columns 2*xb-1 .. 2*xb+8
-  for (int bc = blockIdx.y; bc < BC; bc += gridDim.y) {
+  unsigned am = 0u;                // largest |dx| this thread wrote (amax table of dx, common.h)
+  for (int bc = blockIdx.y; live && bc < BC; bc += gridDim.y) {
     const float* src = dout + (size_t)bc * Ho * Wo;
     float k1 = 1.f, k2 = 0.f, k3 = 0.f;
     if (BN) {
@@ -350,7 +351,9 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_v_k(const float* __restric
       o = make_float4(p.x + o.x, p.y + o.y, p.z + o.z, p.w + o.w);
     }
     *reinterpret_cast<float4*>(dst) = o;
+    am = max(am, max(max(amax_bits(o.x), amax_bits(o.y)), max(amax_bits(o.z), amax_bits(o.w))));
   }
+  if (amax) amax_publish_block(amax, am, blockIdx.x + blockIdx.y);
 }
 
 // F.interpolate(x, size=(Ho,Wo), mode="bilinear") with align_corners=False (Trainer.py:206-209): validation resizes the
@@ -769,21 +772,36 @@ extern "C" int wtpse_upsample2x_fwd_stats(const float* x, float* out, float* sta
   hipLaunchKernelGGL(upsample2x_fwd4_v_k, PLANE_GRID((H + 1) * (W / 2), B * C), dim3(256), 0, ST, x, nullptr, 0, out, stats, B * C, C, H, W);
   return wtpse_status();
 }
-extern "C" int wtpse_upsample2x_bwd(const float* dout, float* dx, int accumulate, int B, int C, int H, int W, void* stream) {
+// amax (optional): the amax table (common.h) of dx, ZERO on entry — dx is the dY of the 1x1 convolution in front of the upsampling.
+// With it the launch is capped at ~4096 workgroups (one atomic each at the end; the planes loop inside the kernel).
+static inline dim3 up_bwd_grid(int per_plane, int planes, bool with_amax) {
+  const unsigned gx = (unsigned)((per_plane + 255) / 256);
+  unsigned gy = (unsigned)(planes < 32768 ? planes : 32768);
+  if (with_amax) {
+    const unsigned cap = gx >= 4096u ? 1u : 4096u / gx;
+    if (gy > cap) gy = cap;
+  }
+  return dim3(gx, gy);
+}
+extern "C" int wtpse_amax(const float* x, long long n, unsigned* amax_table, void* stream);
+extern "C" int wtpse_upsample2x_bwd(const float* dout, float* dx, int accumulate, int B, int C, int H, int W, unsigned* amax, void* stream) {
   WTPSE_REQUIRE(dout && dx && B > 0 && C > 0 && H > 0 && W > 0);
   long long total = (long long)B * C * H * W;
-  if (W % 4 == 0 && (((uintptr_t)dout | (uintptr_t)dx) & 15) == 0)
-    hipLaunchKernelGGL(upsample2x_bwd_v_k<false>, PLANE_GRID(H * (W / 4), B * C), dim3(256), 0, ST, dout, dx, accumulate, B * C, H, W,
-                       nullptr, nullptr, C);
-  else
-    hipLaunchKernelGGL(upsample2x_bwd_k, GRID1(total), dim3(256), 0, ST, dout, dx, accumulate, H, W, total);
-  return wtpse_status();
+  if (W % 4 == 0 && (((uintptr_t)dout | (uintptr_t)dx) & 15) == 0) {
+    hipLaunchKernelGGL(upsample2x_bwd_v_k<false>, up_bwd_grid(H * (W / 4), B * C, amax != nullptr), dim3(256), 0, ST, dout, dx, accumulate,
+                       B * C, H, W, nullptr, nullptr, C, amax);
+    return wtpse_status();
+  }
+  hipLaunchKernelGGL(upsample2x_bwd_k, GRID1(total), dim3(256), 0, ST, dout, dx, accumulate, H, W, total);
+  const int rc = wtpse_status();
+  return (rc || !amax) ? rc : wtpse_amax(dx, total, amax, stream);
 }
 extern "C" int wtpse_upsample2x_bwd_bn(const float* g, const float* bn_y, const float* bn_coef, float* dx, int B, int C, int H, int W,
-                                       void* stream) {
+                                       unsigned* amax, void* stream) {
   WTPSE_REQUIRE(g && bn_y && bn_coef && dx && B > 0 && C > 0 && H > 0 && W > 0 && W % 4 == 0);
   WTPSE_REQUIRE((((uintptr_t)g | (uintptr_t)bn_y | (uintptr_t)dx) & 15) == 0);
-  hipLaunchKernelGGL(upsample2x_bwd_v_k<true>, PLANE_GRID(H * (W / 4), B * C), dim3(256), 0, ST, g, dx, 0, B * C, H, W, bn_y, bn_coef, C);
+  hipLaunchKernelGGL(upsample2x_bwd_v_k<true>, up_bwd_grid(H * (W / 4), B * C, amax != nullptr), dim3(256), 0, ST, g, dx, 0, B * C, H, W,
+                     bn_y, bn_coef, C, amax);
   return wtpse_status();
 }
 extern "C" int wtpse_resize_bilinear(const float* x, float* out, int B, int C, int H, int W, int Ho, int Wo, void* stream) {
@@ -819,6 +837,34 @@ extern "C" int wtpse_copy_probe(const float* src, float* dst, long long n, int b
     hipLaunchKernelGGL(copy_w16_k, dim3(8192), dim3(256), 0, ST, reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst), n / 4);
   else
     hipLaunchKernelGGL(copy_w4_k, dim3(16384), dim3(256), 0, ST, src, dst, n);
+  return wtpse_status();
+}
+// ---- largest magnitude of a tensor into an amax table (common.h; wtpse_x3_terms == 2: the power-of-two scale of a gradient operand,
+// wtpse_hip.h).  NaN patterns sort above inf and make the consumer fall back to scale 1, where the NaN propagates as it would anyway.
+__global__ __launch_bounds__(256) void amax_k(const float* __restrict__ x, long long n, unsigned* __restrict__ table) {
+  unsigned m = 0u;
+  const long long n4 = n >> 2;
+  const uint4* x4 = reinterpret_cast<const uint4*>(x);
+  if ((reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+      const uint4 v = x4[i];
+      m = max(max(m, v.x & 0x7FFFFFFFu), max(v.y & 0x7FFFFFFFu, max(v.z & 0x7FFFFFFFu, v.w & 0x7FFFFFFFu)));
+    }
+    for (long long i = (n4 << 2) + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+      m = max(m, __float_as_uint(x[i]) & 0x7FFFFFFFu);
+  } else {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+      m = max(m, __float_as_uint(x[i]) & 0x7FFFFFFFu);
+  }
+  amax_publish_block(table, m, blockIdx.x);
+}
+extern "C" int wtpse_amax(const float* x, long long n, unsigned* amax_table, void* stream) {
+  WTPSE_REQUIRE(amax_table && n >= 0 && (x || n == 0));
+  if (hipMemsetAsync(amax_table, 0, AMAX_WORDS * sizeof(unsigned), ST) != hipSuccess) return wtpse_status();
+  if (n > 0) {
+    const long long blocks = (n / 4 + 255) / 256 + 1;
+    hipLaunchKernelGGL(amax_k, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, ST, x, n, amax_table);
+  }
   return wtpse_status();
 }
 extern "C" int wtpse_axpy(float* dst, const float* src, float alpha, long long n, void* stream) {

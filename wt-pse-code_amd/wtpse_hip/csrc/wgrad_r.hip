@@ -39,6 +39,10 @@ struct WgradRArgs {
   const float* bn_coef;
   float* slab;     // [nslab][Cout][Cin][9]
   float* slab_b;   // [nslab_b][Cout] or null
+  // TERMS 2 (two fp16 terms per operand, conv_x3_kernels.h): dY is multiplied by the power of two that brings its largest magnitude
+  // (dy_amax: its amax table, common.h, from its producer / wtpse_amax; null: X3_FWD_SCALE) into [2^14, 2^15), X by X3_FWD_SCALE as it is loaded;
+  // the slabs are scaled back as they are written
+  const unsigned* dy_amax;
   int B, H, W, C0, C1, Cin, Cout;
   int pro_relu;
   int strips;      // W / 32
@@ -73,8 +77,10 @@ __device__ __forceinline__ void wr_split3_pair(float a, float b, unsigned& p0, u
   p2 = wr_pack_rne(sa, sb);
 }
 
+template <int TERMS>
 __device__ __forceinline__ f32x4 mfma16x32(u32x4v a, u32x4v b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  if constexpr (TERMS == 2) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
 // 8 fp32 values -> three fragments (4 dwords each) of bf16 terms
@@ -94,16 +100,19 @@ __device__ __forceinline__ f32x4 mfma16x32(u32x4v a, u32x4v b, f32x4 c) {
 // their SIMD to themselves: four waves
 template <int MF, int NF> struct WgradRGeom { static constexpr int NW = (MF * NF >= 2) ? 4 : 8; };
 
-// TERMS: bf16 terms per fp32 operand — 3 (x3 arithmetic, six products per multiply) or 1 (bf16 mode: wtpse_x3_terms, conv_x3.hip)
+// TERMS: 16-bit terms per fp32 operand — 3 (x3: three bf16 terms, six products per multiply), 2 (x2h: two fp16 terms, three products,
+// power-of-two operand scaling; the host launches PRO = true, the scale rides in the prologue coefficients) or 1 (bf16 mode) — wtpse_x3_terms
 // TWIN: W == 16, two images per 32-pixel step (WgradRArgs::twin) — a template flag: the seam masks and per-lane image offsets cost the
 // row step ~10 % when they were run-time selects in every instantiation (the step is bound by its vector-instruction count)
 template <int MF, int NF, bool PRO, bool BIAS, bool AFF = false, int TERMS = 3, bool TWIN = false>
 __global__ __launch_bounds__((64 * WgradRGeom<MF, NF>::NW), 1) void wgrad_r_k(WgradRArgs a) {
-  static_assert(TERMS == 3 || TERMS == 1, "three bf16 terms or one");
+  static_assert(TERMS >= 1 && TERMS <= 3, "three bf16 terms, two fp16 terms or one bf16 term");
+  static_assert(TERMS != 2 || (PRO && !AFF), "x2h: the X scale rides in the prologue; the fused-BatchNorm form has no amax of the dY it forms");
   constexpr int NT = 9, NW = WgradRGeom<MF, NF>::NW;
   // (a, b) -> TERMS dwords of packed bf16 pairs
   auto split_pair = [](float v0, float v1, unsigned (&q)[TERMS]) __attribute__((always_inline)) {
     if constexpr (TERMS == 3) wr_split3_pair(v0, v1, q[0], q[1], q[2]);
+    else if constexpr (TERMS == 2) split2h_pair(v0, v1, q[0], q[1]);
     else q[0] = wr_pack_rne(v0, v1);
   };
   // (the wave id is wave-uniform, but only readfirstlane tells the compiler: everything derived from it — the unit, the image,
@@ -117,6 +126,8 @@ __global__ __launch_bounds__((64 * WgradRGeom<MF, NF>::NW), 1) void wgrad_r_k(Wg
   const int u0 = (int)((long long)wv * a.units / a.wpp), u1 = (int)((long long)(wv + 1) * a.units / a.wpp);
   const int HW = a.H * a.W;
   const unsigned W4 = (unsigned)a.W * 4u;
+  const float sx = TERMS == 2 ? X3_FWD_SCALE : 1.f;
+  const float sdy = TERMS == 2 ? (a.dy_amax ? x3_scale_from_amax(amax_read(a.dy_amax)) : X3_FWD_SCALE) : 1.f;
 
   f32x4 acc[MF][NF][NT];
 #pragma unroll
@@ -149,6 +160,7 @@ __global__ __launch_bounds__((64 * WgradRGeom<MF, NF>::NW), 1) void wgrad_r_k(Wg
       const float* pro = xfirst[n] ? a.pro0 : a.pro1;
       if (pro) { psc[n] = pro[2 * xch[n]]; psh[n] = pro[2 * xch[n] + 1]; }
       if (a.pro_relu & (xfirst[n] ? 1 : 2)) plo[n] = 0.f;
+      if (TERMS == 2) { psc[n] *= sx; psh[n] *= sx; }     // (exact: a power of two commutes with the rounding of the fma and with the ReLU)
     }
   }
   float ak1[MF], ak2[MF], ak3[MF];
@@ -265,6 +277,7 @@ __global__ __launch_bounds__((64 * WgradRGeom<MF, NF>::NW), 1) void wgrad_r_k(Wg
           v1 = fmaf(ak1[m], v1, fmaf(ak2[m], rawb[SA][m][q >> 1][2 * (q & 1) + 1], ak3v[SA][m]));
         }
         if (BIAS) bsum[m] += (double)v0 + (double)v1;
+        if (TERMS == 2) { v0 *= sdy; v1 *= sdy; }
         unsigned qq[TERMS];
         split_pair(v0, v1, qq);
 #pragma unroll
@@ -335,20 +348,22 @@ __global__ __launch_bounds__((64 * WgradRGeom<MF, NF>::NW), 1) void wgrad_r_k(Wg
           constexpr int slot = (J + 1 - ky + 4) & 3;         // dY row r + 1 - ky
           f32x4 v = acc[m][n][ky * 3 + kx];
           if constexpr (TERMS == 3) {      // the six leading cross terms, smallest first (as conv_x3.hip)
-            v = mfma16x32(ay[slot][m][0], xs[kx][2], v);
-            v = mfma16x32(ay[slot][m][1], xs[kx][1], v);
-            v = mfma16x32(ay[slot][m][2], xs[kx][0], v);
-            v = mfma16x32(ay[slot][m][0], xs[kx][1], v);
-            v = mfma16x32(ay[slot][m][1], xs[kx][0], v);
+            v = mfma16x32<3>(ay[slot][m][0], xs[kx][2], v);
+            v = mfma16x32<3>(ay[slot][m][1], xs[kx][1], v);
+            v = mfma16x32<3>(ay[slot][m][2], xs[kx][0], v);
           }
-          v = mfma16x32(ay[slot][m][0], xs[kx][0], v);
+          if constexpr (TERMS >= 2) {
+            v = mfma16x32<TERMS>(ay[slot][m][0], xs[kx][1], v);
+            v = mfma16x32<TERMS>(ay[slot][m][1], xs[kx][0], v);
+          }
+          v = mfma16x32<TERMS>(ay[slot][m][0], xs[kx][0], v);
           acc[m][n][ky * 3 + kx] = v;
           constexpr int cg = n * 9 * MF + c;                 // chain index within the step
           constexpr int plo_ = (cg * NP + NC - 1) / NC, phi_ = ((cg + 1) * NP + NC - 1) / NC;
           static_for<phi_ - plo_>([&](auto pp) { piece(IC<plo_ + decltype(pp)::value>{}, IC<CS>{}, IC<AS>{}, r + 2); });
 #ifndef WGRAD_R_NO_INTERLEAVE
 #pragma unroll
-          for (int i = 0; i < (TERMS == 3 ? 6 : 1); ++i) {
+          for (int i = 0; i < (TERMS == 3 ? 6 : TERMS == 2 ? 3 : 1); ++i) {
             __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);      // 1 MFMA
             __builtin_amdgcn_sched_group_barrier(0x2, 2, 0);      // 2 VALU
           }
@@ -403,6 +418,7 @@ __global__ __launch_bounds__((64 * WgradRGeom<MF, NF>::NW), 1) void wgrad_r_k(Wg
   // ---- the four waves' partial sums meet in LDS, one vertical tap (3 x MF x NF tiles) at a time
   __shared__ f32x4 red[NW][3 * MF * NF][64];
   float* out = a.slab + (size_t)wg * a.Cout * a.Cin * NT;      // slab `wg`: every pair writes its own (cout, cin) block of it
+  const float unscale = TERMS == 2 ? 1.f / (sx * sdy) : 1.f;
 #pragma unroll
   for (int ky = 0; ky < 3; ++ky) {
     __syncthreads();
@@ -422,7 +438,7 @@ __global__ __launch_bounds__((64 * WgradRGeom<MF, NF>::NW), 1) void wgrad_r_k(Wg
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int co = cout0 + 16 * m + 4 * (l >> 4) + i;
-        out[((size_t)co * a.Cin + ci) * NT + ky * 3 + kx] = s[i];
+        out[((size_t)co * a.Cin + ci) * NT + ky * 3 + kx] = TERMS == 2 ? s[i] * unscale : s[i];
       }
     }
   }
@@ -506,7 +522,7 @@ extern "C" void wtpse_wgrad_reduce_launch2(const float* slab, int ksplit, int n,
 static int wgrad_r_impl(const float* dy, const float* x0, int C0, const float* x1, int C1, const float* pro0,
                         const float* pro1, int pro_relu, float* slab, float* dbias_slab, int nslab, float* dw,
                         float* dbias, int accumulate, int B, int H, int W, int Cout, const float* bn_y, const float* bn_coef,
-                        void* stream) {
+                        const unsigned* dy_amax, void* stream) {
   WTPSE_REQUIRE(dy && x0 && slab && dw && B > 0 && H > 0 && W > 0 && C0 > 0 && C1 >= 0 && Cout > 0);
   WTPSE_REQUIRE((C1 == 0) == (x1 == nullptr));
   WTPSE_REQUIRE((dbias == nullptr) == (dbias_slab == nullptr));
@@ -521,7 +537,7 @@ static int wgrad_r_impl(const float* dy, const float* x0, int C0, const float* x
   WTPSE_REQUIRE((long long)(C0 > C1 ? C0 : C1) * H * W * 4 < (1ll << 31) && (long long)Cout * H * W * 4 < (1ll << 31));
   WgradRArgs a;
   a.dy = dy; a.x0 = x0; a.x1 = x1; a.pro0 = pro0; a.pro1 = pro1; a.slab = slab; a.slab_b = dbias_slab;
-  a.bn_y = bn_y; a.bn_coef = bn_coef;
+  a.bn_y = bn_y; a.bn_coef = bn_coef; a.dy_amax = dy_amax;
   a.B = B; a.H = H; a.W = W; a.C0 = C0; a.C1 = C1; a.Cin = Cin; a.Cout = Cout; a.pro_relu = pro_relu;
   a.strips = p.strips; a.nseg = p.nseg; a.rseg = p.rseg; a.units = p.units; a.wpp = p.wpp; a.nci = p.nci; a.twin = W == 16 ? 1 : 0;
   const bool pro = pro0 != nullptr || pro1 != nullptr || pro_relu != 0;
@@ -539,6 +555,20 @@ static int wgrad_r_impl(const float* dy, const float* x0, int C0, const float* x
 #define WR_LAUNCH1(M, N) do { \
     if (pro) hipLaunchKernelGGL((wgrad_r_k<M, N, true, false, false, 1>), grid, blk, 0, st, a); \
     else hipLaunchKernelGGL((wgrad_r_k<M, N, false, false, false, 1>), grid, blk, 0, st, a); } while (0)
+  // x2h (wtpse_x3_terms(2)): every block shape, PRO always on (the X scale rides in the prologue coefficients); the fused-BatchNorm
+  // form (aff) stays on three bf16 terms (nothing knows the largest magnitude of a dY that is never materialised)
+#define WR_LAUNCH2(M, N) hipLaunchKernelGGL((wgrad_r_k<M, N, true, false, false, 2>), grid, blk, 0, st, a)
+  if (g_x3_terms == 2 && !aff) {
+    if (a.twin) {
+      WTPSE_REQUIRE(p.mf == 2 && p.nf == 2 && !bias);
+      hipLaunchKernelGGL((wgrad_r_k<2, 2, true, false, false, 2, true>), grid, blk, 0, st, a);
+    } else if (p.mf == 2 && p.nf == 2) WR_LAUNCH2(2, 2);
+    else if (p.mf == 2) WR_LAUNCH2(2, 1);
+    else if (p.nf == 2) WR_LAUNCH2(1, 2);
+    else if (bias) hipLaunchKernelGGL((wgrad_r_k<1, 1, true, true, false, 2>), grid, blk, 0, st, a);
+    else WR_LAUNCH2(1, 1);
+  } else
+#undef WR_LAUNCH2
   if (a.twin) {        // 16-pixel-wide maps: 32 x 32 blocks, no bias gradient, dY materialised
     WTPSE_REQUIRE(p.mf == 2 && p.nf == 2 && !bias && !aff);
     if (g_x3_terms == 1) {
@@ -572,9 +602,9 @@ static int wgrad_r_impl(const float* dy, const float* x0, int C0, const float* x
 // Same contract as wtpse_conv_wgrad (include/wtpse_hip.h), 3x3 only; requires wtpse_wgrad_r_supported().
 extern "C" int wtpse_conv_wgrad_r(const float* dy, const float* x0, int C0, const float* x1, int C1, const float* pro0,
                                   const float* pro1, int pro_relu, float* slab, float* dbias_slab, int nslab, float* dw,
-                                  float* dbias, int accumulate, int B, int H, int W, int Cout, void* stream) {
+                                  float* dbias, int accumulate, int B, int H, int W, int Cout, const unsigned* dy_amax, void* stream) {
   return wgrad_r_impl(dy, x0, C0, x1, C1, pro0, pro1, pro_relu, slab, dbias_slab, nslab, dw, dbias, accumulate, B, H, W, Cout,
-                      nullptr, nullptr, stream);
+                      nullptr, nullptr, dy_amax, stream);
 }
 
 // The same with dY given as the un-applied second half of a BatchNorm backward: dY = k1[c] * g + k2[c] * bn_y + k3[c],
@@ -584,5 +614,5 @@ extern "C" int wtpse_conv_wgrad_r_bn(const float* g, const float* bn_y, const fl
                                      int nslab, float* dw, int accumulate, int B, int H, int W, int Cout, void* stream) {
   WTPSE_REQUIRE(bn_y && bn_coef);
   return wgrad_r_impl(g, x0, C0, x1, C1, pro0, pro1, pro_relu, slab, nullptr, nslab, dw, nullptr, accumulate, B, H, W, Cout, bn_y,
-                      bn_coef, stream);
+                      bn_coef, nullptr, stream);
 }

@@ -144,10 +144,11 @@ class DataParallel:
                t.invstd.data_ptr(), partial.data_ptr(), s_local.data_ptr(), B, C, H * W, ops.stream_ptr())
         s_global = self.allreduce_sum(s_local.clone())
         dy = torch.empty_like(t.y)
+        dy.wt_amax = ops._amax_table(dy.device)
         L.call("wtpse_bn_bwd_apply", dz.data_ptr(), t.y.data_ptr(), t.ss.data_ptr(), int(t.relu), bn.weight.data_ptr(),
                t.mean.data_ptr(), t.invstd.data_ptr(), s_local.data_ptr(), s_global.data_ptr(), B * H * W * self.world,
                coef.data_ptr(), root.gview(bn.weight).data_ptr(), root.gview(bn.bias).data_ptr(), 0, dy.data_ptr(), B, C,
-               H * W, ops.stream_ptr())
+               H * W, ops.ptr(dy.wt_amax), ops.stream_ptr())
         return dy
 
     # -------------------------------------------------------------------------------------------- WT loss

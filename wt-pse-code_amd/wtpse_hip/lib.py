@@ -114,6 +114,9 @@ class _Lib:
 
     def plan_replay(self, plan):
         rc = self._raw_wtpse_plan_replay(plan)
+        if rc == -2:
+            raise WtpseError("wtpse_plan_replay refused: wtpse_x3_terms / wtpse_x3r_enable / wtpse_x3_xcd changed since the plan was "
+                             "recorded (the recorded buffer sizes and packed weights belong to the old setting): record a new plan")
         if rc:
             raise WtpseError("wtpse_plan_replay failed with status %d" % rc)
 

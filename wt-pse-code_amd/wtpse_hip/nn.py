@@ -295,6 +295,7 @@ class HipNet(nn.Module):
         object.__setattr__(self, "_x16desc", torch.tensor(xdesc, dtype=torch.int32).to(dev) if xdesc else None)
         object.__setattr__(self, "_flag", torch.zeros(1, dtype=torch.int32, device=dev))
         ops._tickets(0, dev)          # the ticket ring of the self-folding data gradients: created outside any stream capture
+        ops.amax_begin(dev)           # ... and the arena of the gradients' amax tables (x2h arithmetic)
         # position in this network's Philox stream.  It lives in device memory (advanced by a one-thread launch after each
         # draw) so that nothing that changes from step to step is passed to a kernel by value: a captured step (hipGraph)
         # then draws fresh noise on every replay, and eager and captured runs see the same stream.
@@ -310,7 +311,8 @@ class HipNet(nn.Module):
         optimiser, vouches for the packed copy through `_packed_valid`."""
         if not self._is_flat():
             self._flatten()
-        if self._packed_version < 0 or (repack and not self._packed_valid):
+        terms = ops.x3_terms()       # the packed x3 weights are in the format of the arithmetic they were packed under
+        if self._packed_version < 0 or (repack and not self._packed_valid) or self._packed_version != terms:
             ops.lib().call("wtpse_pack_conv_weights", self._flat.data_ptr(), self._desc.data_ptr(), len(self._convs),
                            self._packed.data_ptr(), ops.stream_ptr())
             if self._xdesc is not None:
@@ -319,7 +321,7 @@ class HipNet(nn.Module):
             if self._x16desc is not None:
                 ops.lib().call("wtpse_pack_conv16_x3", self._flat.data_ptr(), self._x16desc.data_ptr(), len(self._x16_convs),
                                self._x3.data_ptr(), ops.stream_ptr())
-            object.__setattr__(self, "_packed_version", 1)
+            object.__setattr__(self, "_packed_version", terms)
 
     def invalidate_packed(self):
         object.__setattr__(self, "_packed_version", -1)
@@ -346,6 +348,7 @@ class HipNet(nn.Module):
         """Choose the buffer this backward writes into: the attached flat gradient when every .grad is None
         (the normal zero_grad(set_to_none=True) flow), a work buffer otherwise (accumulation semantics)."""
         self._touched.clear()
+        ops.amax_begin(self._flat.device)      # the amax tables of the previous pass are free again (zeroed: one launch)
         clean = all(p.grad is None for p in self._plist)
         if clean:
             object.__setattr__(self, "_gtarget", self._gflat)
@@ -523,6 +526,12 @@ BN_FUSED_STATS = os.environ.get("WTPSE_BN_FUSED_STATS", "1") != "0"
 BN_TAIL = os.environ.get("WTPSE_BN_TAIL", "1") != "0"
 
 
+def _gamax(dy):
+    """x2h arithmetic (ops.x3_terms() == 2): the device slot with the largest magnitude of the gradient `dy` — left on the tensor by
+    its producer, or computed by one extra pass (ops.amax_of).  None otherwise."""
+    return ops.amax_of(dy) if ops.x3_terms() == 2 else None
+
+
 def _dgrad(layer, dy, split=None, mask_ref=None, below0=None, below1=None):
     """Data gradient; mask_ref fuses the ReLU backward of the tensor the gradient flows into (d * [ref > 0]).
     below0 / below1: tape of the conv + BatchNorm layer whose activated output the first / second returned gradient is taken
@@ -540,7 +549,7 @@ def _dgrad(layer, dy, split=None, mask_ref=None, below0=None, below1=None):
         else:
             layout, wptr = 0, root.packed_ptr(layer.wd_off)
         d0, d1, stats, coef = ops.dgrad_bnb(dy, wptr, layout, layer.cin, layer.k, below.y, below.ss, below.mean, below.relu, split,
-                                            below1 is not None and below0 is None, tail)
+                                            below1 is not None and below0 is None, tail, _gamax(dy) if layout == 1 else None)
         if below0 is not None:
             return PreBN(d0, stats, coef), d1
         return d0, PreBN(d1, stats, coef)
@@ -548,7 +557,7 @@ def _dgrad(layer, dy, split=None, mask_ref=None, below0=None, below1=None):
         return ops.conv16_x3(dy, root.x3_ptr(layer.x16d_off), None, layer.cin, mask_ref=mask_ref)[0], None
     if layer.xd_off >= 0:
         return ops.conv_fwd_x3(dy, None, root.x3_ptr(layer.xd_off), None, layer.cin, layer.k, None, 0, False, False, split,
-                               mask_ref)[:2]
+                               mask_ref, None, _gamax(dy))[:2]
     return ops.conv_fwd(dy, None, root.packed_ptr(layer.wd_off), None, layer.cin, layer.k, None, 0, False, False, split,
                         mask_ref)[:2]
 
@@ -606,13 +615,14 @@ def _wgrad_side(layer, dy, a0, a1=None):
     root = layer._root
     if not WGRAD_SIDE_STREAM:
         return _wgrad(layer, dy, a0, a1, with_bias=False)
+    amax = _gamax(dy)                # (on the main stream, in front of the fork: the data gradient that follows uses the same slot)
     main = torch.cuda.current_stream()
     side = _side_stream(dy.device)
     stream_wait(side, main)
     with torch.cuda.stream(side):
         _wgrad(layer, dy, a0, a1, with_bias=False)
     a0 = as_act(a0)
-    for t in (dy, a0.t, a0.pro) + ((as_act(a1).t, as_act(a1).pro) if a1 is not None else ()):
+    for t in (dy, amax, a0.t, a0.pro) + ((as_act(a1).t, as_act(a1).pro) if a1 is not None else ()):
         if t is not None:
             t.record_stream(side)       # the caching allocator must not hand these out again before the side stream is done
     # (Under stream capture the allocator keeps record_stream'ed blocks out of circulation until the capture ends.  Holding the
@@ -634,7 +644,7 @@ def _wgrad(layer, dy, a0, a1=None, with_bias=True):
             ops.wgrad_r_supported(layer.cin, layer.cout, 3, a0.t.shape[1] if a1 is not None else 16, a0.t.shape[3]) and
             (db is None or (layer.cin % 32 != 0 and layer.cout % 32 != 0))):
         ops.conv_wgrad_r(dy, a0.t, a1.t if a1 is not None else None, dw, db, a0.pro, _relu_bits(a0, a1), False,
-                         a1.pro if a1 is not None else None)
+                         a1.pro if a1 is not None else None, _gamax(dy))
         return
     if (X3 and X3_WGRAD and db is None and
             ops.wgrad_x3_supported(layer.cin, layer.cout, layer.k, a0.t.shape[1] if a1 is not None else 8)):

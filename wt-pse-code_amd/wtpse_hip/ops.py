@@ -107,13 +107,66 @@ def conv16_x3(in0, wx16_ptr, bias, cout, pro0=None, pro_relu=0, relu_out=False, 
 
 
 def x3_packed_size(rows, k, taps):
-    """unsigned shorts of one direction of one conv in the x3 layout (include/wtpse_hip.h)."""
-    return ((k + 15) & ~15) * ((rows + 31) & ~31) * taps * 3
+    """unsigned shorts of one direction of one conv in the x3 layout (include/wtpse_hip.h): 16 bytes of header + the term slots."""
+    return 8 + ((k + 15) & ~15) * ((rows + 31) & ~31) * taps * 3
+
+
+def x3_terms():
+    """16-bit terms per fp32 operand in the x3 kernels right now (wtpse_x3_terms: 3 x3, 2 x2h, 1 bf16 mode)."""
+    return lib().query("wtpse_x3_terms", -1)
+
+
+AMAX_WORDS = 256            # unsigneds of one amax table (include/wtpse_hip.h, wtpse_amax)
+_AMAX = {}
+_AMAX_TABLES = 512          # tables per arena (512 KB): a backward pass of the largest network hands out ~120
+
+
+def amax_begin(device):
+    """Start of a backward pass: every amax table of the device's arena is zero again and free.  ONE launch over the WHOLE arena,
+    unconditionally — the call is part of recorded launch plans / captured graphs, so what it zeroes must not depend on how many
+    tables the pass before it happened to use when the step was recorded (a conditional, sized zeroing left the replayed steps
+    with the tables of earlier steps: scales that only ever grew, results that differed from the eager step in the last bits).
+    The producers of a pass (bn_bwd_*, upsample2x_bwd*) take their tables with _amax_table(); they stay valid until the next
+    amax_begin on the device — HipNet.begin_backward() calls it on the stream the previous pass's consumers were joined into."""
+    st = _AMAX.get(device)
+    if st is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("the amax arena must exist before a step is captured: HipNet.ensure_ready() creates it")
+        st = _AMAX[device] = [torch.empty(_AMAX_TABLES * AMAX_WORDS, dtype=torch.int32, device=device), 0]
+    zero_(st[0])           # (whatever the arithmetic: 512 KB, ~2 us — a table handed out is zero, always)
+    st[1] = 0
+
+
+def _amax_table(device):
+    """A zeroed amax table for a producer, or None when the x2h arithmetic is off (nothing would read it)."""
+    if x3_terms() != 2:
+        return None
+    st = _AMAX.get(device)
+    if st is None or st[1] >= _AMAX_TABLES:        # no arena yet / exhausted (micro-benchmarks looping without begin_backward)
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("amax arena exhausted inside a captured step")
+        return torch.zeros(AMAX_WORDS, dtype=torch.int32, device=device)
+    t = st[0][st[1] * AMAX_WORDS:(st[1] + 1) * AMAX_WORDS]
+    st[1] += 1
+    return t
+
+
+def amax_of(t):
+    """The amax table (int32 tensor [256]) of the GRADIENT tensor t: the scale source of a gradient operand of the x2h kernels.
+    Producers that fill it as they write t (bn_bwd_*, upsample2x_bwd*) attach it to their result as `t.wt_amax`; anything else pays
+    one extra pass here (and keeps the table on the tensor for its other consumer)."""
+    tab = getattr(t, "wt_amax", None)
+    if tab is None:
+        tab = torch.empty(AMAX_WORDS, dtype=torch.int32, device=t.device)
+        lib().call("wtpse_amax", ptr(t), t.numel(), ptr(tab), stream_ptr())
+        t.wt_amax = tab
+    return tab
 
 
 def conv_fwd_x3(in0, in1, wpacked_ptr, bias, cout, ksize, pro0=None, pro_relu=0, relu_out=False, want_stats=False,
-                split=None, mask_ref=None, pro1=None):
-    """conv_fwd on the BF16 matrix cores at fp32 accuracy (csrc/conv_x3.hip); `wpacked_ptr` points into the x3-packed weights."""
+                split=None, mask_ref=None, pro1=None, in_amax=None):
+    """conv_fwd on the 16-bit matrix cores at fp32 accuracy (csrc/conv_x3.hip); `wpacked_ptr` points into the x3-packed weights.
+    in_amax: amax_of(in0) when in0 is a gradient (a data gradient launch) — include/wtpse_hip.h, wtpse_x3_terms."""
     _chk(in0, "in0"); _chk(in1, "in1"); _chk(pro0, "pro0"); _chk(pro1, "pro1")
     B, C0, H, W = in0.shape
     C1 = 0 if in1 is None else in1.shape[1]
@@ -131,7 +184,7 @@ def conv_fwd_x3(in0, in1, wpacked_ptr, bias, cout, ksize, pro0=None, pro_relu=0,
         nblk = L.query("wtpse_conv_x3_stats_blocks", B, H, W, cout, int(ksize))
         stats = torch.empty((nblk, cout, 2), dtype=torch.float32, device=in0.device)
     L.call("wtpse_conv_fwd_x3", ptr(in0), C0, ptr(in1), C1, wpacked_ptr, ptr(bias), ptr(pro0), ptr(pro1), int(pro_relu), ptr(out0),
-           ptr(out1), csplit, ptr(stats), B, H, W, cout, ksize, int(relu_out), ptr(mask_ref), stream_ptr())
+           ptr(out1), csplit, ptr(stats), B, H, W, cout, ksize, int(relu_out), ptr(mask_ref), ptr(in_amax), stream_ptr())
     return out0, out1, stats
 
 
@@ -159,7 +212,8 @@ def _tickets(n, device):
     return st[0].data_ptr() + 4 * off
 
 
-def dgrad_bnb(dy, wpacked_ptr, layout, cout, ksize, bn_y, bn_ss, bn_mean, bn_relu, split=None, bn_second=False, tail=None):
+def dgrad_bnb(dy, wpacked_ptr, layout, cout, ksize, bn_y, bn_ss, bn_mean, bn_relu, split=None, bn_second=False, tail=None,
+              in_amax=None):
     """Data gradient (`wpacked_ptr`: the layer's data-gradient weights; layout 0 fp32, 1 x3, 2 the 16-channel x3 fragments) whose
     epilogue masks the result with the ReLU of the conv + BatchNorm layer it flows into and forms that layer's BatchNorm-backward
     reductions (include/wtpse_hip.h, wtpse_dgrad_bnb).  With a split the BatchNorm'd tensor is out0, or out1 if `bn_second`.
@@ -189,13 +243,16 @@ def dgrad_bnb(dy, wpacked_ptr, layout, cout, ksize, bn_y, bn_ss, bn_mean, bn_rel
         tickets = _tickets(L.query("wtpse_bnb_tail_tickets", nblk, cout), dy.device)
         L.call("wtpse_dgrad_bnb_coef", ptr(dy), C, wpacked_ptr, layout, ptr(out0), ptr(out1), csplit, ptr(bn_y), ptr(bn_ss),
                ptr(bn_mean), int(bool(bn_relu)), c0, c1, ptr(stats), ptr(gamma), ptr(invstd), ptr(coef), ptr(dgamma), ptr(dbeta), 0,
-               ptr(partial2), tickets, B, H, W, cout, ksize, stream_ptr())
+               ptr(partial2), tickets, B, H, W, cout, ksize, ptr(in_amax), stream_ptr())
         return out0, out1, stats, coef
     if layout == 2:
         L.call("wtpse_conv16_x3", ptr(dy), C, wpacked_ptr, 0, 0, 0, ptr(out0), ptr(stats), 0, ptr(bn_y), ptr(bn_ss), ptr(bn_mean),
                int(bool(bn_relu)), B, H, W, cout, 0, stream_ptr())
+    elif layout == 1:
+        L.call("wtpse_dgrad_x3_bnb", ptr(dy), C, wpacked_ptr, ptr(out0), ptr(out1), csplit, ptr(bn_y), ptr(bn_ss), ptr(bn_mean),
+               int(bool(bn_relu)), c0, c1, ptr(stats), B, H, W, cout, ksize, ptr(in_amax), stream_ptr())
     else:
-        L.call("wtpse_dgrad_x3_bnb" if layout == 1 else "wtpse_dgrad_bnb", ptr(dy), C, wpacked_ptr, ptr(out0), ptr(out1), csplit,
+        L.call("wtpse_dgrad_bnb", ptr(dy), C, wpacked_ptr, ptr(out0), ptr(out1), csplit,
                ptr(bn_y), ptr(bn_ss), ptr(bn_mean), int(bool(bn_relu)), c0, c1, ptr(stats), B, H, W, cout, ksize, stream_ptr())
     return out0, out1, stats, None
 
@@ -237,8 +294,9 @@ def wgrad_r_supported(cin, cout, ksize, c0, w):
     return bool(lib().query("wtpse_wgrad_r_supported", int(cin), int(cout), int(ksize), int(c0), int(w)))
 
 
-def conv_wgrad_r(dy, x0, x1, dw, dbias=None, pro0=None, pro_relu=0, accumulate=False, pro1=None):
-    """3x3 conv_wgrad in the x3 arithmetic with register-resident operands (csrc/wgrad_r.hip); with bias gradient."""
+def conv_wgrad_r(dy, x0, x1, dw, dbias=None, pro0=None, pro_relu=0, accumulate=False, pro1=None, dy_amax=None):
+    """3x3 conv_wgrad in the x3 arithmetic with register-resident operands (csrc/wgrad_r.hip); with bias gradient.
+    dy_amax: amax_of(dy) (x2h: the scale of the gradient operand)."""
     _chk(dy, "dy"); _chk(x0, "x0"); _chk(x1, "x1")
     B, cout, H, W = dy.shape
     C0 = x0.shape[1]
@@ -249,7 +307,7 @@ def conv_wgrad_r(dy, x0, x1, dw, dbias=None, pro0=None, pro_relu=0, accumulate=F
     slab = workspace("wgrad_slab", ns * cout * cin * 9, dy.device)
     dbs = workspace("wgrad_dbias", ns * cout, dy.device) if dbias is not None else None
     L.call("wtpse_conv_wgrad_r", ptr(dy), ptr(x0), C0, ptr(x1), C1, ptr(pro0), ptr(pro1), int(pro_relu), ptr(slab), ptr(dbs), ns,
-           ptr(dw), ptr(dbias), int(accumulate), B, H, W, cout, stream_ptr())
+           ptr(dw), ptr(dbias), int(accumulate), B, H, W, cout, ptr(dy_amax), stream_ptr())
 
 
 def conv_wgrad_r_bn(g, bn_y, coef, x0, x1, dw, pro0=None, pro_relu=0, accumulate=False, pro1=None):
@@ -325,8 +383,9 @@ def bn_bwd(dz, y, ss, relu, gamma, mean, invstd, dgamma, dbeta, accumulate=False
     partial = workspace("bn_bwd_partial", ns * C * 2, y.device)
     coef = workspace("bn_bwd_coef", C * 3, y.device)
     dy = torch.empty_like(y)
+    dy.wt_amax = _amax_table(y.device)
     L.call("wtpse_bn_bwd", ptr(dz), ptr(y), ptr(ss), int(relu), ptr(gamma), ptr(mean), ptr(invstd), ptr(partial),
-           ptr(coef), ptr(dgamma), ptr(dbeta), int(accumulate), ptr(dy), B, C, H * W, stream_ptr())
+           ptr(coef), ptr(dgamma), ptr(dbeta), int(accumulate), ptr(dy), B, C, H * W, ptr(dy.wt_amax), stream_ptr())
     return dy
 
 
@@ -337,8 +396,9 @@ def bn_bwd_from_stats(g, y, stats, gamma, mean, invstd, dgamma, dbeta, accumulat
     assert stats.shape[1] == C
     coef = workspace("bn_bwd_coef", C * 3, y.device)
     dy = torch.empty_like(y)
+    dy.wt_amax = _amax_table(y.device)
     lib().call("wtpse_bn_bwd_from_stats", ptr(g), ptr(y), ptr(stats), stats.shape[0], ptr(gamma), ptr(mean), ptr(invstd), ptr(coef),
-               ptr(dgamma), ptr(dbeta), int(accumulate), ptr(dy), B, C, H * W, stream_ptr())
+               ptr(dgamma), ptr(dbeta), int(accumulate), ptr(dy), B, C, H * W, ptr(dy.wt_amax), stream_ptr())
     return dy
 
 
@@ -352,7 +412,8 @@ def bn_bwd_apply_coef(g, y, coef):
     _chk(g, "g"); _chk(y, "y")
     B, C, H, W = y.shape
     dy = torch.empty_like(y)
-    lib().call("wtpse_bn_bwd_apply_coef", ptr(g), ptr(y), ptr(coef), ptr(dy), B, C, H * W, stream_ptr())
+    dy.wt_amax = _amax_table(y.device)
+    lib().call("wtpse_bn_bwd_apply_coef", ptr(g), ptr(y), ptr(coef), ptr(dy), B, C, H * W, ptr(dy.wt_amax), stream_ptr())
     return dy
 
 
@@ -463,7 +524,8 @@ def upsample2x_bwd(dout):
     _chk(dout, "dout")
     B, C, Ho, Wo = dout.shape
     dx = torch.empty((B, C, Ho // 2, Wo // 2), dtype=torch.float32, device=dout.device)
-    lib().call("wtpse_upsample2x_bwd", ptr(dout), ptr(dx), 0, B, C, Ho // 2, Wo // 2, stream_ptr())
+    dx.wt_amax = _amax_table(dout.device)
+    lib().call("wtpse_upsample2x_bwd", ptr(dout), ptr(dx), 0, B, C, Ho // 2, Wo // 2, ptr(dx.wt_amax), stream_ptr())
     return dx
 
 
@@ -473,7 +535,8 @@ def upsample2x_bwd_bn(g, bn_y, coef):
     B, C, Ho, Wo = g.shape
     assert bn_y.shape == g.shape and coef.shape == (C, 3) and Wo % 8 == 0, (g.shape, bn_y.shape, coef.shape)
     dx = torch.empty((B, C, Ho // 2, Wo // 2), dtype=torch.float32, device=g.device)
-    lib().call("wtpse_upsample2x_bwd_bn", ptr(g), ptr(bn_y), ptr(coef), ptr(dx), B, C, Ho // 2, Wo // 2, stream_ptr())
+    dx.wt_amax = _amax_table(g.device)
+    lib().call("wtpse_upsample2x_bwd_bn", ptr(g), ptr(bn_y), ptr(coef), ptr(dx), B, C, Ho // 2, Wo // 2, ptr(dx.wt_amax), stream_ptr())
     return dx
 
 
