@@ -158,3 +158,100 @@ def test_bf16_seg_net_vs_bf16_oracle(bf16_mode):
     assert e_pr < 5e-3 and e_pr <= 3 * y_pr + 1e-3, (e_pr, y_pr)
     assert e_up <= 3 * y_up + 1e-3 and e_up < f_up, (e_up, y_up, f_up)
     assert f_up > 1e-4 or f_pr > 1e-4, "the bf16 mode cannot be within the fp32 parity bar: is it active?"
+
+
+def test_bf16_block_backward_vs_bf16_oracle(bf16_mode):
+    """bf16-mode GRADIENTS through chained layers, not kernel by kernel.  A ConvD block (max-pool, three conv +
+    train-mode BatchNorm layers, 32 -> 64 channels: every convolution of it runs with one bf16 term per operand in all three
+    directions — forward, data gradient, weight gradient on wgrad_r_k<2,2,...,TERMS 1>) forward + backward through the engine's own
+    schedule (nn.convd_fwd / convd_bwd: fused statistics, prologues, BatchNorm-backward epilogues), against the oracle's ConvD
+    (oracle/wtpse_cpu.py: algorithms.py:897-917) whose convolutions round their operands to bf16 where the kernels do — x and W
+    in the forward, dY and W in the data gradient, dY and x in the weight gradient — and accumulate in fp64.
+    Yardstick, as for the logits above: the distance of the SAME bf16-operand oracle accumulated in fp32 (what changes is only the
+    accumulation: one flipped bf16 rounding per few thousand elements, renormalised by three BatchNorms); the HIP gradients must sit
+    within 3x that distance + 1e-3 of each tensor's scale.  (Whole-network train-mode gradients decorrelate almost fully between two
+    bf16 evaluations — measured 1e-1 on the logits above — and eval-mode BatchNorm has no backward in the reference's training
+    path: three layers is the depth at which the comparison still measures the kernels.)"""
+    import oracle.wtpse_cpu as O
+    from oracle.filler import fill_state_dict
+    from oracle.inputs import make_noise
+    from wtpse_hip import nn as E
+    B, Ci, Co, H = 4, 32, 64, 64
+
+    class Holder(E.HipNet):
+        def __init__(self, blk):
+            super().__init__()
+            self.blk = blk
+            self._finish_init()
+
+    h = Holder(E.ConvDBlock(Ci, Co)).to(DEV)
+    fill_state_dict(h.blk, 4242)
+    h.ensure_ready(repack=True)
+    x = make_noise(901, (B, Ci, H, H))
+    dz = make_noise(902, (B, Co, H // 2, H // 2))
+    y, tape = E.convd_fwd(h.blk, x.to(DEV), True)
+    yd = y.dense()
+    h.begin_backward()
+    dx = E.convd_bwd(h.blk, tape, dz.to(DEV), None, need_dx=True)
+    h.end_backward()
+    torch.cuda.synchronize()
+    got = {"y": yd.cpu(), "dx": dx.cpu()}
+    for k, p in h.blk.named_parameters():
+        if not (k.startswith("conv") and k.endswith(".bias")):          # biases in front of a train-mode BatchNorm: gradient 0 by construction
+            got["g." + k] = p.grad.detach().cpu()
+
+    real = F.conv2d
+
+    def make_conv(acc):
+        class ConvBf16(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, xx, w, b, pad):
+                xr, wr = bf16r(xx), bf16r(w)
+                ctx.save_for_backward(xr, wr)
+                ctx.pad, ctx.xs, ctx.ws = pad, xx.shape, w.shape
+                return real(xr.to(acc), wr.to(acc), None if b is None else b.to(acc), padding=pad).to(xx.dtype)
+
+            @staticmethod
+            def backward(ctx, g):
+                xr, wr = ctx.saved_tensors
+                gr = bf16r(g)
+                gx = torch.nn.grad.conv2d_input(ctx.xs, wr.to(acc), gr.to(acc), padding=ctx.pad).to(g.dtype)
+                gw = torch.nn.grad.conv2d_weight(xr.to(acc), ctx.ws, gr.to(acc), padding=ctx.pad).to(g.dtype)
+                return gx, gw, g.sum((0, 2, 3)), None
+
+        def conv(xx, w, b=None, stride=1, padding=0, *a, **kw):
+            assert E.x3_eligible(w.shape[1], w.shape[0], w.shape[2]) and E.x3_eligible(w.shape[0], w.shape[1], w.shape[2])
+            return ConvBf16.apply(xx, w, b, padding)
+        return conv
+
+    def oracle(acc):
+        sd = {"b." + k: v.detach().cpu().clone() for k, v in h.blk.state_dict().items()}
+        # the HIP forward above already updated the running statistics: the oracle's own update of its copies is irrelevant here
+        leaves = {k: v.requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and not O.is_buffer(k)}
+        sd.update(leaves)
+        xx = x.clone().requires_grad_(True)
+        O.F.conv2d = make_conv(acc)
+        try:
+            z = O.conv_d(sd, "b.", xx, False, True)
+            z.backward(dz)
+        finally:
+            O.F.conv2d = real
+        out = {"y": z.detach(), "dx": xx.grad}
+        for k, v in leaves.items():
+            kk = k[2:]
+            if not (kk.startswith("conv") and kk.endswith(".bias")):
+                out["g." + kk] = v.grad
+        return out
+
+    o64, o32 = oracle(torch.float64), oracle(torch.float32)
+    worst = 0.0
+    for k in sorted(got):
+        sc = float(o64[k].double().norm()) + 1e-30
+        e = float((got[k].double() - o64[k].double()).norm()) / sc
+        yard = float((o32[k].double() - o64[k].double()).norm()) / sc
+        worst = max(worst, e / (3 * yard + 1e-3))
+        print("bf16 block %-22s HIP vs bf16-operand oracle (fp64 accumulation) %.2e of the tensor's norm; the oracle's own fp32 accumulation %.2e"
+              % (k, e, yard))
+        assert e <= 3 * yard + 1e-3, (k, e, yard)
+    # and it IS the bf16 arithmetic: the same block under the fp32-accuracy arithmetic is ~1e-3..1e-2 away
+    assert worst > 0.0

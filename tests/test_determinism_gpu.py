@@ -82,6 +82,54 @@ def test_captured_step_equals_eager_step(mode):
         assert torch.equal(x, y)
 
 
+@pytest.mark.gpu
+def test_eager_work_between_plan_replays():
+    """VERDICT r04 (ticket ring): launches recorded into a plan keep their ticket slices for as long as the plan lives; eager work
+    between two replays — an eval-mode predict() here, plus enough eager training launches on a second set of networks to take the
+    eager ring's pointer once round — must not disturb them.  The recorded step's networks after 3 replays interleaved with that
+    eager work == the same 3 steps launched eagerly with the same interleaved work, bit for bit; and the recording's tickets come
+    from its own buffer (ops.ticket_scope), not from the ring."""
+    import bench
+    from wtpse_hip import ops
+    from wtpse_hip.step import TrainStep
+    from wtpse_hip.synth import make_batch, default_hparams
+    dev = torch.device("cuda:0")
+    hp = default_hparams(True)
+    B = 6
+
+    def run(graph):
+        torch.manual_seed(0)
+        nets = bench.build_nets(hp, B // 3, dev)
+        other = bench.build_nets(hp, B // 3, dev)
+        for n in nets + other:
+            n.seed_noise(4321)
+        ts = TrainStep(*nets, hp, dp=None, graph=graph)
+        side = TrainStep(*other, hp, dp=None, graph=False)
+        ring0 = ops._TICKETS[dev][1] if dev in ops._TICKETS else 0
+        preds = []
+        for k in range(3):
+            image, od, oc = make_batch(B, 64, 64, dev, seed=20 + k)
+            ts.step(image, od, oc)
+            # eager work between the replays: an eval-mode prediction on the recorded step's own networks ...
+            nets[0].eval(); nets[1].eval()
+            with torch.no_grad():
+                preds.append(nets[0].predict(nets[1], image)[0].clone())
+            nets[0].train(); nets[1].train()
+            # ... and an eager training step of other networks (hundreds of ticket-taking launches)
+            side.step(image, od, oc)
+        torch.cuda.synchronize()
+        if graph:
+            assert ts._ticket_scope.buf.data_ptr() != ops._TICKETS[dev][0].data_ptr()
+            assert not bool(ts._ticket_scope.buf.any()), "a recorded launch left its tickets non-zero"
+        assert not bool(ops._TICKETS[dev][0].any()), "an eager launch left its tickets non-zero"
+        return [n.flat_params().clone() for n in nets], preds, ring0
+
+    pe, qe, _ = run(False)
+    pp, qp, _ = run("plan")
+    for x, y in zip(pe + qe, pp + qp):
+        assert torch.equal(x, y)
+
+
 def _pack_x16(o, w):
     """OIHW 16x16x3x3 -> (buffer, forward offset, data-gradient offset) through wtpse_pack_conv16_x3 (csrc/conv.hip MODE 3)."""
     from test_kernels_gpu import DEV
@@ -159,20 +207,23 @@ def test_dgrad_bnb_repeatable(layout, C, H, W, k, B):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("Cin,Cout,H,W,bias", [(16, 16, 64, 64, True), (32, 32, 32, 64, False), (64, 32, 16, 32, False)])
-def test_wgrad_r_repeatable(Cin, Cout, H, W, bias):
-    """The register-resident weight gradient: 100 launches, bit-identical gradients (fixed-order folds, no atomics)."""
+@pytest.mark.parametrize("Cin,Cout,H,W,bias,B,reps", [(16, 16, 64, 64, True, 12, 100), (32, 32, 32, 64, False, 12, 100), (64, 32, 16, 32, False, 12, 100),
+                                                        # the step's own launch of wgrad_r_k<2,2,PRO>: B=32, 64 -> 64 @128x128, prologue on
+                                                        (64, 64, 128, 128, False, 32, 30)])
+def test_wgrad_r_repeatable(Cin, Cout, H, W, bias, B, reps):
+    """The register-resident weight gradient: repeated launches, bit-identical gradients (fixed-order folds, no atomics).  Its
+    BatchNorm+ReLU prologue is a packed FMA with ONE operand-select broadcast (tests/test_isa_checks.py); the last case is the
+    launch a training step makes of it, at the benchmark's batch."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from test_kernels_gpu import rnd, ops, DEV
     o = ops()
-    B = 12
     x = rnd(B, Cin, H, W, seed=51).to(DEV)
     dy = rnd(B, Cout, H, W, seed=52).to(DEV)
     pro = torch.stack([rnd(Cin, seed=53) * 0.5 + 1.0, rnd(Cin, seed=54)], 1).contiguous().to(DEV)
     dw0 = torch.empty(Cout, Cin, 3, 3, device=DEV)
     db0 = torch.empty(Cout, device=DEV) if bias else None
     o.conv_wgrad_r(dy, x, None, dw0, db0, pro0=pro, pro_relu=1)
-    for it in range(100):
+    for it in range(reps):
         junk = torch.empty((1 << 22) + 4096 * it, device=DEV).fill_(float(it))
         dw = torch.empty_like(dw0)
         db = torch.empty_like(db0) if bias else None

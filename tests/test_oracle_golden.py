@@ -193,14 +193,15 @@ def test_blocks(golden_dir, name, bi, kind):
             "convu_first": (convu_template("", 64, True), (B, 64, H // 2, H // 2), (B, 32, H, H), True),
             "convu": (convu_template("", 32, False), (B, 64, H // 2, H // 2), (B, 16, H, H), False)}[name]
     tmpl, xs, ps, first = spec
+    seed_t = 1000 * int(g[name + ".seed_t"])       # the kink-free input seeds oracle/make_golden_blocks.py settled on
     sd = O.as_leaves(filled_state(tmpl, SEED_W + 20 + bi))
-    x = make_noise(300 + bi, xs).requires_grad_(True)
+    x = make_noise(300 + bi + seed_t, xs).requires_grad_(True)
     if kind == "d":
         y = O.conv_d(sd, "", x, first, True)
     else:
-        prev = make_noise(400 + bi, ps).requires_grad_(True)
+        prev = make_noise(400 + bi + seed_t, ps).requires_grad_(True)
         y = O.conv_u(sd, "", x, prev, first, True)
-    (y * make_noise(500 + bi, y.shape)).sum().backward()
+    (y * make_noise(500 + bi + seed_t, y.shape)).sum().backward()
     close(y.detach().numpy(), g[name + ".y"], rtol=1e-4, atol=1e-5, what="y")
     close(x.grad.numpy(), g[name + ".dx"], rtol=1e-3, atol=1e-4, what="dx")
     if kind == "u":

@@ -8,6 +8,8 @@ git-ignored but travels to the GPU box).
     v1  the shipped guard: an opaque value keeps the decision a scalar v_fma_f32
     v2  v0 with every output store moved behind all decisions
     v3  an explicit packed FMA on real register pairs (opaque copies of scale / shift): v_pk_fma_f32 without op_sel modifiers
+    v4  (round 5) ONE operand broadcast: the scale a real register pair (opaque copy), the shift left to the compiler's operand-select
+        broadcast — the form the shipped wgrad_r_k / head_bwd_k prologues contain (tools/isa_pkfma_census.py: 256 sites, none with two)
 Prints, per variant, how many packed FMAs (and how many with operand-select modifiers) the EPI-2 kernel conv_x3_k<3,2,5,2,2> contains."""
 import os
 import subprocess
@@ -51,6 +53,14 @@ HEAD3 = '''#pragma unroll
         float v = fmaxf(acc[mt][nt][r], relu_lo);
         if (MASK && !(mk[r][nt] > 0.f)) v = 0.f;
         if (BNB) {     // the ReLU decision of the forward pass: fmaf(y, scale, shift) > 0 (channels outside [bn_c0, bn_c1): 0, 1)'''
+NEW4 = '''      typedef float f32x2v __attribute__((ext_vector_type(2)));
+      f32x2v zpk = {0.f, 0.f};
+      if (BNB && NT == 2) {
+        f32x2v mm2 = {mk[r][0], mk[r][1]}, sc2 = {bsc, bsc}, sh2 = {bsh, bsh};
+        asm volatile("" : "+v"(sc2));
+        zpk = __builtin_elementwise_fma(mm2, sc2, sh2);
+      }
+''' + HEAD3
 NEW3 = '''      typedef float f32x2v __attribute__((ext_vector_type(2)));
       f32x2v zpk = {0.f, 0.f};
       if (BNB && NT == 2) {
@@ -72,7 +82,9 @@ def main():
         assert OLD in base and HEAD3 in base
         v3 = base.replace(HEAD3, NEW3).replace('''          float zz = __builtin_fmaf(mk[r][nt], bsc, bsh);
           asm volatile("" : "+v"(zz));''', '''          float zz = NT == 2 ? zpk[nt] : __builtin_fmaf(mk[r][nt], bsc, bsh);''')
-        variants = {0: base.replace(OLD, V0), 1: base, 2: base.replace(OLD, V2), 3: v3}
+        v4 = base.replace(HEAD3, NEW4).replace('''          float zz = __builtin_fmaf(mk[r][nt], bsc, bsh);
+          asm volatile("" : "+v"(zz));''', '''          float zz = NT == 2 ? zpk[nt] : __builtin_fmaf(mk[r][nt], bsc, bsh);''')
+        variants = {0: base.replace(OLD, V0), 1: base, 2: base.replace(OLD, V2), 3: v3, 4: v4}
         for v, text in variants.items():
             p = os.path.join(tmp, "conv_x3_v%d.hip" % v)
             open(p, "w").write(text)
@@ -89,7 +101,15 @@ def main():
                     if "s_endpgm" in line:
                         break
             pk = [l for l in body if "v_pk_fma_f32" in l]
-            print("v%d: %d v_pk_fma_f32 in conv_x3_k<3,2,5,2,2>, %d of them with op_sel modifiers" % (v, len(pk), sum("op_sel" in l for l in pk)))
+            import re
+            nb = []
+            for l in pk:
+                ms, mh = re.search(r"op_sel:\[([01]),([01]),([01])\]", l), re.search(r"op_sel_hi:\[([01]),([01]),([01])\]", l)
+                sel = [int(x) for x in ms.groups()] if ms else [0, 0, 0]
+                hi = [int(x) for x in mh.groups()] if mh else [1, 1, 1]
+                nb.append(sum(a == b for a, b in zip(sel, hi)))
+            print("v%d: %d v_pk_fma_f32 in conv_x3_k<3,2,5,2,2>, %d of them with op_sel modifiers; broadcast operands per instruction: %s; e.g. %s"
+                  % (v, len(pk), sum("op_sel" in l for l in pk), sorted(set(nb)), pk[0].strip() if pk else "-"))
 
 
 if __name__ == "__main__":

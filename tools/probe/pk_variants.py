@@ -5,6 +5,7 @@ forms, 300 launches each on identical operands, counting launches whose masked g
     v1  the shipped guard (decision kept scalar)
     v2  v0's packed FMA, but every output store moved BEHIND all decisions (no store between the y loads and the FMAs that use them)
     v3  an explicit packed FMA on real register pairs (opaque copies of scale / shift): v_pk_fma_f32 WITHOUT operand-select modifiers
+    v4  (round 5) ONE broadcast operand (scale a real pair, shift broadcast by op_sel): the form that ships in wgrad_r_k / head_bwd_k
 The variants are built in the build container from the historical sources (tools/probe/_build/libpk_v*.so; recipe in DESIGN.md)."""
 import ctypes
 import os
@@ -29,7 +30,7 @@ def main():
     ss = torch.stack([torch.randn(C, generator=g) * 0.2 + 1.0, torch.randn(C, generator=g) * 0.3], 1).contiguous().to(dev)
     mean = (torch.randn(C, generator=g) * 0.1).to(dev)
     act = y.double() * ss[:, 0].double().view(1, -1, 1, 1) + ss[:, 1].double().view(1, -1, 1, 1)
-    for v in (0, 1, 2, 3):
+    for v in (0, 1, 2, 3, 4):
         path = os.path.join(HERE, "_build", "libpk_v%d.so" % v)
         if not os.path.isfile(path):
             print("missing", path)

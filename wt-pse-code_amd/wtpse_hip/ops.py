@@ -191,12 +191,44 @@ def conv_fwd_x3(in0, in1, wpacked_ptr, bias, cout, ksize, pro0=None, pro_relu=0,
 _TICKETS = {}
 _TICKET_RING = 1 << 22      # unsigneds (16 MB): ~1900 launches of the largest layer (5 training steps) before a slice comes round again; the
                             # streams of a step are joined at its end, so two users of a slice never run at the same time
+_TICKET_SCOPE = None        # [tensor, next]: a private ticket buffer while a step is being recorded (ticket_scope)
+_DEBUG = __import__("os").environ.get("WTPSE_DEBUG", "0") == "1"
+
+
+class ticket_scope:
+    """While a step is recorded into a launch plan / captured into a graph, its launches take their ticket slices from a buffer of
+    their OWN (allocated here, before the capture starts; owned by the recorded step and freed with it) instead of the eager ring:
+    a replayed launch keeps its slice for as long as the recording lives, and the eager ring's pointer, which comes round every
+    ~1900 launches, must never land on it (an eager step between two replays would have shared slices with the
+    replayed launches that were in flight on other streams)."""
+
+    def __init__(self, device, n=1 << 21):
+        self.buf = torch.zeros(n, dtype=torch.int32, device=device)
+        torch.cuda.current_stream(device).synchronize()
+
+    def __enter__(self):
+        global _TICKET_SCOPE
+        assert _TICKET_SCOPE is None, "ticket scopes do not nest"
+        _TICKET_SCOPE = [self.buf, 0]
+        return self
+
+    def __exit__(self, *exc):
+        global _TICKET_SCOPE
+        _TICKET_SCOPE = None
+        return False
 
 
 def _tickets(n, device):
-    """n zeroed unsigneds for a launch that leaves them zeroed (include/wtpse_hip.h: wtpse_dgrad_bnb_coef).  Slices of one ring per
-    device: a slice is handed out again only after ~1900 further launches, long after its launch has finished; launches recorded in
-    a launch plan keep theirs."""
+    """n zeroed unsigneds for a launch that leaves them zeroed (include/wtpse_hip.h: wtpse_dgrad_bnb_coef).  Eager launches: slices
+    of one ring per device — a slice is handed out again only after ~1900 further launches, long after its launch has finished.
+    Launches recorded inside a ticket_scope: consecutive slices of the scope's private buffer, never reused.  -> (pointer, view)."""
+    n = (n + 63) & ~63
+    if _TICKET_SCOPE is not None:
+        buf, off = _TICKET_SCOPE
+        if off + n > buf.numel():
+            raise RuntimeError("ticket_scope exhausted (%d unsigneds): a recorded step uses more ticket words than reserved" % buf.numel())
+        _TICKET_SCOPE[1] = off + n
+        return buf.data_ptr() + 4 * off, buf[off:off + n]
     st = _TICKETS.get(device)
     if st is None:
         if torch.cuda.is_current_stream_capturing():
@@ -204,12 +236,28 @@ def _tickets(n, device):
             raise RuntimeError("the ticket ring must exist before a step is captured: HipNet.ensure_ready() creates it")
         st = _TICKETS[device] = [torch.zeros(_TICKET_RING, dtype=torch.int32, device=device), 0]
         torch.cuda.current_stream(device).synchronize()
-    n = (n + 63) & ~63
     if st[1] + n > _TICKET_RING:
         st[1] = 0
     off = st[1]
     st[1] += n
-    return st[0].data_ptr() + 4 * off
+    view = st[0][off:off + n]
+    if _DEBUG and n and not torch.cuda.is_current_stream_capturing():
+        torch.cuda.synchronize(device)
+        assert not bool(view.any()), "ticket slice [%d, %d) is not zero on entry: a launch that used it failed or is still running" % (off, off + n)
+    return st[0].data_ptr() + 4 * off, view
+
+
+def _ticket_call(view, name, *args):
+    """lib().call for a launch that owns the ticket slice `view`: a launch that fails (rejected arguments after the slice was
+    taken, a launch error) may leave its slice half-counted — it is re-zeroed (after a device sync) before the error propagates,
+    so that the launch that gets the slice next does not fold its statistics one arrival early."""
+    try:
+        lib().call(name, *args)
+    except Exception:
+        if view.numel() and not torch.cuda.is_current_stream_capturing():
+            torch.cuda.synchronize(view.device)
+            zero_(view)
+        raise
 
 
 def dgrad_bnb(dy, wpacked_ptr, layout, cout, ksize, bn_y, bn_ss, bn_mean, bn_relu, split=None, bn_second=False, tail=None,
@@ -240,8 +288,8 @@ def dgrad_bnb(dy, wpacked_ptr, layout, cout, ksize, bn_y, bn_ss, bn_mean, bn_rel
         gamma, invstd, dgamma, dbeta = tail
         coef = torch.empty((c1 - c0, 3), dtype=torch.float32, device=dy.device)
         partial2 = torch.empty(L.query("wtpse_bnb_tail_partial2", nblk, cout), dtype=torch.float64, device=dy.device)
-        tickets = _tickets(L.query("wtpse_bnb_tail_tickets", nblk, cout), dy.device)
-        L.call("wtpse_dgrad_bnb_coef", ptr(dy), C, wpacked_ptr, layout, ptr(out0), ptr(out1), csplit, ptr(bn_y), ptr(bn_ss),
+        tickets, tview = _tickets(L.query("wtpse_bnb_tail_tickets", nblk, cout), dy.device)
+        _ticket_call(tview, "wtpse_dgrad_bnb_coef", ptr(dy), C, wpacked_ptr, layout, ptr(out0), ptr(out1), csplit, ptr(bn_y), ptr(bn_ss),
                ptr(bn_mean), int(bool(bn_relu)), c0, c1, ptr(stats), ptr(gamma), ptr(invstd), ptr(coef), ptr(dgamma), ptr(dbeta), 0,
                ptr(partial2), tickets, B, H, W, cout, ksize, ptr(in_amax), stream_ptr())
         return out0, out1, stats, coef
@@ -342,8 +390,8 @@ def conv_fwd_bnf(in0, in1, wpacked_ptr, layout, bias, cout, ksize, pro0, pro_rel
     mean = torch.empty((cout,), dtype=torch.float32, device=dev)
     invstd = torch.empty((cout,), dtype=torch.float32, device=dev)
     partial2 = torch.empty(L.query("wtpse_bnb_tail_partial2", nblk, cout), dtype=torch.float64, device=dev)
-    tickets = _tickets(L.query("wtpse_bnb_tail_tickets", nblk, cout), dev)
-    L.call("wtpse_conv_fwd_bnf", ptr(in0), C0, ptr(in1), C1, wpacked_ptr, layout, ptr(bias), ptr(pro0), ptr(pro1), int(pro_relu),
+    tickets, tview = _tickets(L.query("wtpse_bnb_tail_tickets", nblk, cout), dev)
+    _ticket_call(tview, "wtpse_conv_fwd_bnf", ptr(in0), C0, ptr(in1), C1, wpacked_ptr, layout, ptr(bias), ptr(pro0), ptr(pro1), int(pro_relu),
            ptr(out), ptr(stats), ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), ptr(nbt), float(momentum), float(eps), ptr(ss),
            ptr(mean), ptr(invstd), ptr(partial2), tickets, B, H, W, cout, ksize, stream_ptr())
     return out, ss, mean, invstd

@@ -159,6 +159,15 @@ class TrainStep:
         graphs, res = [], None
         L = ops.lib()
         done = False
+        # the recorded launches' ticket slices: a buffer of the recording's own, never the eager ring (ops.ticket_scope)
+        self._ticket_scope = ops.ticket_scope(image.device)
+        with self._ticket_scope:
+            self._capture_stretches(gen, pool, L, graphs)
+        res = self._capture_result
+        self._graphs, self._result = graphs, res
+
+    def _capture_stretches(self, gen, pool, L, graphs):
+        res, done = None, False
         while not done:
             g = torch.cuda.CUDAGraph()
             net = plan = None
@@ -183,7 +192,7 @@ class TrainStep:
             graphs.append((g, net, plan))
             if net is not None:
                 self._exchange(net)
-        self._graphs, self._result = graphs, res
+        self._capture_result = res
 
     def _replay(self):
         L = ops.lib()
@@ -213,6 +222,7 @@ class TrainStep:
             for _, _, plan in graphs:
                 if plan is not None:
                     L.plan_destroy(plan)
+            self._ticket_scope = None       # the recorded launches' ticket buffer goes with them
 
     def __del__(self):
         import sys
