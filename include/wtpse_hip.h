@@ -99,15 +99,19 @@ int wtpse_conv_fwd_x3(const float* in0, int C0, const float* in1, int C1, const 
                       int B, int H, int W, int Cout, int ksize, int relu_out, const float* mask_ref, const unsigned* in_amax,
                       void* stream);
 
-/* The 16-channel 3x3 layers (inc, DeepWT, the teacher's inc: algorithms.py:897-917,1091-1117,398-413) in the x3 arithmetic on
- * v_mfma_f32_16x16x32_bf16 (csrc/conv.hip, MODE 3): Cout <= 16, C0 <= 16, one input.  wx16: the layer's register-resident weight
- * fragments (forward or data-gradient direction) from wtpse_pack_conv16_x3, 7680 unsigned shorts per direction, 16-byte aligned.
+/* The 16-channel 3x3 layers (inc, DeepWT, the teacher's inc: algorithms.py:897-917,1091-1117,398-413) on v_mfma_f32_16x16x32_* with
+ * register-resident weight fragments (csrc/conv.hip, MODE 3 / 4): Cout <= 16, C0 <= 16, one input.  wx16: the layer's fragments
+ * (forward or data-gradient direction) from wtpse_pack_conv16_x3, 12808 unsigned shorts per direction (a 16-byte header with the
+ * x2h weight scale, the x3 fragments, the x2h fragments), 16-byte aligned.  Arithmetic: wtpse_x3_terms() — x2h when it is 2, except
+ * that a GRADIENT input (in_is_grad != 0) without its amax table (in_amax == NULL) runs in x3 (no scale is known for it and a pass
+ * to find one costs more than this HBM-bound kernel would gain); in_is_grad == 0: a forward activation, scaled by 2^4.
  * Options as wtpse_conv_fwd (bias, prologue, relu_out, stats [wtpse_conv_stats_blocks][Cout][2], mask_ref) plus gram_partial
  * (as wtpse_conv_fwd_gram; Cout == 16, relu_out == 0) and — with bn_mean — the BatchNorm-backward epilogue of wtpse_dgrad_bnb
  * over all output channels (mask_ref = that layer's raw conv output, stats = its partials). */
 int wtpse_conv16_x3(const float* in0, int C0, const unsigned short* wx16, const float* bias, const float* pro0, int pro_relu,
                     float* out0, float* stats, float* gram_partial, const float* mask_ref, const float* bn_ss,
-                    const float* bn_mean, int bn_relu, int B, int H, int W, int Cout, int relu_out, void* stream);
+                    const float* bn_mean, int bn_relu, int B, int H, int W, int Cout, int relu_out, int in_is_grad,
+                    const unsigned* in_amax, void* stream);
 /* desc: n_desc x 8 ints {w_off, Cout, Cin, 9, fwd_off (-1: none), dgrad_off (-1: none), 0, 0}; w_off in floats, *_off in
  * unsigned shorts (multiples of 8). */
 int wtpse_pack_conv16_x3(const float* params, const int* desc, int n_desc, unsigned short* packed, void* stream);
@@ -178,8 +182,10 @@ int wtpse_conv_wgrad_x3(const float* dy, const float* x0, int C0, const float* x
  * multiple of 32, Cin / Cout multiples of 16 (C0 % 16 == 0 for a concat) — or exactly 16 wide with Cin / Cout multiples of 32 (two images
  * side by side per 32-pixel step; no bias gradient, not the _bn form) —: wtpse_wgrad_r_supported().  With bias gradient
  * (dbias / dbias_slab NULL: skip).  slab: [nslab][Cout*Cin*9], dbias_slab: [nslab][Cout], nslab = wtpse_wgrad_r_slabs(...).
- * Arithmetic by wtpse_x3_terms(); with 2 (x2h) dY is scaled from dy_amax (NULL: like a forward activation), X by 2^4; the _bn
- * form below stays on three bf16 terms. */
+ * Arithmetic by wtpse_x3_terms(); with 2 (x2h) dY is scaled from dy_amax (NULL: like a forward activation — and the 16 x 16-channel
+ * blocks, HBM-bound, then stay on x3), X by 2^4; the _bn form below stays on three bf16 terms.  With 1 (bf16 mode) only the blocks of
+ * 32 channels on at least one side run with one term: the 16 x 16 blocks (which alone carry a bias gradient), the _bn form and
+ * wtpse_conv_wgrad_x3 keep three — the mode is a mix of arithmetics by design (the 16-channel layers are not MFMA-bound). */
 int wtpse_wgrad_r_supported(int Cin, int Cout, int ksize, int C0, int W);
 int wtpse_wgrad_r_slabs(int B, int H, int W, int Cin, int Cout);
 int wtpse_conv_wgrad_r(const float* dy, const float* x0, int C0, const float* x1, int C1, const float* pro0,

@@ -53,4 +53,17 @@ def make_tree(root, seed=5):
                 mk.save(os.path.join(dm, base))
                 written.setdefault((dom, phase), []).append(base)
                 k += 1
+    # Domain5 (round 5): files whose names carry none of the known prefixes — the reference's reader prints "[ERROR:] Unknown dataset!"
+    # and stops reading (fundus_dataloader.py:176-178); written last, so every other domain's bytes are what they were
+    for phase in ("train",):
+        di = os.path.join(root, "Domain5", phase, "ROIs", "image")
+        dm = os.path.join(root, "Domain5", phase, "ROIs", "mask")
+        os.makedirs(di, exist_ok=True)
+        os.makedirs(dm, exist_ok=True)
+        for n in ("x0001", "y0002"):
+            im, mk = _sample(rs, 256, 256, rgb_mask=False)
+            base = "%s_%s.png" % (n, phase)
+            im.save(os.path.join(di, base))
+            mk.save(os.path.join(dm, base))
+            written.setdefault((5, phase), []).append(base)
     return written

@@ -17,7 +17,8 @@ from oracle import ref_import  # noqa: E402
 from oracle.fundus_tree import make_tree  # noqa: E402
 
 CASES = [((1,), "train", "train"), ((2,), "train", "train"), ((3,), "train", "train"), ((4,), "test", "prediction"),
-         ((1, 2), "train", "train"), ((3,), "test", "train")]
+         ((1, 2), "train", "train"), ((3,), "test", "train"),
+         ((5,), "train", "train")]        # unknown file prefixes only: the reader stops, three of the four empty pools are removed (:58-75)
 
 
 def checksum(pil):
@@ -39,12 +40,15 @@ def main():
             out["c%d_meta" % ci] = np.array(["|".join(str(s) for s in split), phase, state, "|".join(keys), str(len(ds))])
             for key in keys:
                 names = ds.img_name_pool[key]
+                if not names:          # a pool the reference left in place although it is empty (unknown-prefix tree)
+                    out["c%d_%s_names" % (ci, key)] = np.array([], dtype="<U1")
+                    continue
                 out["c%d_%s_names" % (ci, key)] = np.array(names)
                 out["c%d_%s_img" % (ci, key)] = np.stack([np.concatenate([np.array(im.size), checksum(im)]) for im in ds.image_pool[key]])
                 out["c%d_%s_imgmode" % (ci, key)] = np.array([im.mode for im in ds.image_pool[key]])
                 out["c%d_%s_mask" % (ci, key)] = np.stack([np.concatenate([np.array(m.size), checksum(m)]) for m in ds.label_pool[key]])
                 out["c%d_%s_maskmode" % (ci, key)] = np.array([m.mode for m in ds.label_pool[key]])
-            if phase == "train":
+            if phase == "train" and len(ds) > 0:
                 np.random.seed(11)
                 seq = []
                 for _ in range(12):

@@ -34,7 +34,8 @@ X3_CASES = [
     (1, 128, 0, 256, 2, 2, 3),     # deepest level of the 32x32 test network
     (2, 40, 0, 96, 12, 20, 3),     # non-power-of-two channels: ragged chunk (40 -> 48) and 3 cout blocks
     (2, 3, 0, 32, 20, 40, 3),      # 3-channel input padded to one chunk
-    (20, 32, 32, 64, 32, 64, 3),   # enough tiles for the 64-cout (MT 2) variant
+    (20, 32, 32, 64, 32, 64, 3),   # 64 output channels on few tiles: 32-channel blocks (the 64-channel blocks need 512 workgroups)
+    (32, 64, 0, 64, 64, 64, 3),    # 512 tiles of 256 pixels x one 64-channel block: the step's default kernel conv_x3r_k<2,1,4,5>
 ]
 
 
@@ -474,7 +475,16 @@ X3R_CASES = [
     (2, 40, 0, 96, 12, 20),        # WM 1, ragged chunk, three cout blocks
     (2, 128, 0, 64, 16, 16),       # WM 1, 128-pixel tiles (few workgroups on a 16-wide map)
     (3, 16, 0, 32, 40, 72),        # a single chunk (the prefetch runs past the end)
+    (32, 64, 0, 64, 64, 64),       # x3_mt2: 512 tiles x one 64-channel block — conv_x3r_k<2,1,4,5> (2 x 2 waves) against conv_x3_k<3,2,5> (1 x 4)
+    (64, 32, 32, 128, 32, 16),     # x3_mt2 on 16-wide tiles: conv_x3r_k<2,1,4,4>
 ]
+
+
+def _is_mt2(case):
+    B, C0, C1, Co, H, W = case
+    TW = 16 if W <= 16 else 32
+    tiles = B * -(-W // TW) * -(-H // (256 // TW))
+    return Co % 64 == 0 and tiles * (Co // 64) >= 512
 
 
 def _x3_case_runner(case):
@@ -527,14 +537,18 @@ def test_x3r_equals_x3(case):
         old = run()
     finally:
         o.lib().query("wtpse_x3r_enable", 1)
-    _assert_same_outputs(new, old)
+    # 64-channel blocks: the two kernels split a tile between their waves differently (2 x 2 waves of 32 channels x 128 pixels against
+    # 1 x 4 of 64 x 64), so a channel's BatchNorm partial is summed over other groups of pixels — convolution outputs and masked
+    # gradients stay bitwise equal, the statistics partials agree to fp32 summation order (stated and tested explicitly)
+    _assert_same_outputs(new, old, stats_exact=not _is_mt2(case))
 
 
-def _assert_same_outputs(new, old):
-    """Bitwise, except statistics partials that come in a different number of rows (a launch that took the 128-pixel tiling of
-    x3_half on one side only): their column sums must agree to fp32 summation order."""
+def _assert_same_outputs(new, old, stats_exact=True):
+    """Bitwise, except statistics partials (the 3-d outputs) that come in a different number of rows (a launch that took the 128-pixel
+    tiling of x3_half on one side only) or, with stats_exact = False, from a different split of the tile between the waves: their
+    column sums must agree to fp32 summation order."""
     for i, (a_, b_) in enumerate(zip(new, old)):
-        if a_.shape == b_.shape:
+        if a_.shape == b_.shape and (stats_exact or a_.dim() != 3):
             assert torch.equal(a_, b_), "output %d differs: max |d| = %g" % (i, float((a_ - b_).abs().max()))
         else:
             assert a_.dim() == 3 and a_.shape[1:] == b_.shape[1:], (a_.shape, b_.shape)

@@ -25,6 +25,9 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_w" -o w -- $B --kern
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OUT/pmc_a" -o a -- $B --kernels-only > "$OUT/pmc_a.log" 2>&1 &&
 python3 tools/pmc_traffic.py "$(ls $OUT/pmc_f/*/f_counter_collection.csv $OUT/pmc_f/f_counter_collection.csv 2>/dev/null | head -1)" "$(ls $OUT/pmc_w/*/w_counter_collection.csv $OUT/pmc_w/w_counter_collection.csv 2>/dev/null | head -1)" > "$OUT/pmc_traffic.log" 2>&1 &&
 cp profiles/pmc_traffic.json "$OUT/pmc_traffic.json" &&
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_sf" -o f -- $B --steps 2 --warmup 1 --roi-presteps 0 --no-cpu-baseline --no-kernel-roofline > "$OUT/pmc_sf.log" 2>&1 &&
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_sw" -o w -- $B --steps 2 --warmup 1 --roi-presteps 0 --no-cpu-baseline --no-kernel-roofline > "$OUT/pmc_sw.log" 2>&1 &&
+python3 tools/pmc_step_traffic.py "$(ls $OUT/pmc_sf/*/f_counter_collection.csv $OUT/pmc_sf/f_counter_collection.csv 2>/dev/null | head -1)" "$(ls $OUT/pmc_sw/*/w_counter_collection.csv $OUT/pmc_sw/w_counter_collection.csv 2>/dev/null | head -1)" 5 > "$OUT/step_traffic.json" 2> "$OUT/step_traffic.err" &&
 python3 tools/microbench_x3.py > "$OUT/microbench_x3.log" 2>&1 &&
 python3 tools/microbench_wgrad.py 32 > "$OUT/microbench_wgrad.log" 2>&1 &&
 python3 tools/microbench_c16.py 32 > "$OUT/microbench_c16.log" 2>&1 &&

@@ -141,6 +141,10 @@ __device__ __forceinline__ void split2h_pair(float a, float b, unsigned& p0, uns
   p1 = pack_h_rne(a - (float)v[0], b - (float)v[1]);
 }
 
+__device__ __forceinline__ f32x4 wt_mfma16x32h(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
+}
+
 // ---- BatchNorm-backward coefficients from the epilogue of the data gradient that produced the statistics (conv.hip, conv_x3.hip:
 // EPI 2).  Every workgroup has written its (sum g, sum g (y - mean)) partials to stats[tile][Cbn][2]; instead of a separate
 // finalize launch (a 16..256-workgroup kernel that sat between two big launches of a dependency chain, 142 times per step, and

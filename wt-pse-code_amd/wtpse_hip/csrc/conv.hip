@@ -42,6 +42,8 @@ struct ConvArgs {
   float* out1;
   float* stats;        // [gridDim.x][Cout][2] or null
   const float* mask;   // [B][Cout][H][W] or null: out = mask > 0 ? value : 0 (ReLU backward fused into a data gradient)
+  const unsigned* in_amax;   // MODE 4 (x2h): the amax table of in0 when it is a gradient (common.h), or null: in_scale
+  float in_scale;
   float* gram;         // [gridDim.x][16][16] or null (16-cout path): the tile's partial Gram  sum_px out[i][px] * out[j][px]
   // EPI == 2 (BatchNorm backward statistics in a data gradient's epilogue, see conv_x3.hip): output channels [bn_c0, bn_c1) are
   // masked with the ReLU of the conv + BatchNorm layer they flow into (raw conv output: `mask`, [B][bn_c1 - bn_c0][H][W]) and
@@ -97,9 +99,10 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
   // this phase costs about one MFMA slot (tools/probe/conv_stamps.py)
   constexpr int NPOS = (PE + 255) / 256;
   constexpr int S = PlaneStride<NPOS * 256>::value;
-  constexpr bool XP = (MODE == 3);                 // 16-cout path in the x3 arithmetic (3x3, Cin <= 16)
+  constexpr bool XP = (MODE == 3 || MODE == 4);    // 16-cout path in the x3 (MODE 3) / x2h (MODE 4) arithmetic (3x3, Cin <= 16)
+  constexpr int XT = MODE == 4 ? 2 : 3;            // 16-bit terms per fp32 operand on that path
   constexpr bool P16 = (MODE == 0) || XP;
-  static_assert(!XP || KS == 3, "MODE 3 is the 3x3 path");
+  static_assert(!XP || KS == 3, "MODE 3 / 4 is the 3x3 path");
   constexpr int MT = P16 ? 1 : MODE;
   constexpr int MB = P16 ? 16 : 32;
   constexpr int CB = MB * MT;
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
   constexpr int CB4 = CB / 4;
   constexpr int NW = (KC * TAPS * CB4 + 255) / 256;   // 16-byte weight loads per thread and chunk
   constexpr int PEP = (PE + 7) & ~7;                     // MODE 3: 16-byte slots per (term, k-half) plane of the split tile
-  constexpr int XS_SZ = XP ? 6 * PEP * 4 : KC * S;
+  constexpr int XS_SZ = XP ? 2 * XT * PEP * 4 : KC * S;
   constexpr int WS_SZ = XP ? 0 : NW * 1024;            // weight slab [KC*TAPS][CB], padded to whole load rounds
   constexpr int GRAM_SZ = (P16 && KS == 3) ? 4 * 16 * 65 + 4 * 256 : 0;   // wave-private [16 ch][64 px (+1)] tiles + 4 partial Grams
   constexpr int RED_SZ = 4 * CB * 2 > GRAM_SZ ? 4 * CB * 2 : GRAM_SZ;
@@ -168,13 +171,16 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
       for (int r = 0; r < NACC; ++r) acc[mt][nt][r] = 0.f;
 
   if constexpr (XP) {
-    // ---- MODE 3: one 16-channel chunk, split once; weights in registers; 16x16x32 bf16 MFMAs, six per fp32 product
-    u32x4* Xq = reinterpret_cast<u32x4*>(smem);           // [term 3][k-half 2][PEP positions] 16-byte rows of 8 channels
+    // ---- MODE 3 / 4: one 16-channel chunk, split once; weights in registers; 16x16x32 MFMAs: six bf16 products per fp32 multiply
+    // (x3) or three fp16 products (x2h: operands scaled by powers of two on the way in, the accumulators back on the way out —
+    // conv_x3_kernels.h has the full description)
+    u32x4* Xq = reinterpret_cast<u32x4*>(smem);           // [term XT][k-half 2][PEP positions] 16-byte rows of 8 channels
+    const float sx = MODE == 4 ? (a.in_amax ? x3_scale_from_amax(amax_read(a.in_amax)) : a.in_scale) : 1.f;
     const int g4 = lane >> 4;
     // loader work items: (halo position, k-half) in whole-wave blocks (as conv_x3.hip)
     constexpr int PB = (PE + 63) / 64, NIT = (2 * PB + 3) / 4;
     const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(a.in0 + (size_t)b * a.C0 * HW, (unsigned)a.C0 * HW * 4u);
-    const bool any_pro = a.pro0 != nullptr || a.pro_relu != 0;
+    const bool any_pro = MODE == 4 || a.pro0 != nullptr || a.pro_relu != 0;      // x2h: the input scale rides in the coefficients
     float xv[NIT][8];
     int ipos[NIT], ihalf[NIT];
     bool iin[NIT];
@@ -189,8 +195,8 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int cg = min(hh * 8 + j, a.C0 - 1);
-        psc[hh][j] = a.pro0 ? a.pro0[2 * cg] : 1.f;
-        psh[hh][j] = a.pro0 ? a.pro0[2 * cg + 1] : 0.f;
+        psc[hh][j] = (a.pro0 ? a.pro0[2 * cg] : 1.f) * sx;
+        psh[hh][j] = (a.pro0 ? a.pro0[2 * cg + 1] : 0.f) * sx;
       }
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
@@ -206,13 +212,14 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
       for (int j = 0; j < 8; ++j)     // channels past C0 are out of the buffer's range and read as zero (their weights are zero too)
         xv[i][j] = buf_load(rs0, vo, (unsigned)min(ihalf[i] * 8 + j, a.C0) * (unsigned)HW * 4u);
     }
-    // the layer's weight fragments: [k-step 5][term 3], one 16-byte row per lane (pre-split by pack_weights_x3p16_k)
-    const u32x4* wq = reinterpret_cast<const u32x4*>(a.wp);
-    u32x4 afr[5][3];
+    // the layer's weight fragments: a 16-byte header (float {1 / scale, scale}: the x2h weight scale), [k-step 5][term 3] bf16 triples,
+    // then [k-step 5][term 2] fp16 pairs of scale * w — one 16-byte row per lane (pre-split by pack_weights_x3p16_k)
+    const u32x4* wq = reinterpret_cast<const u32x4*>(a.wp) + 1 + (MODE == 4 ? 15 * 64 : 0);
+    u32x4 afr[5][XT];
 #pragma unroll
     for (int s5 = 0; s5 < 5; ++s5)
 #pragma unroll
-      for (int t = 0; t < 3; ++t) afr[s5][t] = wq[(s5 * 3 + t) * 64 + lane];
+      for (int t = 0; t < XT; ++t) afr[s5][t] = wq[(s5 * XT + t) * 64 + lane];
     if (any_pro) {   // zero padding applies AFTER the fused affine/ReLU, as in the reference graph
       const bool relu = a.pro_relu & 1;
 #pragma unroll
@@ -228,16 +235,17 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
       if (ipos[i] >= 0) {
-        u32x4 t0, t1, t2;
+        u32x4 tt[XT];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          unsigned q0, q1, q2;
-          wt_split3_pair(xv[i][2 * j], xv[i][2 * j + 1], q0, q1, q2);
-          t0[j] = q0; t1[j] = q1; t2[j] = q2;
+          unsigned q0, q1, q2 = 0u;
+          if constexpr (XT == 3) wt_split3_pair(xv[i][2 * j], xv[i][2 * j + 1], q0, q1, q2);
+          else split2h_pair(xv[i][2 * j], xv[i][2 * j + 1], q0, q1);
+          tt[0][j] = q0; tt[1][j] = q1;
+          if constexpr (XT == 3) tt[2][j] = q2;
         }
-        Xq[(0 * 2 + ihalf[i]) * PEP + ipos[i]] = t0;
-        Xq[(1 * 2 + ihalf[i]) * PEP + ipos[i]] = t1;
-        Xq[(2 * 2 + ihalf[i]) * PEP + ipos[i]] = t2;
+#pragma unroll
+        for (int t = 0; t < XT; ++t) Xq[(t * 2 + ihalf[i]) * PEP + ipos[i]] = tt[t];
       }
     }
     __syncthreads();
@@ -253,19 +261,30 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
     for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
       for (int s5 = 0; s5 < 5; ++s5) {
-        u32x4 bfr[3];
+        u32x4 bfr[XT];
 #pragma unroll
-        for (int t = 0; t < 3; ++t) bfr[t] = Xq[(t * 2) * PEP + hsel + off[nt] + toff[s5]];
+        for (int t = 0; t < XT; ++t) bfr[t] = Xq[(t * 2) * PEP + hsel + off[nt] + toff[s5]];
         f32x4 c = acc[0][nt];
-        // the six leading cross terms, smallest first (as conv_x3.hip)
-        c = wt_mfma16x32(afr[s5][0], bfr[2], c);
-        c = wt_mfma16x32(afr[s5][1], bfr[1], c);
-        c = wt_mfma16x32(afr[s5][2], bfr[0], c);
-        c = wt_mfma16x32(afr[s5][0], bfr[1], c);
-        c = wt_mfma16x32(afr[s5][1], bfr[0], c);
-        c = wt_mfma16x32(afr[s5][0], bfr[0], c);
+        if constexpr (XT == 3) {
+          // the six leading cross terms, smallest first (as conv_x3.hip)
+          c = wt_mfma16x32(afr[s5][0], bfr[2], c);
+          c = wt_mfma16x32(afr[s5][1], bfr[1], c);
+          c = wt_mfma16x32(afr[s5][2], bfr[0], c);
+          c = wt_mfma16x32(afr[s5][0], bfr[1], c);
+          c = wt_mfma16x32(afr[s5][1], bfr[0], c);
+          c = wt_mfma16x32(afr[s5][0], bfr[0], c);
+        } else {
+          c = wt_mfma16x32h(afr[s5][0], bfr[1], c);
+          c = wt_mfma16x32h(afr[s5][1], bfr[0], c);
+          c = wt_mfma16x32h(afr[s5][0], bfr[0], c);
+        }
         acc[0][nt] = c;
       }
+    }
+    if constexpr (MODE == 4) {      // back to the operands' own scale (exact: powers of two) before bias / statistics / stores
+      const float inv = a.wp[0] / sx;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[0][nt] *= inv;
     }
     __syncthreads();      // the epilogue reuses the tile's LDS (Gram staging, statistics)
   } else {
@@ -632,7 +651,7 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
 
 template <int KS, int MODE, bool DB, int EPI>
 static int launch_fwd(const ConvArgs& a, hipStream_t st) {
-  constexpr int CB = (MODE == 0 || MODE == 3) ? 16 : 32 * MODE;
+  constexpr int CB = (MODE == 0 || MODE == 3 || MODE == 4) ? 16 : 32 * MODE;
   ConvArgs args = a;
   const bool narrow = a.W <= 16;  // 16x16 tiles for the deepest levels, 8x32 otherwise
   const int TW = narrow ? 16 : 32, TH = 256 / TW;
@@ -697,6 +716,7 @@ static int conv_fwd_impl(const float* in0, int C0, const float* in1, int C1, con
   a.ftail = ftail;
   a.bn_ss = bn.ss; a.bn_mean = bn.mean; a.bn_relu = bn.relu; a.bn_c0 = bnb ? bn.c0 : 0; a.bn_c1 = bnb ? bn.c1 : 0;
   a.in0 = in0; a.in1 = in1; a.wp = wpacked; a.bias = bias; a.pro0 = pro0; a.pro1 = pro1; a.out0 = out0; a.out1 = out1; a.stats = stats; a.mask = mask_ref; a.gram = gram;
+  a.in_amax = nullptr; a.in_scale = 1.f;
   a.B = B; a.H = H; a.W = W; a.C0 = C0; a.C1 = C1; a.Cin = C0 + C1; a.CinP = (a.Cin + 3) & ~3;
   a.Cout = Cout; a.CoutP = (Cout + 15) & ~15; a.Csplit = Csplit; a.pro_relu = pro_relu; a.relu_out = relu_out;
   a.tiles_x = a.tiles_y = 0;
@@ -745,10 +765,15 @@ extern "C" int wtpse_dgrad_bnb(const float* dy, int C, const float* wpacked, flo
 // fragments from wtpse_pack_conv16_x3.  Everything optional: bias, prologue, ReLU, BatchNorm (sum, sum^2) partials `stats`,
 // Gram partials `gram_partial` (Cout == 16), ReLU mask `mask_ref`, or — with bn_mean — the BatchNorm-backward epilogue of
 // wtpse_dgrad_bnb over all output channels (mask_ref = that layer's raw conv output).
+// Arithmetic: wtpse_x3_terms() == 2 -> x2h (MODE 4), unless the input is a GRADIENT (in_is_grad) whose amax table is not given — a
+// gradient has no scale known a priori, and an extra pass to find it costs more than this HBM-bound kernel gains: those launches stay
+// on x3 (the packed fragments carry both formats).
+extern int g_x3_terms;      // conv_x3.hip
 static int conv16_x3_impl(const float* in0, int C0, const unsigned short* wx16, const float* bias, const float* pro0,
                           int pro_relu, float* out0, float* stats, float* gram_partial, const float* mask_ref,
                           const float* bn_ss, const float* bn_mean, int bn_relu, int B, int H, int W, int Cout, int relu_out,
-                          void* stream, BnbTail tail = bnb_tail_none(), BnfTail ftail = bnf_tail_none()) {
+                          int in_is_grad, const unsigned* in_amax, void* stream, BnbTail tail = bnb_tail_none(),
+                          BnfTail ftail = bnf_tail_none()) {
   WTPSE_REQUIRE(in0 && wx16 && out0 && B > 0 && H > 0 && W > 0 && C0 > 0 && C0 <= 16 && Cout > 0 && Cout <= 16);
   WTPSE_REQUIRE(!(stats && relu_out) && !(gram_partial && (Cout != 16 || relu_out)));
   WTPSE_REQUIRE((((uintptr_t)wx16) & 15) == 0);
@@ -767,7 +792,13 @@ static int conv16_x3_impl(const float* in0, int C0, const unsigned short* wx16, 
   a.B = B; a.H = H; a.W = W; a.C0 = C0; a.C1 = 0; a.Cin = C0; a.CinP = 16;
   a.Cout = Cout; a.CoutP = 16; a.Csplit = Cout; a.pro_relu = pro_relu; a.relu_out = relu_out;
   a.tiles_x = a.tiles_y = 0;
+  a.in_amax = in_amax; a.in_scale = X3_FWD_SCALE;
   hipStream_t st = (hipStream_t)stream;
+  if (g_x3_terms == 2 && (!in_is_grad || in_amax)) {
+    if (bnb) return launch_fwd<3, 4, false, 2>(a, st);
+    if (mask_ref) return launch_fwd<3, 4, false, 1>(a, st);
+    return launch_fwd<3, 4, false, 0>(a, st);
+  }
   if (bnb) return launch_fwd<3, 3, false, 2>(a, st);
   if (mask_ref) return launch_fwd<3, 3, false, 1>(a, st);
   return launch_fwd<3, 3, false, 0>(a, st);
@@ -776,9 +807,9 @@ static int conv16_x3_impl(const float* in0, int C0, const unsigned short* wx16, 
 extern "C" int wtpse_conv16_x3(const float* in0, int C0, const unsigned short* wx16, const float* bias, const float* pro0,
                                int pro_relu, float* out0, float* stats, float* gram_partial, const float* mask_ref,
                                const float* bn_ss, const float* bn_mean, int bn_relu, int B, int H, int W, int Cout, int relu_out,
-                               void* stream) {
+                               int in_is_grad, const unsigned* in_amax, void* stream) {
   return conv16_x3_impl(in0, C0, wx16, bias, pro0, pro_relu, out0, stats, gram_partial, mask_ref, bn_ss, bn_mean, bn_relu, B, H, W,
-                        Cout, relu_out, stream);
+                        Cout, relu_out, in_is_grad, in_amax, stream);
 }
 
 // ---- wtpse_dgrad_bnb / wtpse_dgrad_x3_bnb / wtpse_conv16_x3(bn_mean) whose launch ALSO finishes the statistics: the last
@@ -813,7 +844,7 @@ extern "C" int wtpse_conv_fwd_bnf(const float* in0, int C0, const float* in1, in
   if (layout == 2) {
     WTPSE_REQUIRE(ksize == 3 && !in1 && C1 == 0 && !pro1);
     return conv16_x3_impl(in0, C0, static_cast<const unsigned short*>(wpacked), bias, pro0, pro_relu, out0, stats, nullptr, nullptr,
-                          nullptr, nullptr, 0, B, H, W, Cout, 0, stream, bnb_tail_none(), t);
+                          nullptr, nullptr, 0, B, H, W, Cout, 0, 0, nullptr, stream, bnb_tail_none(), t);
   }
   return conv_fwd_impl(in0, C0, in1, C1, static_cast<const float*>(wpacked), bias, pro0, pro1, pro_relu, out0, nullptr, Cout, stats,
                        B, H, W, Cout, ksize, 0, nullptr, nullptr, stream, BnbArgs{nullptr, nullptr, 0, 0, 0}, bnb_tail_none(), t);
@@ -838,26 +869,40 @@ extern "C" int wtpse_dgrad_bnb_coef(const float* dy, int C, const void* wpacked,
   if (layout == 2) {
     WTPSE_REQUIRE(ksize == 3 && !out1 && Csplit == Cout && bn_c0 == 0 && bn_c1 == Cout);
     return conv16_x3_impl(dy, C, static_cast<const unsigned short*>(wpacked), nullptr, nullptr, 0, out0, stats, nullptr, bn_y, bn_ss,
-                          bn_mean, bn_relu, B, H, W, Cout, 0, stream, t);
+                          bn_mean, bn_relu, B, H, W, Cout, 0, 1, in_amax, stream, t);
   }
   return conv_fwd_impl(dy, C, nullptr, 0, static_cast<const float*>(wpacked), nullptr, nullptr, nullptr, 0, out0, out1, Csplit, stats,
                        B, H, W, Cout, ksize, 0, bn_y, nullptr, stream, BnbArgs{bn_ss, bn_mean, bn_relu, bn_c0, bn_c1}, t);
 }
 
-// Weight fragments of the 16-channel x3 path, all convs of a network in one launch.  desc: n_desc x 8 ints {w_off, Cout, Cin,
+// Weight fragments of the 16-channel x3 / x2h path, all convs of a network in one launch.  desc: n_desc x 8 ints {w_off, Cout, Cin,
 // 9, fwd_off (-1: none), dgrad_off (-1: none), 0, 0}, w_off in floats into `params`, *_off in unsigned shorts into `packed`;
-// one direction = [5 k-steps][3 terms][64 lanes][8] bf16 = 7680 shorts:  lane = (row = lane & 15, g = lane >> 4),
+// one direction = 8 shorts of header (float {1 / scale, scale}) + [5 k-steps][3 terms][64 lanes][8] bf16 (x3: 7680 shorts) +
+// [5 k-steps][2 terms][64 lanes][8] fp16 of scale * w (x2h: 5120 shorts) = 12808 shorts:  lane = (row = lane & 15, g = lane >> 4),
 // tap = 2 s + (g >> 1), k = 8 (g & 1) + j;  forward: rows = Cout, k = Cin, w[row][k][tap];  data gradient: rows = Cin,
-// k = Cout, w[k][row][8 - tap];  zero beyond the layer's channels and for the tenth tap.
+// k = Cout, w[k][row][8 - tap];  zero beyond the layer's channels and for the tenth tap.  scale: the power of two that brings the
+// layer's largest |w| into [2^14, 2^15) (every workgroup of the layer finds it for itself: at most 2304 weights).
 __global__ __launch_bounds__(256) void pack_weights_x3p16_k(const float* __restrict__ params, const int* __restrict__ desc,
                                                             unsigned short* __restrict__ packed) {
   const int* d = desc + blockIdx.y * 8;
   const int w_off = d[0], Co = d[1], Ci = d[2];
   const float* w = params + w_off;
+  __shared__ float red[4];
+  float m = 0.f;
+  for (int e = threadIdx.x; e < Co * Ci * 9; e += 256) m = fmaxf(m, fabsf(w[e]));
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const float sc = x3_scale_from_amax(__builtin_bit_cast(unsigned, m));
   for (int dir = 0; dir < 2; ++dir) {
     const int base = d[4 + dir];
     if (base < 0) continue;
     const int R = dir == 0 ? Co : Ci, K = dir == 0 ? Ci : Co;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      float* hdr = reinterpret_cast<float*>(packed + base);
+      hdr[0] = 1.f / sc; hdr[1] = sc; hdr[2] = hdr[3] = 0.f;
+    }
     for (int e = blockIdx.x * 256 + threadIdx.x; e < 5 * 64 * 8; e += gridDim.x * 256) {
       const int j = e & 7, lane = (e >> 3) & 63, s5 = e >> 9;
       const int row = lane & 15, g = lane >> 4;
@@ -866,10 +911,14 @@ __global__ __launch_bounds__(256) void pack_weights_x3p16_k(const float* __restr
       if (tap < 9 && row < R && k < K) v = dir == 0 ? w[(row * Ci + k) * 9 + tap] : w[(k * Ci + row) * 9 + (8 - tap)];
       unsigned q0, q1, q2;
       wt_split3_pair(v, 0.f, q0, q1, q2);
-      unsigned short* o = packed + base;
+      unsigned short* o = packed + base + 8;
       o[((s5 * 3 + 0) * 64 + lane) * 8 + j] = (unsigned short)(q0 & 0xFFFFu);
       o[((s5 * 3 + 1) * 64 + lane) * 8 + j] = (unsigned short)(q1 & 0xFFFFu);
       o[((s5 * 3 + 2) * 64 + lane) * 8 + j] = (unsigned short)(q2 & 0xFFFFu);
+      split2h_pair(v * sc, 0.f, q0, q1);
+      unsigned short* oh = o + 5 * 3 * 64 * 8;
+      oh[((s5 * 2 + 0) * 64 + lane) * 8 + j] = (unsigned short)(q0 & 0xFFFFu);
+      oh[((s5 * 2 + 1) * 64 + lane) * 8 + j] = (unsigned short)(q1 & 0xFFFFu);
     }
   }
 }

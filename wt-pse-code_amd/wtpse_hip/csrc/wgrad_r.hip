@@ -290,6 +290,9 @@ __global__ __launch_bounds__((64 * WgradRGeom<MF, NF>::NW), 1) void wgrad_r_k(Wg
         if (PRO) {
           v0 = fmaxf(fmaf(v0, psc[n], psh[n]), plo[n]);
           v1 = fmaxf(fmaf(v1, psc[n], psh[n]), plo[n]);
+          // an odd batch's missing twin image reads zeros, which the prologue turns into act(shift): harmless while its dY is zero
+          // too, but a non-finite shift would make 0 * inf of it — the dead lanes' X is zero, explicitly
+          if (TWIN && !lane_live) v0 = v1 = 0.f;
         }
         unsigned qq[TERMS];
         split_pair(v0, v1, qq);
@@ -558,7 +561,7 @@ static int wgrad_r_impl(const float* dy, const float* x0, int C0, const float* x
   // x2h (wtpse_x3_terms(2)): every block shape, PRO always on (the X scale rides in the prologue coefficients); the fused-BatchNorm
   // form (aff) stays on three bf16 terms (nothing knows the largest magnitude of a dY that is never materialised)
 #define WR_LAUNCH2(M, N) hipLaunchKernelGGL((wgrad_r_k<M, N, true, false, false, 2>), grid, blk, 0, st, a)
-  if (g_x3_terms == 2 && !aff) {
+  if (g_x3_terms == 2 && !aff && (dy_amax || p.mf * p.nf >= 2)) {     // (16 x 16 blocks without an amax table: x3, see wtpse_hip.h)
     if (a.twin) {
       WTPSE_REQUIRE(p.mf == 2 && p.nf == 2 && !bias);
       hipLaunchKernelGGL((wgrad_r_k<2, 2, true, false, false, 2, true>), grid, blk, 0, st, a);

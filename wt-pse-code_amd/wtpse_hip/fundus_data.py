@@ -9,8 +9,12 @@
 
 Host side and Python as in the reference (PNG decoding is PIL's on both sides); what it hands on are DECODED uint8 arrays, which
 `DeviceInputPipeline` (input_pipeline.py) turns into the fp32 batch on the GPU.  Kept quirks: the Domain-4 centre crop is dead
-code in the reference (`self.splitid[0] == '4'` compares an int with a str, :180) and is not performed; pools that stay empty are
-dropped, so `dc` (the domain code) is the index among the NON-empty pools — 0 for every single-domain dataset train.py builds."""
+code in the reference (`self.splitid[0] == '4'` compares an int with a str, :180) and is not performed; empty pools are removed the
+reference's way — the first empty one, three times (:58-75) — so `dc` (the domain code) is the index among the pools that are left:
+0 for every single-domain dataset train.py builds; a file with an unknown prefix prints the reference's error line and STOPS the
+reading (:176-178).  One spelling differs without a difference: the reference tests `_target.mode is 'RGB'` (:193) — an identity
+test that holds in CPython because PIL's mode strings and the literal are the same interned constant — and this file writes `==`;
+the fixture's RGB masks (every fifth sample of oracle/fundus_tree.py) come out 'L' on both sides."""
 import os
 from glob import glob
 
@@ -41,7 +45,9 @@ class FundusTree:
             base = os.path.basename(item["image"])
             key = dataset_of(base)
             if key is None:
-                raise ValueError("unknown dataset prefix: %s" % base)          # the reference prints an error and stops reading
+                # as the reference: an error line, and reading STOPS — the pools keep what was read so far (:176-178)
+                print("[ERROR:] Unknown dataset!")
+                break
             img = Image.open(item["image"]).convert("RGB").resize((self.size, self.size), Image.LANCZOS)
             target = Image.open(item["label"])
             if target.mode == "RGB":
@@ -51,7 +57,14 @@ class FundusTree:
             pools[key][0].append(img)
             pools[key][1].append(target)
             pools[key][2].append(item["image"].split("/")[-1])
-        self.pools = {k: v for k, v in pools.items() if len(v[0]) > 0}
+        # the reference deletes the FIRST empty pool it meets, three times over (:58-75): with all four pools empty one stays
+        # (then __len__ is 0 and drawing from it raises, there as here)
+        for _ in range(3):
+            for k in list(pools):
+                if len(pools[k][0]) < 1:
+                    del pools[k]
+                    break
+        self.pools = pools
 
     def __len__(self):
         return max((len(v[0]) for v in self.pools.values()), default=-1)

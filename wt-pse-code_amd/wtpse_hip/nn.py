@@ -549,12 +549,13 @@ def _dgrad(layer, dy, split=None, mask_ref=None, below0=None, below1=None):
         else:
             layout, wptr = 0, root.packed_ptr(layer.wd_off)
         d0, d1, stats, coef = ops.dgrad_bnb(dy, wptr, layout, layer.cin, layer.k, below.y, below.ss, below.mean, below.relu, split,
-                                            below1 is not None and below0 is None, tail, _gamax(dy) if layout == 1 else None)
+                                            below1 is not None and below0 is None, tail,
+                                            _gamax(dy) if layout == 1 else getattr(dy, "wt_amax", None) if layout == 2 else None)
         if below0 is not None:
             return PreBN(d0, stats, coef), d1
         return d0, PreBN(d1, stats, coef)
     if layer.x16d_off >= 0 and split is None:
-        return ops.conv16_x3(dy, root.x3_ptr(layer.x16d_off), None, layer.cin, mask_ref=mask_ref)[0], None
+        return ops.conv16_x3(dy, root.x3_ptr(layer.x16d_off), None, layer.cin, mask_ref=mask_ref, grad_in=True)[0], None
     if layer.xd_off >= 0:
         return ops.conv_fwd_x3(dy, None, root.x3_ptr(layer.xd_off), None, layer.cin, layer.k, None, 0, False, False, split,
                                mask_ref, None, _gamax(dy))[:2]
@@ -643,8 +644,11 @@ def _wgrad(layer, dy, a0, a1=None, with_bias=True):
     if (X3 and X3_WGRAD and WGRAD_R and layer.k == 3 and
             ops.wgrad_r_supported(layer.cin, layer.cout, 3, a0.t.shape[1] if a1 is not None else 16, a0.t.shape[3]) and
             (db is None or (layer.cin % 32 != 0 and layer.cout % 32 != 0))):
+        # (the 16 x 16-channel blocks are HBM-bound: an extra pass over dY to find its scale costs more than x2h gains there — they
+        # take the table their dY's producer attached, or run in x3)
+        small = layer.cin % 32 != 0 and layer.cout % 32 != 0
         ops.conv_wgrad_r(dy, a0.t, a1.t if a1 is not None else None, dw, db, a0.pro, _relu_bits(a0, a1), False,
-                         a1.pro if a1 is not None else None, _gamax(dy))
+                         a1.pro if a1 is not None else None, getattr(dy, "wt_amax", None) if small else _gamax(dy))
         return
     if (X3 and X3_WGRAD and db is None and
             ops.wgrad_x3_supported(layer.cin, layer.cout, layer.k, a0.t.shape[1] if a1 is not None else 8)):

@@ -80,13 +80,15 @@ def conv_fwd_gram(in0, wpacked_ptr, bias, pro0=None, pro_relu=0, relu_out=False)
     return out, (partial, nblk // B)
 
 
-X16_SIZE = 5 * 3 * 64 * 8       # unsigned shorts of one direction of one conv in the 16-channel x3 layout
+X16_SIZE = 8 + 5 * 3 * 64 * 8 + 5 * 2 * 64 * 8      # unsigned shorts of one direction of one conv in the 16-channel layout: header, x3 and x2h fragments
 
 
 def conv16_x3(in0, wx16_ptr, bias, cout, pro0=None, pro_relu=0, relu_out=False, want_stats=False, want_gram=False, mask_ref=None,
-              bnb=None):
-    """3x3 conv with at most 16 input and 16 output channels in the x3 arithmetic (csrc/conv.hip MODE 3; include/wtpse_hip.h,
-    wtpse_conv16_x3).  bnb = (bn_y, bn_ss, bn_mean, bn_relu): the BatchNorm-backward epilogue of dgrad_bnb.
+              bnb=None, grad_in=False):
+    """3x3 conv with at most 16 input and 16 output channels in the x3 / x2h arithmetic (csrc/conv.hip MODE 3 / 4; include/wtpse_hip.h,
+    wtpse_conv16_x3).  bnb = (bn_y, bn_ss, bn_mean, bn_relu): the BatchNorm-backward epilogue of dgrad_bnb.  grad_in: in0 is a
+    gradient (a data-gradient launch): x2h only with the amax table its producer attached (`in0.wt_amax`), x3 otherwise — never an
+    extra pass for it.
     -> (out, stats or None, (gram partial, tiles per image) or None)."""
     _chk(in0, "in0"); _chk(pro0, "pro0"); _chk(mask_ref, "mask_ref")
     B, C0, H, W = in0.shape
@@ -102,7 +104,8 @@ def conv16_x3(in0, wx16_ptr, bias, cout, pro0=None, pro_relu=0, relu_out=False, 
         _chk(mask_ref, "bn_y"); _chk(bn_ss, "bn_ss"); _chk(bn_mean, "bn_mean")
         assert mask_ref.shape == out.shape
     L.call("wtpse_conv16_x3", ptr(in0), C0, wx16_ptr, ptr(bias), ptr(pro0), int(pro_relu), ptr(out), ptr(stats), ptr(gram),
-           ptr(mask_ref), ptr(bn_ss), ptr(bn_mean), int(bool(bn_relu)), B, H, W, cout, int(relu_out), stream_ptr())
+           ptr(mask_ref), ptr(bn_ss), ptr(bn_mean), int(bool(bn_relu)), B, H, W, cout, int(relu_out), int(bool(grad_in)),
+           ptr(getattr(in0, "wt_amax", None)) if grad_in else 0, stream_ptr())
     return out, stats, ((gram, nblk // B) if want_gram else None)
 
 
@@ -295,7 +298,7 @@ def dgrad_bnb(dy, wpacked_ptr, layout, cout, ksize, bn_y, bn_ss, bn_mean, bn_rel
         return out0, out1, stats, coef
     if layout == 2:
         L.call("wtpse_conv16_x3", ptr(dy), C, wpacked_ptr, 0, 0, 0, ptr(out0), ptr(stats), 0, ptr(bn_y), ptr(bn_ss), ptr(bn_mean),
-               int(bool(bn_relu)), B, H, W, cout, 0, stream_ptr())
+               int(bool(bn_relu)), B, H, W, cout, 0, 1, ptr(in_amax), stream_ptr())
     elif layout == 1:
         L.call("wtpse_dgrad_x3_bnb", ptr(dy), C, wpacked_ptr, ptr(out0), ptr(out1), csplit, ptr(bn_y), ptr(bn_ss), ptr(bn_mean),
                int(bool(bn_relu)), c0, c1, ptr(stats), B, H, W, cout, ksize, ptr(in_amax), stream_ptr())
