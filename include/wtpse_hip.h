@@ -87,9 +87,9 @@ int wtpse_x3_xcd(int on);
  * query; returns the previous setting.  A recorded launch plan (wtpse_plan_*) remembers the setting it was recorded under and
  * refuses to replay under another one. */
 int wtpse_x3_terms(int terms);
-/* An "amax table" carries the largest magnitude of a gradient tensor from its producer to the x2h kernels that consume it: 256
- * unsigneds (1 KB, 16-byte aligned) holding float bits of non-negative values in 16 shards, one per 64-byte line (workgroups fold their
- * maximum into shard (index % 16) with one atomic max; consumers take the maximum over the shards).  Producers with an `amax` argument
+/* An "amax table" carries the largest magnitude of a gradient tensor from its producer to the x2h kernels that consume it: 1024
+ * unsigneds (4 KB, 16-byte aligned) holding float bits of non-negative values in 64 shards, one per 64-byte line (waves / workgroups
+ * fold their maximum into shard (index % 64) with one no-return atomic max; consumers take the maximum over the shards).  Producers with an `amax` argument
  * (wtpse_bn_bwd*, wtpse_upsample2x_bwd*) fill the table of the gradient they write when amax != NULL: the table must be ZERO on entry.
  * wtpse_amax zeroes and fills the table of an existing tensor (one extra pass: the slow way). */
 int wtpse_amax(const float* x, long long n, unsigned* amax_table, void* stream);

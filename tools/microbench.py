@@ -135,6 +135,15 @@ def main():
             dg = torch.zeros(C, device=DEV); db = torch.zeros(C, device=DEV)
             med, _ = timeit(lambda: ops.bn_bwd(dz, y, ss, True, gamma, mean, invstd, dg, db), a.reps)
             print("bn_bwd (reduce+finalize+apply) [%d,%d,%d,%d]  %7.1f us  %6.0f GB/s (5 passes)" % (B, C, H, H, med, 5 * y.numel() * 4.0 / med / 1e3))
+    if a.only in ("", "bn"):
+        # the apply pass alone (dy = k1 g + k2 y + k3: what remains of a BatchNorm backward whose reductions rode in the producing data
+        # gradient), with the amax table of dy it fills under the x2h arithmetic
+        for C, H in ((32, 256), (64, 128), (128, 64), (256, 32)):
+            g = torch.randn(B, C, H, H, device=DEV)
+            y = torch.randn(B, C, H, H, device=DEV)
+            coef = torch.rand(C, 3, device=DEV)
+            med, _ = timeit(lambda: ops.bn_bwd_apply_coef(g, y, coef), a.reps)
+            print("bn_bwd_apply_coef [%d,%d,%d,%d]  %7.1f us  %6.0f GB/s (3 passes; x3_terms %d)" % (B, C, H, H, med, 3 * y.numel() * 4.0 / med / 1e3, ops.x3_terms()))
     if a.only in ("", "pw"):
         y = torch.randn(B, 16, 256, 256, device=DEV)
         ss = torch.rand(16, 2, device=DEV)

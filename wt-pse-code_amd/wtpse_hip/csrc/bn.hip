@@ -188,46 +188,43 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_k(const float* __restrict
   }
 }
 
-// dy = k1 * dz*[z>0] + k2*y + k3.  Work items = (plane bc, chunk of 1024 | 256 elements), nitems = B*C*bpp of them; the workgroups
-// walk them grid-stride (at most APPLY_MAX_WGS workgroups: each ends with ONE atomic when `amax` — the amax table of dy, common.h,
-// zero on entry — is wanted: dy is the gradient operand of the x2h convolutions that consume it).
-constexpr int APPLY_MAX_WGS = 2048;      // 8 workgroups of 256 threads per CU: one resident round
+// dy = k1 * dz*[z>0] + k2*y + k3 ; one item (plane bc, chunk of 1024 | 256 elements) per workgroup.  amax (optional): the amax table
+// of dy (common.h; zero on entry) — dy is the gradient operand of the x2h convolutions that consume it; every wave folds its maximum
+// into a shard with one no-return atomic.
 template <bool VEC>
 __global__ __launch_bounds__(256) void bn_bwd_apply_k(const float* __restrict__ dz, const float* __restrict__ y,
                                                       const float* __restrict__ ss, int relu,
-                                                      const float* __restrict__ coef, int C, int HW, int bpp, int nitems,
+                                                      const float* __restrict__ coef, int C, int HW, int bpp,
                                                       float* __restrict__ dy, unsigned* __restrict__ amax) {
+  const int bc = blockIdx.x / bpp, blk = blockIdx.x - bc * bpp, c = bc % C;
+  const float sc = ss[2 * c], sf = ss[2 * c + 1];
+  const float k1 = coef[3 * c], k2 = coef[3 * c + 1], k3 = coef[3 * c + 2];
+  const size_t base = (size_t)bc * HW;
   unsigned am = 0u;
-  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
-    const int bc = item / bpp, blk = item - bc * bpp, c = bc % C;
-    const float sc = ss[2 * c], sf = ss[2 * c + 1];
-    const float k1 = coef[3 * c], k2 = coef[3 * c + 1], k3 = coef[3 * c + 2];
-    const size_t base = (size_t)bc * HW;
-    if (VEC) {
-      int p = (blk * 256 + threadIdx.x) * 4;
-      if (p < HW) {
-        float4 g = *reinterpret_cast<const float4*>(dz + base + p);
-        float4 v = *reinterpret_cast<const float4*>(y + base + p);
-        float4 o;
-        o.x = fmaf(k1, (relu && !(fmaf(v.x, sc, sf) > 0.f)) ? 0.f : g.x, fmaf(k2, v.x, k3));
-        o.y = fmaf(k1, (relu && !(fmaf(v.y, sc, sf) > 0.f)) ? 0.f : g.y, fmaf(k2, v.y, k3));
-        o.z = fmaf(k1, (relu && !(fmaf(v.z, sc, sf) > 0.f)) ? 0.f : g.z, fmaf(k2, v.z, k3));
-        o.w = fmaf(k1, (relu && !(fmaf(v.w, sc, sf) > 0.f)) ? 0.f : g.w, fmaf(k2, v.w, k3));
-        *reinterpret_cast<float4*>(dy + base + p) = o;
-        am = max(am, max(max(amax_bits(o.x), amax_bits(o.y)), max(amax_bits(o.z), amax_bits(o.w))));
-      }
-    } else {
-      int p = blk * 256 + threadIdx.x;
-      if (p < HW) {
-        float g = dz[base + p], v = y[base + p];
-        if (relu && !(fmaf(v, sc, sf) > 0.f)) g = 0.f;
-        const float o = fmaf(k1, g, fmaf(k2, v, k3));
-        dy[base + p] = o;
-        am = max(am, amax_bits(o));
-      }
+  if (VEC) {
+    int p = (blk * 256 + threadIdx.x) * 4;
+    if (p < HW) {
+      float4 g = *reinterpret_cast<const float4*>(dz + base + p);
+      float4 v = *reinterpret_cast<const float4*>(y + base + p);
+      float4 o;
+      o.x = fmaf(k1, (relu && !(fmaf(v.x, sc, sf) > 0.f)) ? 0.f : g.x, fmaf(k2, v.x, k3));
+      o.y = fmaf(k1, (relu && !(fmaf(v.y, sc, sf) > 0.f)) ? 0.f : g.y, fmaf(k2, v.y, k3));
+      o.z = fmaf(k1, (relu && !(fmaf(v.z, sc, sf) > 0.f)) ? 0.f : g.z, fmaf(k2, v.z, k3));
+      o.w = fmaf(k1, (relu && !(fmaf(v.w, sc, sf) > 0.f)) ? 0.f : g.w, fmaf(k2, v.w, k3));
+      *reinterpret_cast<float4*>(dy + base + p) = o;
+      am = max(max(amax_bits(o.x), amax_bits(o.y)), max(amax_bits(o.z), amax_bits(o.w)));
+    }
+  } else {
+    int p = blk * 256 + threadIdx.x;
+    if (p < HW) {
+      float g = dz[base + p], v = y[base + p];
+      if (relu && !(fmaf(v, sc, sf) > 0.f)) g = 0.f;
+      const float o = fmaf(k1, g, fmaf(k2, v, k3));
+      dy[base + p] = o;
+      am = amax_bits(o);
     }
   }
-  if (amax) amax_publish_block(amax, am, blockIdx.x);
+  if (amax) amax_publish_wave(amax, am, blockIdx.x * 4u + (threadIdx.x >> 6));
 }
 
 // Small maps (the 16x16 / 32x32 levels): the three launches above cost 23-30 us of mostly launch latency for a few MB.
@@ -311,13 +308,12 @@ static inline bool vec_ok(int HW, const void* a, const void* b, const void* c) {
 // the apply pass dy = k1 [masked] dz + k2 y + k3 (+ the amax table of dy, zero on entry, or null)
 static void launch_apply(const float* dz, const float* y, const float* ss, int relu, const float* coef, float* dy, int B, int C, int HW,
                          unsigned* amax, hipStream_t st) {
-  const bool vec = vec_ok(HW, dz, y, dy);
-  const int bpp = ceil_div(HW, vec ? 1024 : 256);
-  const long long nitems = (long long)bpp * B * C;
-  // without an amax table: one item per workgroup, as rounds 1-4 launched it; with: at most APPLY_MAX_WGS workgroups walk the items
-  const int grid = (int)((amax && nitems > APPLY_MAX_WGS) ? APPLY_MAX_WGS : nitems);
-  if (vec) hipLaunchKernelGGL(bn_bwd_apply_k<true>, dim3(grid), dim3(256), 0, st, dz, y, ss, relu, coef, C, HW, bpp, (int)nitems, dy, amax);
-  else hipLaunchKernelGGL(bn_bwd_apply_k<false>, dim3(grid), dim3(256), 0, st, dz, y, ss, relu, coef, C, HW, bpp, (int)nitems, dy, amax);
+  if (vec_ok(HW, dz, y, dy))
+    hipLaunchKernelGGL(bn_bwd_apply_k<true>, dim3(ceil_div(HW, 1024) * B * C), dim3(256), 0, st, dz, y, ss, relu, coef, C, HW,
+                       ceil_div(HW, 1024), dy, amax);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_k<false>, dim3(ceil_div(HW, 256) * B * C), dim3(256), 0, st, dz, y, ss, relu, coef, C, HW,
+                       ceil_div(HW, 256), dy, amax);
 }
 
 extern "C" int wtpse_bn_finalize(const float* stats_partial, int nblk, int C, long long count, const float* gamma,

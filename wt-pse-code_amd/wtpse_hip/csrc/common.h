@@ -88,10 +88,12 @@ constexpr float X3_FWD_SCALE = 16.f;
 constexpr float X3_H_MAX = 65504.f;
 
 // The largest magnitude of a gradient tensor travels as an "amax table": AMAX_SHARDS unsigneds (float bits of non-negative values:
-// they order like their bit patterns), one per 64-byte line, zero before the tensor's producer runs.  Producers fold their workgroup's
-// maximum into shard (workgroup index % AMAX_SHARDS) with one no-return atomic max — a few thousand workgroups finishing together
-// on ONE word would queue ~12 ns each at the memory side (MI355X_MICROARCH.md, fan-in); consumers take the maximum of the shards.
-constexpr int AMAX_SHARDS = 16, AMAX_STRIDE = 16, AMAX_WORDS = AMAX_SHARDS * AMAX_STRIDE;
+// they order like their bit patterns), one per 64-byte line, zero before the tensor's producer runs.  Producers fold a wave's (or a
+// workgroup's) maximum into shard (index % AMAX_SHARDS) with one NO-RETURN atomic max — fire and forget: nothing waits for it — and
+// consumers take the maximum of the shards.  64 shards: the largest producer launch (65 536 workgroups of four waves in ~140 us) sends
+// a shard one atomic per ~35 ns, above the ~12 ns one word takes at the memory side (MI355X_MICROARCH.md, fan-in); on ONE word the
+// atomics of a launch would queue for milliseconds.
+constexpr int AMAX_SHARDS = 64, AMAX_STRIDE = 16, AMAX_WORDS = AMAX_SHARDS * AMAX_STRIDE;
 __device__ __forceinline__ unsigned amax_bits(float v) { return __builtin_bit_cast(unsigned, v) & 0x7FFFFFFFu; }
 __device__ __forceinline__ unsigned amax_bits4(f32x4 v) {
   return max(max(amax_bits(v[0]), amax_bits(v[1])), max(amax_bits(v[2]), amax_bits(v[3])));
@@ -107,6 +109,13 @@ __device__ __forceinline__ void amax_publish_block(unsigned* table, unsigned m, 
     for (int i = 1; i < nw; ++i) m = max(m, amax_red[i]);
     if (m) (void)__hip_atomic_fetch_max(table + (shard_seed % AMAX_SHARDS) * AMAX_STRIDE, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+}
+// every lane of a full wave calls (no barrier, no LDS: for streaming kernels that run one small item per workgroup — a persistent,
+// one-atomic-per-workgroup form of the BatchNorm-backward apply pass measured 14-29 % slower than this)
+__device__ __forceinline__ void amax_publish_wave(unsigned* table, unsigned m, unsigned shard_seed) {
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m)
+    (void)__hip_atomic_fetch_max(table + (shard_seed % AMAX_SHARDS) * AMAX_STRIDE, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // consumer side (any full wave): the maximum over the shards, wave-uniform
 __device__ __forceinline__ unsigned amax_read(const unsigned* table) {

@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_v_k(const float* __restric
     *reinterpret_cast<float4*>(dst) = o;
     am = max(am, max(max(amax_bits(o.x), amax_bits(o.y)), max(amax_bits(o.z), amax_bits(o.w))));
   }
-  if (amax) amax_publish_block(amax, am, blockIdx.x + blockIdx.y);
+  if (amax) amax_publish_wave(amax, am, (blockIdx.x + blockIdx.y * gridDim.x) * 4u + (threadIdx.x >> 6));
 }
 
 // F.interpolate(x, size=(Ho,Wo), mode="bilinear") with align_corners=False (Trainer.py:206-209): validation resizes the
@@ -772,17 +772,9 @@ extern "C" int wtpse_upsample2x_fwd_stats(const float* x, float* out, float* sta
   hipLaunchKernelGGL(upsample2x_fwd4_v_k, PLANE_GRID((H + 1) * (W / 2), B * C), dim3(256), 0, ST, x, nullptr, 0, out, stats, B * C, C, H, W);
   return wtpse_status();
 }
-// amax (optional): the amax table (common.h) of dx, ZERO on entry — dx is the dY of the 1x1 convolution in front of the upsampling.
-// With it the launch is capped at ~4096 workgroups (one atomic each at the end; the planes loop inside the kernel).
-static inline dim3 up_bwd_grid(int per_plane, int planes, bool with_amax) {
-  const unsigned gx = (unsigned)((per_plane + 255) / 256);
-  unsigned gy = (unsigned)(planes < 32768 ? planes : 32768);
-  if (with_amax) {
-    const unsigned cap = gx >= 4096u ? 1u : 4096u / gx;
-    if (gy > cap) gy = cap;
-  }
-  return dim3(gx, gy);
-}
+// amax (optional): the amax table (common.h) of dx, ZERO on entry — dx is the dY of the 1x1 convolution in front of the upsampling
+// (every wave folds its maximum into a shard with one no-return atomic).
+static inline dim3 up_bwd_grid(int per_plane, int planes, bool) { return PLANE_GRID(per_plane, planes); }
 extern "C" int wtpse_amax(const float* x, long long n, unsigned* amax_table, void* stream);
 extern "C" int wtpse_upsample2x_bwd(const float* dout, float* dx, int accumulate, int B, int C, int H, int W, unsigned* amax, void* stream) {
   WTPSE_REQUIRE(dout && dx && B > 0 && C > 0 && H > 0 && W > 0);

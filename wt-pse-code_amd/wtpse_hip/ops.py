@@ -119,9 +119,9 @@ def x3_terms():
     return lib().query("wtpse_x3_terms", -1)
 
 
-AMAX_WORDS = 256            # unsigneds of one amax table (include/wtpse_hip.h, wtpse_amax)
+AMAX_WORDS = 1024           # unsigneds of one amax table (include/wtpse_hip.h, wtpse_amax): 64 shards, one per 64-byte line
 _AMAX = {}
-_AMAX_TABLES = 512          # tables per arena (512 KB): a backward pass of the largest network hands out ~120
+_AMAX_TABLES = 512          # tables per arena (2 MB): a backward pass of the largest network hands out ~120
 
 
 def amax_begin(device):
@@ -136,7 +136,7 @@ def amax_begin(device):
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError("the amax arena must exist before a step is captured: HipNet.ensure_ready() creates it")
         st = _AMAX[device] = [torch.empty(_AMAX_TABLES * AMAX_WORDS, dtype=torch.int32, device=device), 0]
-    zero_(st[0])           # (whatever the arithmetic: 512 KB, ~2 us — a table handed out is zero, always)
+    zero_(st[0])           # (whatever the arithmetic: 2 MB, ~2 us — a table handed out is zero, always)
     st[1] = 0
 
 
