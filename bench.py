@@ -237,7 +237,7 @@ def unet_layer_rooflines(B, H, dev):
 
 
 FAMILIES = (("x3_conv", ("conv_x3_k", "conv_x3r_k")), ("x3_wgrad", ("wgrad_r_k<2", "wgrad_r_k<1, 2", "wgrad_r_k<2, 1", "conv_wgrad_x3_k", "wgrad_fold4_k")),
-            ("bn_backward", ("bn_bwd_",)), ("conv16", ("conv_fwd_k<3, 3", "wgrad_r_k<1, 1")), ("heads", ("head_",)),
+            ("bn_backward", ("bn_bwd_",)), ("conv16", ("conv_fwd_k<3, 3", "conv_fwd_k<3, 4", "wgrad_r_k<1, 1")), ("heads", ("head_",)),
             ("conv_fp32", ("conv_fwd_k", "conv_wgrad_k", "wgrad_reduce_k")))
 
 
@@ -250,6 +250,15 @@ def dominant_kernel_share():
              or sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_b32_kernel_stats.csv"))))
     if not files:
         return None
+    # the profile belongs to the library it was measured on: profiles/r<NN>_STAMP.json carries that library's source hash
+    # (tools/profile_round.sh); a profile of OTHER kernels than the ones loaded now is named, but no in-step rate is derived from it
+    stamp_path = os.path.join(ROOT, "profiles", os.path.basename(files[-1]).split("_")[0] + "_STAMP.json")
+    stamp_ok = None
+    try:
+        from wtpse_hip import build
+        stamp_ok = json.load(open(stamp_path)).get("source_hash") == build.source_hash()
+    except (OSError, ValueError):
+        pass
     with open(files[-1]) as f:
         rows = [r for r in csv.DictReader(f) if not r["Name"].startswith("__amd_rocclr")]
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
@@ -264,7 +273,7 @@ def dominant_kernel_share():
     return {"profile": os.path.relpath(files[-1], ROOT), "family": top, "percent": 100.0 * fam[top] / tot,
             "families_percent": {k: round(100.0 * v / tot, 1) for k, v in sorted(fam.items(), key=lambda kv: -kv[1])},
             "kernel": top, "steps_in_profile": steps, "family_ms_per_step": (fam[top] / steps / 1e6) if steps else None,
-            "all_kernels_ms_per_step": (tot / steps / 1e6) if steps else None}
+            "all_kernels_ms_per_step": (tot / steps / 1e6) if steps else None, "same_library": stamp_ok}
 
 
 # U-Net passes of one full iteration on the x3 forward / data-gradient family (calls A-D, Trainer.py:766-914; dead teacher
@@ -277,7 +286,7 @@ def in_step_fraction(dom, un, B):
     """The leading family's rate INSIDE the step, from the committed back-to-back (single-stream) rocprofv3 summary: the FLOPs one
     step issues on that family (per-layer table of this run: which layers run on the x3 kernels, forward / data gradient counted
     separately) / the family's summed kernel time per step in that profile.  Not measured by this run."""
-    if not dom or not dom.get("family_ms_per_step"):
+    if not dom or not dom.get("family_ms_per_step") or not dom.get("same_library"):
         return None
     rows = un["layers"]
     f = sum(r["flop"] for r in rows if r["fwd_path"] == "x3")
@@ -601,6 +610,10 @@ def compact_line(line):
         out[k] = o
     if copy16:
         out["copy_yardstick_gbs"] = copy16
+    sh = line.get("step_hbm")
+    if sh:
+        out["step_hbm"] = {"gb_per_step": sh["gb_per_step"], "floor_ms_at_copy_rate": sh["floor_ms_at_copy_rate"],
+                           "floor_frac_of_step": sh["floor_frac_of_step"], "source": sh["source"]}
     s1 = line.get("configs1_seg_only")
     if s1:
         out["configs1_seg_only"] = {k: {"value": s1[k]["value"], "ms_per_step": s1[k]["ms_per_step"]} for k in ("f32", "bf16") if k in s1}
@@ -639,6 +652,28 @@ def emit(line, args):
         small = json.dumps(c)
     assert len(small) < COMPACT_LIMIT, "bench line too long for the driver's parser: %d bytes" % len(small)
     print(small, flush=True)
+
+
+def step_hbm_traffic(ms_per_step, copy_gbs):
+    """HBM bytes ONE training step moves (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over whole steps, calibrated on the copy
+    kernels: tools/pmc_step_traffic.py -> profiles/r<NN>_step_traffic.json, same-library stamp as the in-step profile) and what that
+    traffic alone costs at this box's own streaming-copy rate: the HBM floor of the step as it is scheduled now."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_step_traffic.json")))
+    if not files:
+        return None
+    try:
+        from wtpse_hip import build
+        stamp = json.load(open(os.path.join(ROOT, "profiles", os.path.basename(files[-1]).split("_")[0] + "_STAMP.json")))
+        if stamp.get("source_hash") != build.source_hash():
+            return None
+        t = json.load(open(files[-1]))
+    except (OSError, ValueError):
+        return None
+    gb = t["_total"]["GB_per_step"]
+    floor_ms = gb / copy_gbs * 1e3 if copy_gbs else None
+    return {"gb_per_step": gb, "floor_ms_at_copy_rate": floor_ms, "floor_frac_of_step": (floor_ms / ms_per_step) if floor_ms else None,
+            "by_family_gb": {k: (v["read_MB_per_step"] + v["write_MB_per_step"]) / 1e3 for k, v in t.items() if not k.startswith("_")},
+            "source": "committed %s (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes over whole steps), not this run" % os.path.relpath(files[-1], ROOT)}
 
 
 def _x3_on():
@@ -847,6 +882,8 @@ def main():
             head["in_step_frac"] = ins["frac"] if ins else None
             head["in_step"] = ins
             line["roofline"] = dict(head, dominant_in_profile=dom)
+            if (B, H) == (32, 256) and full and args.dtype == "f32":
+                line["step_hbm"] = step_hbm_traffic(line["ms_per_step"], kr["copy_w16"]["gbs"])
             line["roofline_unet_layers"] = {"what": "every convolution of one U-Net as the step launches it (B=%d): FLOP-weighted TFLOP/s over the "
                                                     "layers on the x3 kernels, per direction, and the per-layer rows" % B,
                                             "fwd": un["fwd"], "dgrad": un["dgrad"], "wgrad": un["wgrad"], "fwd_dgrad": un["fwd_dgrad"],

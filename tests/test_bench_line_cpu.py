@@ -23,6 +23,9 @@ def test_compact_line_is_small_and_complete():
     if "roofline_unet_layers" not in full:        # a compact record (round 5 on): the detail file sits beside it
         full = json.load(open(recs[-1].replace(".json", "_detail.json")))
     dom = b.dominant_kernel_share()
+    assert dom is not None and "same_library" in dom          # the committed profile is tied to the library it was measured on
+    assert b.in_step_fraction(dict(dom, same_library=False), {"layers": full["roofline_unet_layers"]["layers"]}, 32) is None
+    dom["same_library"] = True                                  # (this test is about the line, whatever library is built here)
     ins = b.in_step_fraction(dom, {"layers": full["roofline_unet_layers"]["layers"]}, 32)
     assert ins is not None and 0.05 < ins["frac"] < 1.0
     full["roofline"].update(in_step=ins, in_step_frac=ins["frac"], dominant_in_profile=dom)
