@@ -372,7 +372,7 @@ def kernel_rooflines(B, H, dev):
     a16s = [E.Act(x, p16, True) for x in x16s]
     nb16 = 2.0 * B * C16 * H * H * 4
     ms = time_kernel([(lambda a=a: E._conv(n16.conv, a, None, False, True)) for a in a16s])
-    out["c16_fwd"] = {"kernel": "conv_fwd_k<3,%d,5> 16->16 3x3 @%dx%d B=%d (BatchNorm+ReLU prologue, bias, BatchNorm partials)" % (3 if E.X16 else 0, H, H, B),
+    out["c16_fwd"] = {"kernel": "conv_fwd_k<3,%d,5> 16->16 3x3 @%dx%d B=%d (BatchNorm+ReLU prologue, bias, BatchNorm partials)" % ((4 if X3_TERMS == 2 else 3) if E.X16 else 0, H, H, B),
                       "ms": ms, "gbs": nb16 / ms / 1e6, "bytes_per_launch": nb16, "tflops": 2.0 * 16 * 16 * 9 * H * H * B / ms / 1e9}
     n16.begin_backward()
     ms = time_kernel([(lambda a=a, d=d: E._wgrad(n16.conv, d, a, None, with_bias=True)) for a, d in zip(a16s, dy16s)])

@@ -26,7 +26,7 @@ sys.path[:0] = [os.path.join(ROOT, "wt-pse-code_amd")]
 KERNELS = {"x3_conv": (("conv_x3_k<3", "conv_x3r_k<"), 4, 4),      # tile loader: dword buffer loads; epilogue: dword buffer stores
            "x3_wgrad": (("wgrad_r_k<2, 2",), 16, 16),
            "conv": (("conv_fwd_k<3, 2, 5",), 4, 4),
-           "c16_fwd": (("conv_fwd_k<3, 3, 5",), 4, 4), "c16_wgrad": (("wgrad_r_k<1, 1",), 16, 16),
+           "c16_fwd": (("conv_fwd_k<3, 3, 5", "conv_fwd_k<3, 4, 5"), 4, 4), "c16_wgrad": (("wgrad_r_k<1, 1",), 16, 16),
            "wt_fwd": (("gram_partial_k",), 16, 16), "wt_bwd": (("gram_bwd_k",), 16, 16),
            "dwt_haar": (("dwt2_stream_k<0",), 4, 4), "dwt_db2": (("dwt2_stream_k<1",), 4, 4),
            "copy_w16": (("copy_w16_k",), 16, 16), "copy_w4": (("copy_w4_k",), 4, 4)}

@@ -62,17 +62,6 @@ struct ConvArgs {
   int xcd_tiles;       // > 0: tiles per XCD — workgroup b works on tile (b % 8) * xcd_tiles + b / 8 (see conv_fwd_k); 0: tile = b
 };
 
-// Phase stamps for tools/probe/conv_stamps.py (never compiled into libwtpse_hip.so): thread 0 of every workgroup
-// records s_memtime at the phase boundaries of the forward kernel.
-#ifdef WTPSE_STAMPS
-__device__ unsigned long long* g_stamps = nullptr;
-extern "C" int wtpse_probe_set_stamps(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &p, sizeof(p)); }
-#define STAMP(i) do { if (g_stamps && threadIdx.x == 0) g_stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 64 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-#define STAMPV(i, v) do { if (g_stamps && threadIdx.x == 0) g_stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 64 + (i)] = (v); } while (0)
-#else
-#define STAMP(i)
-#define STAMPV(i, v)
-#endif
 
 template <bool P16> struct AccT { typedef f32x16 type; };
 template <> struct AccT<true> { typedef f32x4 type; };
@@ -96,7 +85,7 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
   constexpr int PE = PITCH * ROWS;
   // every thread stores all of its NPOS tile positions, valid or not (positions past PE land in the plane's padding):
   // the loader has no per-element branch, which matters because beside another wave's MFMA stream each instruction of
-  // this phase costs about one MFMA slot (tools/probe/conv_stamps.py)
+  // this phase costs about one MFMA slot (phase stamps of round 1: profiles/r01_conv_phase_stamps.txt)
   constexpr int NPOS = (PE + 255) / 256;
   constexpr int S = PlaneStride<NPOS * 256>::value;
   constexpr bool XP = (MODE == 3 || MODE == 4);    // 16-cout path in the x3 (MODE 3) / x2h (MODE 4) arithmetic (3x3, Cin <= 16)
@@ -364,19 +353,13 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
 #pragma unroll
     for (int it = 0; it < NW; ++it) *reinterpret_cast<f32x4*>(Ws + (tid + 256 * it) * 4) = wv[it];
   };
-
-  STAMP(0);
-  STAMPV(1, (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32));
   if (DB) issue_loads(0);
   for (int c0 = 0; c0 < a.CinP; c0 += KC) {
     const int kc = min(KC, a.CinP - c0);
     __syncthreads();   // the previous chunk's MFMAs are done with LDS
-    STAMP(2 + 4 * (c0 / KC));
     if (!DB) issue_loads(c0);
     stash(c0);
-    STAMP(3 + 4 * (c0 / KC));
     __syncthreads();
-    STAMP(4 + 4 * (c0 / KC));
     if (DB && c0 + KC < a.CinP) issue_loads(c0 + KC);
     // ---- MFMA
     const int nq = kc / KQ;
@@ -400,10 +383,8 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mfma(av[t][mt], bv[t][nt], acc[mt][nt]);
     }
-    STAMP(5 + 4 * (c0 / KC));
   }
   }
-  STAMP(60);
   if (a.bias) {
     float bz[MT][NACC];
 #pragma unroll
@@ -435,7 +416,7 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
   // vmcnt counts loads and stores in one in-order queue on gfx9 and s_waitcnt operands are static.  A load issued
   // after a store cannot be waited on without waiting for that store's write acknowledgement (1-2 us), and around a
   // store inside an exec-mask branch the compiler must assume the store was skipped, so every wait behind it drains
-  // the queue (measured with tools/probe/conv_stamps.py: the epilogue took 60k cycles, 21 % of a workgroup's life).
+  // the queue (measured with phase stamps, profiles/r01_conv_phase_stamps.txt: the epilogue took 60k cycles, 21 % of a workgroup's life).
   // Hence: the biases come from LDS (added after the sum, as the reference does), the ReLU-mask loads of an M block are issued before that
   // block's first store, and loads/stores are branch-free buffer operations: the lane's pixel (and the +4 channels of
   // the upper half-wave) sit in a per-lane voffset computed once, the register's first channel in the scalar soffset,
@@ -646,7 +627,6 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
       bnf_tail<CB>(tk, a.ftail, a.stats, a.Cout, cout0, tile, cblk, tid, reinterpret_cast<double*>(red),
                    reinterpret_cast<int*>(red + 4 * CB));
   }
-  STAMP(61);
 }
 
 template <int KS, int MODE, bool DB, int EPI>
@@ -1055,15 +1035,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_k(WgradArgs a) {
   double db = 0.0;
 
   const int tiles_per_img = a.tiles_x * a.tiles_y;
-  STAMP(0);
-  STAMPV(1, (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32));
   int it = 0;
   for (int tile = ky; tile < a.ntiles; tile += gridDim.y, ++it) {
     const int b = tile / tiles_per_img;
     const int trem = tile - b * tiles_per_img;
     const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
     __syncthreads();
-    if (it < 8) STAMP(2 + 7 * it);
     // ---- tile loads, batched: every global load of a phase is issued before the first LDS store
     // dY tile [MB couts][256 pixels] (this thread: pixel `tid` of every channel), zero outside the image / beyond Cout
     const int gyp = ty * TH + (tid >> TWL), gxp = tx * TW + (tid & (TW - 1));
@@ -1106,7 +1083,6 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_k(WgradArgs a) {
 #pragma unroll
         for (int i = 0; i < NPOS; ++i) xv[c][i] = buf_load(rsx, voff[i], soff);
       }
-      if (it < 8) STAMP(3 + 7 * it + 2 * g);
       if (any_pro) {
         const bool relu = xfirst ? (a.pro_relu & 1) : (a.pro_relu & 2);
         const float* pro = xfirst ? a.pro0 : a.pro1;
@@ -1129,10 +1105,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_k(WgradArgs a) {
 #pragma unroll
         for (int i = 0; i < NPOS; ++i)
           if (lpos[i] >= 0) Xs[(g * 16 + c) * SX + lpos[i]] = xv[c][i];
-      if (it < 8) STAMP(4 + 7 * it + 2 * g);
     }
     __syncthreads();
-    if (it < 8) STAMP(7 + 7 * it);
     if (a.dbias && group == 0) {  // bias gradient: plain per-channel sum of the dY tile
       int c = tid / (256 / MB), part = tid % (256 / MB);
       constexpr int PER = MB;     // 256 pixels / (256/MB) threads
@@ -1142,7 +1116,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_k(WgradArgs a) {
     }
     // MFMA loop, software pipelined by hand: the LDS reads of step s+1 are in flight while the MFMAs of step s issue
     // back to back (left to the compiler, every MFMA sat behind its own ds_read + s_waitcnt: 172 cycles per MFMA
-    // instead of 64, measured with tools/probe/conv_stamps.py wgrad).  sched_barrier keeps the two groups apart.
+    // instead of 64, measured with phase stamps in round 1).  sched_barrier keeps the two groups apart.
     constexpr int STEPS = 64 / KQ;
     const float* yrow = Ys + j * SA + wave * 64 + kl;
     auto lds_step = [&](int s, float& av, float (&bv)[MAXNB]) {
@@ -1173,10 +1147,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_k(WgradArgs a) {
       for (int nb = 0; nb < MAXNB; ++nb) acc[nb] = mfma(a1, b1[nb], acc[nb]);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (it < 8) STAMP(8 + 7 * it);
   }
-  STAMP(60);
-  STAMPV(62, (unsigned long long)it);
 
   // ---- cross-wave reduction through LDS, then slab[ky][co][ci][t]
   float* slab = a.slab + (size_t)ky * a.Cout * a.Cin * TAPS;
@@ -1226,7 +1197,6 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_k(WgradArgs a) {
     int c = tid / TPC;
     if ((tid % TPC) == 0 && cout0 + c < a.Cout) a.dbias[(size_t)ky * a.Cout + cout0 + c] = (float)db;
   }
-  STAMP(61);
 }
 
 // out[i] (+)= sum_k slab[k][i]: 32 outputs x 8 k-slices per workgroup, fp64 accumulation (the slabs are partial sums of
