@@ -589,8 +589,9 @@ def compact_line(line):
             "achieved": r["achieved"], "peak": r["peak"], "unit": r["unit"], "frac": r["frac"],
             "achieved_what": "FLOP-weighted over every launch of one U-Net on this family, isolated launches, HIP events (this run)",
             "in_step_frac": r.get("in_step_frac"), "in_step_tflops": ins.get("tflops"), "in_step_family_ms_per_step": ins.get("family_ms_per_step"),
-            "in_step_source": (dom.get("profile") and "committed %s (back-to-back kernels), not this run" % dom["profile"]),
-            "family_percent_of_step_kernel_time": dom.get("percent"),
+            "in_step_source": (dom.get("profile") and ("committed %s (back-to-back kernels), not this run" % dom["profile"] if dom.get("same_library")
+                                                       else "withheld: %s was measured on another library than the one loaded" % dom["profile"])),
+            "family_percent_of_step_kernel_time": dom.get("percent") if dom.get("same_library") else None,
             "step_frac": r.get("step_frac"), "best_layers_frac": r.get("best_layers_frac"),
             "traffic": tr.get("hbm_bytes"), "traffic_read": tr.get("hbm_read_bytes"), "traffic_write": tr.get("hbm_write_bytes"),
             "traffic_algorithmic": (r.get("traffic_algorithmic") or {}).get("hbm_bytes"),
