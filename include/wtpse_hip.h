@@ -75,11 +75,12 @@ int wtpse_x3_xcd(int on);
  *       in fp32), THREE products a0 b1 + a1 b0 + a0 b0 on v_mfma_f32_*_f16, fp32 accumulation — half the MFMAs of x3 at the same
  *       measured accuracy (tests/test_conv_x3_gpu.py: against fp64 beside x3 and the fp32-input MFMA).  fp16 has 5 exponent bits, so
  *       every operand tensor is multiplied by a power of two as it is loaded (exact) and the result scaled back: weights per layer
- *       (from the layer's largest magnitude, found by wtpse_pack_conv_weights_x3), forward activations by 2^4 (full precision for
- *       2^-7 <= |x| < 2^12, absolute error 2^-29 below, saturation — not overflow — above), gradients by the power of two that brings
+ *       (from the layer's largest magnitude, found by wtpse_pack_conv_weights_x3), forward activations by 2^2 (full precision for
+ *       2^-5 <= |x| < 2^14, absolute error 2^-27 below; beyond 2^14 the fp16 term overflows and the outputs it feeds are NaN — loud, as
+ *       for any divergence; NaN / inf operands propagate as in fp32), gradients by the power of two that brings
  *       `in_amax` — the tensor's amax table (wtpse_amax below), left by the tensor's producer
  *       (wtpse_bn_bwd_apply_coef, wtpse_upsample2x_bwd[_bn], ...) or by wtpse_amax — into [2^14, 2^15).  in_amax = NULL: the tensor is
- *       treated like a forward activation (fixed 2^4: right for O(1) data, NOT for real gradients);
+ *       treated like a forward activation (fixed 2^2: right for O(1) data, NOT for real gradients);
  *   1 = the `bf16` mode of BASELINE.json configs[1]: operands rounded to ONE bf16 term, one product — outside the 1e-4 parity bar by
  *       construction (tests/test_bf16_mode_gpu.py states its tolerance).
  * The weight gradients of the 16-pixel-wide maps (wtpse_conv_wgrad_x3) stay on x3.  Packed weights are in the format of the setting
@@ -104,7 +105,7 @@ int wtpse_conv_fwd_x3(const float* in0, int C0, const float* in1, int C1, const 
  * (forward or data-gradient direction) from wtpse_pack_conv16_x3, 12808 unsigned shorts per direction (a 16-byte header with the
  * x2h weight scale, the x3 fragments, the x2h fragments), 16-byte aligned.  Arithmetic: wtpse_x3_terms() — x2h when it is 2, except
  * that a GRADIENT input (in_is_grad != 0) without its amax table (in_amax == NULL) runs in x3 (no scale is known for it and a pass
- * to find one costs more than this HBM-bound kernel would gain); in_is_grad == 0: a forward activation, scaled by 2^4.
+ * to find one costs more than this HBM-bound kernel would gain); in_is_grad == 0: a forward activation, scaled by 2^2.
  * Options as wtpse_conv_fwd (bias, prologue, relu_out, stats [wtpse_conv_stats_blocks][Cout][2], mask_ref) plus gram_partial
  * (as wtpse_conv_fwd_gram; Cout == 16, relu_out == 0) and — with bn_mean — the BatchNorm-backward epilogue of wtpse_dgrad_bnb
  * over all output channels (mask_ref = that layer's raw conv output, stats = its partials). */
@@ -183,7 +184,7 @@ int wtpse_conv_wgrad_x3(const float* dy, const float* x0, int C0, const float* x
  * side by side per 32-pixel step; no bias gradient, not the _bn form) —: wtpse_wgrad_r_supported().  With bias gradient
  * (dbias / dbias_slab NULL: skip).  slab: [nslab][Cout*Cin*9], dbias_slab: [nslab][Cout], nslab = wtpse_wgrad_r_slabs(...).
  * Arithmetic by wtpse_x3_terms(); with 2 (x2h) dY is scaled from dy_amax (NULL: like a forward activation — and the 16 x 16-channel
- * blocks, HBM-bound, then stay on x3), X by 2^4; the _bn form below stays on three bf16 terms.  With 1 (bf16 mode) only the blocks of
+ * blocks, HBM-bound, then stay on x3), X by 2^2; the _bn form below stays on three bf16 terms.  With 1 (bf16 mode) only the blocks of
  * 32 channels on at least one side run with one term: the 16 x 16 blocks (which alone carry a bias gradient), the _bn form and
  * wtpse_conv_wgrad_x3 keep three — the mode is a mix of arithmetics by design (the 16-channel layers are not MFMA-bound). */
 int wtpse_wgrad_r_supported(int Cin, int Cout, int ksize, int C0, int W);

@@ -601,3 +601,81 @@ def test_x3_half_tiling_equals_32_channel_blocks(case):
     new = run()
     assert any(a_.shape != b_.shape for a_, b_ in zip(new, old)), "the statistics partials must come in more rows"
     _assert_same_outputs(new, old)
+
+
+# ---------------------------------------------------------------- x2h: the range side of the two-fp16-term arithmetic
+def _x2h_only():
+    o = ops()
+    if o.x3_terms() != 2:
+        pytest.skip("x2h is not the active arithmetic (WTPSE_X3_TERMS)")
+    return o
+
+
+@pytest.mark.parametrize("wscale,gscale", [(0.2, 1.0), (3e-6, 1.0), (4e3, 1.0), (0.2, 1e-8), (0.2, 3e5), (1e-4, 1e-7)])
+def test_x2h_scales_follow_the_data(wscale, gscale):
+    """fp16 has five exponent bits; x2h keeps fp32 accuracy over fp32's range by scaling every operand tensor with a power of two:
+    the weights from the layer's largest magnitude (pack kernel), a GRADIENT operand from its amax table.  Data gradients and weight
+    gradients with weights from 3e-6 to 4e3 and gradients from 1e-8 (a mean loss over millions of pixels) to 3e5, against fp64: the
+    relative L2 error must stay at the level of the O(1) case (<= 4e-7), whatever the magnitudes."""
+    o = _x2h_only()
+    B, Ci, Co, H, W = 4, 64, 64, 32, 32
+    w = rnd(Co, Ci, 3, 3, seed=71, scale=wscale)
+    dy = rnd(B, Co, H, W, seed=72) * gscale
+    x = rnd(B, Ci, H, W, seed=73)
+    packed, _, xd = pack_x3(w)
+    dyd = dy.to(DEV)
+    am = o.amax_of(dyd)
+    d, _, _ = o.conv_fwd_x3(dyd, None, packed.data_ptr() + 2 * xd, None, Ci, 3, in_amax=am)
+    ref = F.conv_transpose2d(dy.double(), w.double(), padding=1)
+    e = float((d.cpu().double() - ref).norm() / ref.norm())
+    assert e <= 4e-7, ("dgrad", wscale, gscale, e)
+    dw = torch.empty(Co, Ci, 3, 3, device=DEV)
+    o.conv_wgrad_r(dyd, x.to(DEV), None, dw, dy_amax=am)
+    refw = torch.nn.grad.conv2d_weight(x.double(), (Co, Ci, 3, 3), dy.double(), padding=1)
+    ew = float((dw.cpu().double() - refw).norm() / refw.norm())
+    assert ew <= 4e-7, ("wgrad", wscale, gscale, ew)
+    # the table is what the tensor's largest magnitude is: float bits, the maximum over the 64 shards
+    got = float(am.view(torch.float32).max())
+    assert got == float(dy.abs().max()), (got, float(dy.abs().max()))
+
+
+def test_x2h_out_of_range_activation_is_loud():
+    """A forward activation is scaled by a fixed 2^2 (full precision for 2^-5 <= |x| < 2^14).  A value beyond 65504 / 4 overflows its fp16
+    term: the outputs it feeds are NON-FINITE — loud, the caller's NaN check fires — never a wrong finite number; every output that does
+    not see the outlier is as accurate as without it.  Values far below 2^-5 lose relative, not absolute, precision (absolute error
+    <= 2^-27 per element and unit weight)."""
+    o = _x2h_only()
+    B, Ci, Co, H, W = 2, 32, 32, 16, 32
+    w = rnd(Co, Ci, 3, 3, seed=81, scale=0.2)
+    x = rnd(B, Ci, H, W, seed=82)
+    x[0, 3, 8, 16] = 1e7                      # one outlier far beyond the format's range
+    packed, xf, _ = pack_x3(w)
+    y, _, _ = o.conv_fwd_x3(x.to(DEV), None, packed.data_ptr() + 2 * xf, None, Co, 3)
+    y = y.cpu()
+    ref = F.conv2d(x.double(), w.double(), padding=1)
+    clean = torch.ones_like(ref, dtype=torch.bool)
+    clean[0, :, 7:10, 15:18] = False          # the 3x3 footprint of the outlier
+    assert bool(torch.isfinite(y[clean]).all()) and not bool(torch.isfinite(y[~clean]).any())
+    e = float((y.double() - ref)[clean].norm() / ref[clean].norm())
+    assert e <= 4e-7, e
+    # tiny activations: absolute error bounded by 2^-27 x sum |w| per output
+    xt = rnd(B, Ci, H, W, seed=83) * 1e-5
+    yt, _, _ = o.conv_fwd_x3(xt.to(DEV), None, packed.data_ptr() + 2 * xf, None, Co, 3)
+    reft = F.conv2d(xt.double(), w.double(), padding=1)
+    bound = 2.0 ** -27 * float(w.abs().sum((1, 2, 3)).max())
+    assert float((yt.cpu().double() - reft).abs().max()) <= bound, (float((yt.cpu().double() - reft).abs().max()), bound)
+
+
+def test_x2h_zero_and_nonfinite_gradients():
+    """amax = 0 (an all-zero gradient) and a non-finite amax fall back to scale 1: zeros stay zeros, a NaN propagates as it would in fp32."""
+    o = _x2h_only()
+    B, Ci, Co, H, W = 2, 32, 32, 16, 32
+    w = rnd(Co, Ci, 3, 3, seed=91, scale=0.2)
+    packed, _, xd = pack_x3(w)
+    z = torch.zeros(B, Co, H, W, device=DEV)
+    d, _, _ = o.conv_fwd_x3(z, None, packed.data_ptr() + 2 * xd, None, Ci, 3, in_amax=o.amax_of(z))
+    assert float(d.abs().max()) == 0.0
+    n = rnd(B, Co, H, W, seed=92).to(DEV)
+    n[1, 2, 3, 4] = float("nan")
+    d, _, _ = o.conv_fwd_x3(n, None, packed.data_ptr() + 2 * xd, None, Ci, 3, in_amax=o.amax_of(n))
+    assert bool(torch.isnan(d[1, :, 2:5, 3:6]).all()) and bool(torch.isfinite(d[0]).all())

@@ -84,8 +84,7 @@ __device__ __forceinline__ f32x4 wt_mfma16x32(u32x4 a, u32x4 b, f32x4 c) {
 // ---- "x2h" helpers (two fp16 terms per fp32 operand, three products: conv_x3_kernels.h has the full description) shared by the
 // convolutions and the register-resident weight gradient
 constexpr int X3_WHDR = 8;                 // unsigned shorts of header in front of a packed block: float {1 / scale, scale}
-constexpr float X3_FWD_SCALE = 16.f;
-constexpr float X3_H_MAX = 65504.f;
+constexpr float X3_FWD_SCALE = 4.f;
 
 // The largest magnitude of a gradient tensor travels as an "amax table": AMAX_SHARDS unsigneds (float bits of non-negative values:
 // they order like their bit patterns), one per 64-byte line, zero before the tensor's producer runs.  Producers fold a wave's (or a
@@ -140,11 +139,11 @@ __device__ __forceinline__ unsigned pack_h_rne(float a, float b) {
   h16x2 v = {(_Float16)a, (_Float16)b};
   return __builtin_bit_cast(unsigned, v);
 }
-// (a, b) -> two dwords holding the fp16 pairs (h0(a), h0(b)), (h1(a), h1(b)); saturating: beyond +-65504 the leading term is clamped
-// (a wrong but finite value — the scales above keep every sane tensor far from it) instead of turning into inf - inf = NaN
+// (a, b) -> two dwords holding the fp16 pairs (h0(a), h0(b)), (h1(a), h1(b)).  No clamp: a value beyond +-65504 (after scaling) becomes
+// inf, its remainder -inf, and every product it feeds NaN — an out-of-range operand fails LOUDLY (the caller's NaN check fires, as it does
+// for any other divergence) instead of turning into a wrong finite number; a NaN operand stays NaN, as in fp32.  (A saturating form —
+// v_med3_f32 per element — swallowed NaNs: v_med3 returns the minimum when an input is NaN.)
 __device__ __forceinline__ void split2h_pair(float a, float b, unsigned& p0, unsigned& p1) {
-  a = __builtin_amdgcn_fmed3f(a, -X3_H_MAX, X3_H_MAX);
-  b = __builtin_amdgcn_fmed3f(b, -X3_H_MAX, X3_H_MAX);
   const h16x2 v = {(_Float16)a, (_Float16)b};
   p0 = __builtin_bit_cast(unsigned, v);
   p1 = pack_h_rne(a - (float)v[0], b - (float)v[1]);

@@ -98,8 +98,9 @@ __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
 // bits): h1 keeps its 11 bits only while |h0| >= 2^-3 and fp16 overflows at 65504.  So every operand tensor is multiplied by a power
 // of two on the way in (exact) and the accumulators by the inverse on the way out:
 //   * weights: per layer and direction, from the layer's largest magnitude (pack_weights_x3_k; header in front of the packed block);
-//   * forward activations (BatchNorm'd, pooled, upsampled tensors and the whitening features: O(1) by construction): X3_FWD_SCALE = 2^4
-//     — full precision for 2^-7 <= |x| < 2^12, absolute error 2^-29 below that, saturating (not overflowing) conversion above;
+//   * forward activations (BatchNorm'd, pooled, upsampled tensors and the whitening features: O(1) by construction): X3_FWD_SCALE = 2^2
+//     — full precision for 2^-5 <= |x| < 2^14, absolute error 2^-27 below that (relative to an O(1) tensor: below fp32's own 2^-24); a
+//     value beyond 2^14 overflows to inf and turns the outputs it feeds into NaN: loud, like any divergence (common.h: split2h_pair);
 //   * gradients (no scale known a priori): from the tensor's largest magnitude, left by its producer in ConvX3Args::in_amax.
 template <int TERMS>
 __device__ __forceinline__ float x3_in_scale(const ConvX3Args& a) {
