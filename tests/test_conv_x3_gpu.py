@@ -667,7 +667,8 @@ def test_x2h_out_of_range_activation_is_loud():
 
 
 def test_x2h_zero_and_nonfinite_gradients():
-    """amax = 0 (an all-zero gradient) and a non-finite amax fall back to scale 1: zeros stay zeros, a NaN propagates as it would in fp32."""
+    """amax = 0 (an all-zero gradient) and a non-finite amax fall back to scale 1: zeros stay zeros, a NaN stays non-finite in every output
+    it feeds (and only there), as it would in fp32."""
     o = _x2h_only()
     B, Ci, Co, H, W = 2, 32, 32, 16, 32
     w = rnd(Co, Ci, 3, 3, seed=91, scale=0.2)
@@ -678,4 +679,5 @@ def test_x2h_zero_and_nonfinite_gradients():
     n = rnd(B, Co, H, W, seed=92).to(DEV)
     n[1, 2, 3, 4] = float("nan")
     d, _, _ = o.conv_fwd_x3(n, None, packed.data_ptr() + 2 * xd, None, Ci, 3, in_amax=o.amax_of(n))
-    assert bool(torch.isnan(d[1, :, 2:5, 3:6]).all()) and bool(torch.isfinite(d[0]).all())
+    # (non-finite, not necessarily NaN: the fp16 matrix instruction returns -inf for some NaN operands — loud either way)
+    assert not bool(torch.isfinite(d[1, :, 2:5, 3:6]).any()) and bool(torch.isfinite(d[0]).all())
