@@ -593,6 +593,8 @@ def compact_line(line):
                                                        else "withheld: %s was measured on another library than the one loaded" % dom["profile"])),
             "family_percent_of_step_kernel_time": dom.get("percent") if dom.get("same_library") else None,
             "step_frac": r.get("step_frac"), "best_layers_frac": r.get("best_layers_frac"),
+            # continuity with rounds 2-4, whose bound was the x3 scheme's 419.5 TFLOP/s (6 products per multiply): the same TFLOP/s against it
+            "frac_of_round4_x3_bound_419_5": r["achieved"] / (16.0 * 157.3 / 6.0),
             "traffic": tr.get("hbm_bytes"), "traffic_read": tr.get("hbm_read_bytes"), "traffic_write": tr.get("hbm_write_bytes"),
             "traffic_algorithmic": (r.get("traffic_algorithmic") or {}).get("hbm_bytes"),
             "traffic_source": "committed profiles/pmc_traffic.json (rocprofv3 --pmc, separate passes, copy-kernel calibrated), same library" if tr else r.get("traffic_source"),
@@ -709,7 +711,10 @@ def main():
                  "(use e.g. --batch 30 or 33)" % args.batch)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.launch is None:
-        args.launch = "plan" if world == 1 else "eager"
+        # N > 1: eager launches with the gradient exchange overlapped with the backward — at 32 images per GPU the step is GPU-bound
+        # (host 22 ms vs GPU 42 ms); a small per-GPU batch is host-bound when launched eagerly and takes the five-stretch launch
+        # plan instead (collectives between the stretches: tests/dp_worker.py, plan_equals_eager)
+        args.launch = "plan" if (world == 1 or args.batch < 16) else "eager"
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
