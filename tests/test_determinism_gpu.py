@@ -130,6 +130,47 @@ def test_eager_work_between_plan_replays():
         assert torch.equal(x, y)
 
 
+@pytest.mark.gpu
+def test_plan_refuses_to_replay_under_other_switches():
+    """the tiling of the x3 launches — hence the size of their statistics / tail buffers — and the format of the
+    packed weights depend on run-time switches (wtpse_x3r_enable, wtpse_x3_terms); a recorded plan replays the entry points, which
+    re-read them.  A plan therefore remembers wtpse_tuning_state() and wtpse_plan_replay refuses (status -2, nothing launched) when it
+    differs; with the switches back, the same plan replays again and the step continues where the eager sequence would be."""
+    import bench
+    from wtpse_hip import ops
+    from wtpse_hip.lib import WtpseError
+    from wtpse_hip.step import TrainStep
+    from wtpse_hip.synth import make_batch, default_hparams
+    dev = torch.device("cuda:0")
+    hp = default_hparams(True)
+    B = 6
+    torch.manual_seed(0)
+    nets = bench.build_nets(hp, B // 3, dev)
+    ts = TrainStep(*nets, hp, dp=None, graph="plan")
+    image, od, oc = make_batch(B, 64, 64, dev, seed=30)
+    ts.step(image, od, oc)
+    torch.cuda.synchronize()
+    before = [n.flat_params().clone() for n in nets]
+    L = ops.lib()
+    state = L.query("wtpse_tuning_state")
+    for name, other in (("wtpse_x3r_enable", 0), ("wtpse_x3_terms", 3 if ops.x3_terms() != 3 else 2)):
+        was = L.query(name, other)
+        try:
+            assert L.query("wtpse_tuning_state") != state
+            with pytest.raises(WtpseError, match="refused"):
+                ts.step(image, od, oc)
+        finally:
+            L.query(name, was)
+        torch.cuda.synchronize()
+        assert L.query("wtpse_tuning_state") == state
+        for x, y in zip(before, (n.flat_params() for n in nets)):
+            assert torch.equal(x, y), "a refused replay must not have launched anything"
+    res = ts.step(image, od, oc)                 # the same plan, switches restored
+    torch.cuda.synchronize()
+    assert all(float(v) == float(v) for v in res.values())
+    assert any(not torch.equal(x, n.flat_params()) for x, n in zip(before, nets))
+
+
 def _pack_x16(o, w):
     """OIHW 16x16x3x3 -> (buffer, forward offset, data-gradient offset) through wtpse_pack_conv16_x3 (csrc/conv.hip MODE 3)."""
     from test_kernels_gpu import DEV
