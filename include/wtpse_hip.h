@@ -53,9 +53,9 @@ int wtpse_conv_fwd_gram(const float* in0, int C0, const float* wpacked, const fl
  * the launch uses 64-channel row blocks: Cout % 64 == 0 and at least 512 of them) — the per-channel prologue coefficients are
  * staged in LDS; anything else fails with WTPSE_ERR_ARG.  `wpacked`: the weights pre-split by
  * wtpse_pack_conv_weights_x3 — desc as for wtpse_pack_conv_weights with offsets {xf_off, xd_off} in unsigned shorts; per
- * conv and direction 8 + ceil16(K) * ceil32(rows) * taps * 3 unsigned shorts (forward: rows = Cout, K = Cin; data gradient:
- * rows = Cin, K = Cout): a 16-byte header (float {1 / scale, scale}: the layer's power-of-two weight scale, 1 unless
- * wtpse_x3_terms() == 2), then [K chunk 16][row block 32][tap][term slot 3][k half 2][row 32][8 k]. */
+ * conv and direction 32 + ceil16(K) * ceil32(rows) * taps * 3 unsigned shorts (forward: rows = Cout, K = Cin; data gradient:
+ * rows = Cin, K = Cout): a 64-byte header (float {1 / scale, scale, 0, 0, 12 words of the packer's scratch}: the layer's
+ * power-of-two weight scale, 1 unless wtpse_x3_terms() == 2), then [K chunk 16][row block 32][tap][term slot 3][k half 2][row 32][8 k]. */
 int wtpse_conv_x3_stats_blocks(int B, int H, int W, int Cout, int ksize);   /* rows of `stats` for wtpse_conv_fwd_x3 (the tiling depends on the kernel size) */
 /* Which 3x3 launches of the x3 entry points run conv_x3r_k (weights fed from registers, input tile double-buffered in LDS) instead
  * of conv_x3_k (weights staged through LDS): on = 1 (default) the launches with 64-channel output blocks, 2 all of them, 0 none;

@@ -87,33 +87,43 @@ __global__ __launch_bounds__(256) void affine_act_k(const float* __restrict__ y,
 }
 
 // partial[(split*C + c)*2 + {0,1}] = sum over this split's elements of (dzh, dzh*xhat); grid = (C, nsplit).
-// A split owns whole images (b = split, split + nsplit, ...): no per-element division, float4 streams.
+// A split owns whole (image, segment) units — an image's channel plane in `segs` equal pieces (u = split, split + nsplit, ...): no
+// per-element division, float4 streams, two of them in flight per lane.  (Whole images only: 16 channels x 32 images gave 512
+// workgroups, two per CU, and 0.41 of the copy rate.)
 template <bool VEC>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_k(const float* __restrict__ dz, const float* __restrict__ y,
                                                        const float* __restrict__ ss, int relu,
                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                       int B, int C, int HW, float* __restrict__ partial) {
+                                                       int B, int C, int HW, int segs, float* __restrict__ partial) {
   __shared__ float sh[2][4];
   const int c = blockIdx.x, split = blockIdx.y, nsplit = gridDim.y;
   const float sc = ss[2 * c], sf = ss[2 * c + 1], mu = mean[c], is = invstd[c];
+  const int SL = HW / segs;                        // elements of a segment (segs > 1: a multiple of 2048)
   float s1 = 0.f, s2 = 0.f;
-  for (int b = split; b < B; b += nsplit) {
-    const size_t base = ((size_t)b * C + c) * HW;
+  auto fold4 = [&](float4 yv, float4 g) __attribute__((always_inline)) {
+    if (relu) {
+      if (!(fmaf(yv.x, sc, sf) > 0.f)) g.x = 0.f;
+      if (!(fmaf(yv.y, sc, sf) > 0.f)) g.y = 0.f;
+      if (!(fmaf(yv.z, sc, sf) > 0.f)) g.z = 0.f;
+      if (!(fmaf(yv.w, sc, sf) > 0.f)) g.w = 0.f;
+    }
+    s1 += (g.x + g.y) + (g.z + g.w);
+    s2 += (g.x * (yv.x - mu) + g.y * (yv.y - mu)) + (g.z * (yv.z - mu) + g.w * (yv.w - mu));
+  };
+  for (int u = split; u < B * segs; u += nsplit) {
+    const int b = u / segs, sg = u - b * segs;
+    const size_t base = ((size_t)b * C + c) * HW + (size_t)sg * SL;
     if (VEC) {
-      for (int p = threadIdx.x * 4; p < HW; p += 1024) {
-        float4 yv = *reinterpret_cast<const float4*>(y + base + p);
-        float4 g = *reinterpret_cast<const float4*>(dz + base + p);
-        if (relu) {
-          if (!(fmaf(yv.x, sc, sf) > 0.f)) g.x = 0.f;
-          if (!(fmaf(yv.y, sc, sf) > 0.f)) g.y = 0.f;
-          if (!(fmaf(yv.z, sc, sf) > 0.f)) g.z = 0.f;
-          if (!(fmaf(yv.w, sc, sf) > 0.f)) g.w = 0.f;
-        }
-        s1 += (g.x + g.y) + (g.z + g.w);
-        s2 += (g.x * (yv.x - mu) + g.y * (yv.y - mu)) + (g.z * (yv.z - mu) + g.w * (yv.w - mu));
+      int p = threadIdx.x * 4;
+      for (; p + 1024 < SL; p += 2048) {
+        const float4 y0 = *reinterpret_cast<const float4*>(y + base + p), y1 = *reinterpret_cast<const float4*>(y + base + p + 1024);
+        const float4 g0 = *reinterpret_cast<const float4*>(dz + base + p), g1 = *reinterpret_cast<const float4*>(dz + base + p + 1024);
+        fold4(y0, g0);
+        fold4(y1, g1);
       }
+      if (p < SL) fold4(*reinterpret_cast<const float4*>(y + base + p), *reinterpret_cast<const float4*>(dz + base + p));
     } else {
-      for (int p = threadIdx.x; p < HW; p += 256) {
+      for (int p = threadIdx.x; p < SL; p += 256) {
         float yv = y[base + p], g = dz[base + p];
         if (relu && !(fmaf(yv, sc, sf) > 0.f)) g = 0.f;
         s1 += g;
@@ -347,9 +357,17 @@ extern "C" int wtpse_affine_act(const float* y, const float* scale_shift, int re
   return wtpse_status();
 }
 
+// segments per image plane: doubled while the launch stays within ~2048 workgroups and a segment stays a multiple of 2048 elements
+static int bn_bwd_segs(int B, int C, int HW) {
+  int segs = 1;
+  const int cap = 2048 / (C > 0 ? C : 1);
+  while (B * segs * 2 <= cap && HW % (segs * 2 * 2048) == 0 && HW / (segs * 2) >= 8192) segs *= 2;
+  return segs;
+}
 extern "C" int wtpse_bn_bwd_nsplit(int B, int C, int HW) {
-  int ns = 2048 / (C > 0 ? C : 1);   // ~2048 workgroups; a split owns whole images
-  if (ns > B) ns = B;
+  int ns = 2048 / (C > 0 ? C : 1);   // ~2048 workgroups; a split owns whole (image, segment) units
+  const int units = B * bn_bwd_segs(B, C, HW);
+  if (ns > units) ns = units;
   if (ns < 1) ns = 1;
   return ns;
 }
@@ -370,10 +388,10 @@ extern "C" int wtpse_bn_bwd(const float* dz, const float* y, const float* scale_
   const int ns = wtpse_bn_bwd_nsplit(B, C, HW);
   if (vec_ok(HW, dz, y, nullptr))
     hipLaunchKernelGGL(bn_bwd_reduce_k<true>, dim3(C, ns), dim3(256), 0, st, dz, y, scale_shift, relu, save_mean,
-                       save_invstd, B, C, HW, partial);
+                       save_invstd, B, C, HW, bn_bwd_segs(B, C, HW), partial);
   else
     hipLaunchKernelGGL(bn_bwd_reduce_k<false>, dim3(C, ns), dim3(256), 0, st, dz, y, scale_shift, relu, save_mean,
-                       save_invstd, B, C, HW, partial);
+                       save_invstd, B, C, HW, bn_bwd_segs(B, C, HW), partial);
   hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(C), dim3(256), 0, st, partial, ns, C, (double)B * HW, gamma, save_mean,
                      save_invstd, dgamma, dbeta, accumulate, coef, (const float*)nullptr, (float*)nullptr, 0);
   launch_apply(dz, y, scale_shift, relu, coef, dy, B, C, HW, amax, st);
@@ -391,10 +409,10 @@ extern "C" int wtpse_bn_bwd_reduce(const float* dz, const float* y, const float*
   const int ns = wtpse_bn_bwd_nsplit(B, C, HW);
   if (vec_ok(HW, dz, y, nullptr))
     hipLaunchKernelGGL(bn_bwd_reduce_k<true>, dim3(C, ns), dim3(256), 0, st, dz, y, scale_shift, relu, save_mean,
-                       save_invstd, B, C, HW, partial);
+                       save_invstd, B, C, HW, bn_bwd_segs(B, C, HW), partial);
   else
     hipLaunchKernelGGL(bn_bwd_reduce_k<false>, dim3(C, ns), dim3(256), 0, st, dz, y, scale_shift, relu, save_mean,
-                       save_invstd, B, C, HW, partial);
+                       save_invstd, B, C, HW, bn_bwd_segs(B, C, HW), partial);
   hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(C), dim3(256), 0, st, partial, ns, C, 1.0, (const float*)nullptr, save_mean,
                      save_invstd, (float*)nullptr, (float*)nullptr, 0, (float*)nullptr, (const float*)nullptr, sums_local, 0);
   return wtpse_status();

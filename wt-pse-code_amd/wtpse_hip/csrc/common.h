@@ -83,7 +83,8 @@ __device__ __forceinline__ f32x4 wt_mfma16x32(u32x4 a, u32x4 b, f32x4 c) {
 
 // ---- "x2h" helpers (two fp16 terms per fp32 operand, three products: conv_x3_kernels.h has the full description) shared by the
 // convolutions and the register-resident weight gradient
-constexpr int X3_WHDR = 8;                 // unsigned shorts of header in front of a packed block: float {1 / scale, scale}
+constexpr int X3_WHDR = 32;                // unsigned shorts of header in front of a packed block: float {1 / scale, scale, 0, 0, 12 slice maxima of |w|}
+constexpr int X3_WSLICES = 12;
 constexpr float X3_FWD_SCALE = 4.f;
 
 // The largest magnitude of a gradient tensor travels as an "amax table": AMAX_SHARDS unsigneds (float bits of non-negative values:

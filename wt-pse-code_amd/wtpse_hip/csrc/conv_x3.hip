@@ -10,32 +10,27 @@ int x3_dispatch_t3(const ConvX3Args& a, const X3Launch& L, hipStream_t st);
 // Weight packing for the x3 path: OIHW fp32 -> bf16 triples (or fp16 pairs) in the kernel's LDS image order.
 //   forward : rows = Cout, k = Cin, tap t          element = w[co][ci][t]
 //   dgrad   : rows = Cin,  k = Cout, tap T-1-t     element = w[co][ci][T-1-t]   (the data gradient is the forward kernel on dY)
-// layout: X3_WHDR shorts of header (float {1 / scale, scale}), then [k chunk of 16][row block of 32][tap][term slot 3][k half 2][row 32][8 k]
+// layout: X3_WHDR shorts of header (float {1 / scale, scale, 0, 0, X3_WSLICES partial maxima of |w|}), then [k chunk of 16][row block of 32][tap][term slot 3][k half 2][row 32][8 k]
 // (unsigned short); zero padded.  terms 3 / 1: bf16 terms x0, x1, x2, scale 1.  terms 2: fp16 terms h0, h1 of scale * w (third slot
 // zero), scale = the power of two that brings the layer's largest |w| into [2^14, 2^15) (pack_scale_x3_k, launched in front).
 // desc: n_desc x 8 ints {w_off, Cout, Cin, taps, xf_off, xd_off(-1: none), 0, 0}; x*_off in unsigned shorts.
+// X3_WSLICES workgroups per layer, each the largest |w| of its slice -> header floats [4 .. 4 + X3_WSLICES) of the layer's first
+// direction; pack_weights_x3_k folds them (one workgroup per layer took as long as the largest layer: 105 us for 590 k weights).
 __global__ __launch_bounds__(1024) void pack_scale_x3_k(const float* __restrict__ params, const int* __restrict__ desc,
                                                         unsigned short* __restrict__ packed, int terms) {
-  const int* d = desc + blockIdx.x * 8;
+  const int* d = desc + blockIdx.y * 8;
   const int n = d[1] * d[2] * d[3];
   const float* w = params + d[0];
   float m = 0.f;
   if (terms == 2)
-    for (int e = threadIdx.x; e < n; e += 1024) m = fmaxf(m, fabsf(w[e]));
+    for (int e = blockIdx.x * 1024 + threadIdx.x; e < n; e += X3_WSLICES * 1024) m = fmaxf(m, fabsf(w[e]));
   __shared__ float red[16];
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
   __syncthreads();
   if (threadIdx.x == 0) {
     for (int i = 1; i < 16; ++i) m = fmaxf(m, red[i]);
-    const float sc = terms == 2 ? x3_scale_from_amax(__builtin_bit_cast(unsigned, m)) : 1.f;
-    for (int dir = 0; dir < 2; ++dir)
-      if (d[4 + dir] >= 0) {
-        float* hdr = reinterpret_cast<float*>(packed + d[4 + dir]);
-        hdr[0] = 1.f / sc;
-        hdr[1] = sc;
-        hdr[2] = hdr[3] = 0.f;
-      }
+    reinterpret_cast<float*>(packed + (d[4] >= 0 ? d[4] : d[5]))[4 + blockIdx.x] = m;
   }
 }
 
@@ -47,7 +42,20 @@ __global__ __launch_bounds__(256) void pack_weights_x3_k(const float* __restrict
   for (int dir = 0; dir < 2; ++dir) {
     const int base = d[4 + dir];
     if (base < 0) continue;
-    const float sc = reinterpret_cast<const float*>(packed + base)[1];
+    float sc = 1.f;
+    if (terms == 2) {
+      const float* part = reinterpret_cast<const float*>(packed + (d[4] >= 0 ? d[4] : d[5])) + 4;
+      float m = 0.f;
+#pragma unroll
+      for (int i = 0; i < X3_WSLICES; ++i) m = fmaxf(m, part[i]);
+      sc = x3_scale_from_amax(__builtin_bit_cast(unsigned, m));
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      float* hdr = reinterpret_cast<float*>(packed + base);
+      hdr[0] = 1.f / sc;
+      hdr[1] = sc;
+      hdr[2] = hdr[3] = 0.f;
+    }
     const int R = dir == 0 ? Co : Ci, K = dir == 0 ? Ci : Co;
     const int RP = (R + 31) & ~31, KP = (K + 15) & ~15;
     const int n = KP * RP * T;                     // (row, k, tap) triples
@@ -89,7 +97,7 @@ extern "C" int wtpse_x3_terms(int terms) {
 
 extern "C" int wtpse_pack_conv_weights_x3(const float* params, const int* desc, int n_desc, unsigned short* packed, void* stream) {
   WTPSE_REQUIRE(params && desc && packed && n_desc > 0);
-  hipLaunchKernelGGL(pack_scale_x3_k, dim3(n_desc), dim3(1024), 0, (hipStream_t)stream, params, desc, packed, g_x3_terms);
+  hipLaunchKernelGGL(pack_scale_x3_k, dim3(X3_WSLICES, n_desc), dim3(1024), 0, (hipStream_t)stream, params, desc, packed, g_x3_terms);
   hipLaunchKernelGGL(pack_weights_x3_k, dim3(48, n_desc), dim3(256), 0, (hipStream_t)stream, params, desc, packed, g_x3_terms);
   return wtpse_status();
 }

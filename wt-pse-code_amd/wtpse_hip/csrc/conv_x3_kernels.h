@@ -489,7 +489,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_k(ConvX3Args a) {
   // the wave issued no MFMA: 9 % of the forward kernel with a prologue, 6 % without).  Branch-free: the coefficients come from
   // LDS ((1, 0) without a prologue), the ReLU is a select on a uniform flag.
   u32x4v tq[NIT][TERMS];
-  const bool any_pro = TERMS == 2 || a.pro0 != nullptr || a.pro1 != nullptr || a.pro_relu != 0;     // TERMS 2: the scale rides in the coefficients
+  const bool any_pro = a.pro0 != nullptr || a.pro1 != nullptr || a.pro_relu != 0;     // (TERMS 2 without a prologue: the scale alone, below)
   auto convert_pair = [&](int c0, int i, int j, bool pro) __attribute__((always_inline)) {
     float v0 = xv[i][2 * j], v1 = xv[i][2 * j + 1];
     if (pro) {        // `true` between the MFMA groups (no branch there), any_pro behind a barrier
@@ -502,6 +502,9 @@ __global__ __launch_bounds__(256, 2) void conv_x3_k(ConvX3Args a) {
       v1 = relu ? fmaxf(v1, 0.f) : v1;
       v0 = iin[i] ? v0 : 0.f;
       v1 = iin[i] ? v1 : 0.f;
+    } else if (TERMS == 2) {      // data gradients and block inputs: no prologue, out-of-range loads are zeros already
+      v0 *= sx;
+      v1 *= sx;
     }
     unsigned q[TERMS];
     x3_split_pair<TERMS>(v0, v1, q);
@@ -519,7 +522,9 @@ __global__ __launch_bounds__(256, 2) void conv_x3_k(ConvX3Args a) {
   };
   auto stash_x = [&](int c0) __attribute__((always_inline)) {
     // (compile-time indices: as two `#pragma unroll` loops the 3x3 MT 1 variant indexed xv / tq dynamically, through scratch)
-    x3_static_for<NIT * 4>([&](auto pc) __attribute__((always_inline)) { convert_pair(c0, decltype(pc)::value >> 2, decltype(pc)::value & 3, any_pro); });
+    // (one uniform branch around the whole conversion, not one per pair)
+    if (any_pro) x3_static_for<NIT * 4>([&](auto pc) __attribute__((always_inline)) { convert_pair(c0, decltype(pc)::value >> 2, decltype(pc)::value & 3, true); });
+    else x3_static_for<NIT * 4>([&](auto pc) __attribute__((always_inline)) { convert_pair(c0, decltype(pc)::value >> 2, decltype(pc)::value & 3, false); });
     store_x();
   };
   // one kernel row of weights: LDS slot s = ((tl * 2 TERMS + q) * CB + co), tl = tap within the row, q = term*2 + half (the packed
@@ -690,7 +695,8 @@ __global__ __launch_bounds__(256, 2) void conv_x3_k(ConvX3Args a) {
 //     at the full rate, MI355X_MICROARCH.md), so only two B fragment sets (current, next) are live.
 
 // TERMS: 3 = three bf16 terms per operand, six products (x3); 1 = one bf16 term, one product (bf16 mode); 2 = two fp16 terms, three products ("x2h": split2h_pair above).
-template <int WM, int MT, int NT, int TWL, int EPI, int TERMS = 3>
+// PLAIN: the launch has no prologue (data gradients, a block's first convolution): the conversion is scale + split only.
+template <int WM, int MT, int NT, int TWL, int EPI, int TERMS = 3, bool PLAIN = false>
 __global__ __launch_bounds__(256, 2) void conv_x3r_k(ConvX3Args a) {
   static_assert(TERMS >= 1 && TERMS <= 3, "three bf16 terms (x3), two fp16 terms (x2h) or one bf16 term (bf16 mode)");
   constexpr int KS = 3, TAPS = 9, PAD = 1;
@@ -805,15 +811,22 @@ __global__ __launch_bounds__(256, 2) void conv_x3r_k(ConvX3Args a) {
   u32x4v tq[TERMS];
   auto convert_pair = [&](int c0, int i, int j) __attribute__((always_inline)) {
     float v0 = xv[i][2 * j], v1 = xv[i][2 * j + 1];
-    const bool relu = (c0 < a.C0) ? (a.pro_relu & 1) : (a.pro_relu & 2);
-    const int cg = min(c0 + ihalf[i] * 8 + 2 * j, PRO_MAX - 2);
-    const float2 p0 = pro_s[cg], p1 = pro_s[cg + 1];
-    v0 = fmaf(v0, p0.x, p0.y);
-    v1 = fmaf(v1, p1.x, p1.y);
-    v0 = relu ? fmaxf(v0, 0.f) : v0;
-    v1 = relu ? fmaxf(v1, 0.f) : v1;
-    v0 = iin[i] ? v0 : 0.f;
-    v1 = iin[i] ? v1 : 0.f;
+    if constexpr (PLAIN) {        // out-of-range loads (padding, channels past the tensor) are zeros already
+      if constexpr (TERMS == 2) {
+        v0 *= sx;
+        v1 *= sx;
+      }
+    } else {
+      const bool relu = (c0 < a.C0) ? (a.pro_relu & 1) : (a.pro_relu & 2);
+      const int cg = min(c0 + ihalf[i] * 8 + 2 * j, PRO_MAX - 2);
+      const float2 p0 = pro_s[cg], p1 = pro_s[cg + 1];
+      v0 = fmaf(v0, p0.x, p0.y);
+      v1 = fmaf(v1, p1.x, p1.y);
+      v0 = relu ? fmaxf(v0, 0.f) : v0;
+      v1 = relu ? fmaxf(v1, 0.f) : v1;
+      v0 = iin[i] ? v0 : 0.f;
+      v1 = iin[i] ? v1 : 0.f;
+    }
     unsigned q[TERMS];
     x3_split_pair<TERMS>(v0, v1, q);
 #pragma unroll
@@ -937,20 +950,27 @@ static int launch_x3(const ConvX3Args& a, const X3Launch& L, hipStream_t st) {
   // gradients), 2 = everywhere (32-channel blocks run 8-20 % SLOWER on it: half the MFMAs per converted input element), 0 = nowhere
   if (KS == 3 && (L.x3r == 2 || (L.x3r == 1 && MT == 2))) {
     if constexpr (KS == 3) {
+      const bool plain = !a.pro0 && !a.pro1 && !a.pro_relu;
+#define X3R_GO(WM_, NT_, TWL_)                                                                                          \
+  do {                                                                                                                  \
+    if (plain) hipLaunchKernelGGL((conv_x3r_k<WM_, 1, NT_, TWL_, EPI, TERMS, true>), grid, dim3(256), 0, st, args);     \
+    else hipLaunchKernelGGL((conv_x3r_k<WM_, 1, NT_, TWL_, EPI, TERMS, false>), grid, dim3(256), 0, st, args);          \
+  } while (0)
       if (half) {
         if constexpr (MT == 2) {
-          if (narrow) hipLaunchKernelGGL((conv_x3r_k<2, 1, 2, 4, EPI, TERMS>), grid, dim3(256), 0, st, args);
-          else hipLaunchKernelGGL((conv_x3r_k<2, 1, 2, 5, EPI, TERMS>), grid, dim3(256), 0, st, args);
+          if (narrow) X3R_GO(2, 2, 4);
+          else X3R_GO(2, 2, 5);
         }
       } else if (small) {
-        if constexpr (MT == 1) hipLaunchKernelGGL((conv_x3r_k<1, 1, 1, 4, EPI, TERMS>), grid, dim3(256), 0, st, args);
+        if constexpr (MT == 1) X3R_GO(1, 1, 4);
       } else if (MT == 2) {
-        if (narrow) hipLaunchKernelGGL((conv_x3r_k<2, 1, 4, 4, EPI, TERMS>), grid, dim3(256), 0, st, args);
-        else hipLaunchKernelGGL((conv_x3r_k<2, 1, 4, 5, EPI, TERMS>), grid, dim3(256), 0, st, args);
+        if (narrow) X3R_GO(2, 4, 4);
+        else X3R_GO(2, 4, 5);
       } else {
-        if (narrow) hipLaunchKernelGGL((conv_x3r_k<1, 1, 2, 4, EPI, TERMS>), grid, dim3(256), 0, st, args);
-        else hipLaunchKernelGGL((conv_x3r_k<1, 1, 2, 5, EPI, TERMS>), grid, dim3(256), 0, st, args);
+        if (narrow) X3R_GO(1, 2, 4);
+        else X3R_GO(1, 2, 5);
       }
+#undef X3R_GO
     }
   } else if (small) {
     if constexpr (MT == 1) hipLaunchKernelGGL((conv_x3_k<KS, 1, 4, EPI, 1, TERMS>), grid, dim3(256), 0, st, args);

@@ -110,8 +110,8 @@ def conv16_x3(in0, wx16_ptr, bias, cout, pro0=None, pro_relu=0, relu_out=False, 
 
 
 def x3_packed_size(rows, k, taps):
-    """unsigned shorts of one direction of one conv in the x3 layout (include/wtpse_hip.h): 16 bytes of header + the term slots."""
-    return 8 + ((k + 15) & ~15) * ((rows + 31) & ~31) * taps * 3
+    """unsigned shorts of one direction of one conv in the x3 layout (include/wtpse_hip.h): 64 bytes of header + the term slots."""
+    return 32 + ((k + 15) & ~15) * ((rows + 31) & ~31) * taps * 3
 
 
 def x3_terms():
