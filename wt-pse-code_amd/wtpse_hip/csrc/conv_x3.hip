@@ -58,28 +58,38 @@ __global__ __launch_bounds__(256) void pack_weights_x3_k(const float* __restrict
     }
     const int R = dir == 0 ? Co : Ci, K = dir == 0 ? Ci : Co;
     const int RP = (R + 31) & ~31, KP = (K + 15) & ~15;
-    const int n = KP * RP * T;                     // (row, k, tap) triples
+    const int n = (KP / 8) * RP * T;               // 16-byte slots: (k half, row, tap) of every chunk and row block
     for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
-      // e enumerates [chunk][rb][tap][half][row32][k8]
-      const int k8 = e & 7, row32 = (e >> 3) & 31, hh = (e >> 8) & 1;
-      int q = e >> 9;
+      // e enumerates [chunk][rb][tap][half][row32]: one thread = the 8 k of one row — a 16-byte store per term slot (element-wise
+      // 2-byte stores: 57 us per network and step behind every Adam step)
+      const int row32 = e & 31, hh = (e >> 5) & 1;
+      int q = e >> 6;
       const int t = q % T; q /= T;
       const int rb = q % (RP / 32), chunk = q / (RP / 32);
-      const int row = rb * 32 + row32, k = chunk * 16 + hh * 8 + k8;
-      float v = 0.f;
-      if (row < R && k < K) v = dir == 0 ? w[(row * Ci + k) * T + t] : w[(k * Ci + row) * T + (T - 1 - t)];
-      unsigned q0, q1, q2;
-      if (terms == 2) {
-        split2h_pair(v * sc, 0.f, q0, q1);
-        q2 = 0u;
-      } else {
-        split3_pair(v, 0.f, q0, q1, q2);
+      const int row = rb * 32 + row32, k0 = chunk * 16 + hh * 8;
+      float v[8];
+#pragma unroll
+      for (int k8 = 0; k8 < 8; ++k8) {
+        const int k = k0 + k8;
+        v[k8] = (row < R && k < K) ? (dir == 0 ? w[(row * Ci + k) * T + t] : w[(k * Ci + row) * T + (T - 1 - t)]) : 0.f;
+      }
+      u32x4v o0, o1, o2;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        unsigned q0, q1, q2;
+        if (terms == 2) {
+          split2h_pair(v[2 * j] * sc, v[2 * j + 1] * sc, q0, q1);
+          q2 = 0u;
+        } else {
+          split3_pair(v[2 * j], v[2 * j + 1], q0, q1, q2);
+        }
+        o0[j] = q0; o1[j] = q1; o2[j] = q2;
       }
       const size_t slot = ((((size_t)chunk * (RP / 32) + rb) * T + t) * 6);
-      unsigned short* o = packed + base + X3_WHDR;
-      o[((slot + 0 * 2 + hh) * 32 + row32) * 8 + k8] = (unsigned short)(q0 & 0xFFFFu);
-      o[((slot + 1 * 2 + hh) * 32 + row32) * 8 + k8] = (unsigned short)(q1 & 0xFFFFu);
-      o[((slot + 2 * 2 + hh) * 32 + row32) * 8 + k8] = (unsigned short)(q2 & 0xFFFFu);
+      u32x4v* o = reinterpret_cast<u32x4v*>(packed + base + X3_WHDR);
+      o[(slot + 0 * 2 + hh) * 32 + row32] = o0;
+      o[(slot + 1 * 2 + hh) * 32 + row32] = o1;
+      o[(slot + 2 * 2 + hh) * 32 + row32] = o2;
     }
   }
 }
