@@ -54,8 +54,8 @@ def parse():
     ap.add_argument("--workload", choices=["full", "seg"], default="full",
                     help="full = configs[2] (seg + shape nets + WT loss); seg = configs[1] (seg-net only)")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
-                    help="f32 (default): fp32 results — the MFMA-bound layers in the x3 arithmetic (three bf16 terms per operand, six "
-                         "products); bf16: BASELINE.json configs[1]'s stated dtype — those layers with ONE bf16 term per operand and one "
+                    help="f32 (default): fp32 results — the MFMA-bound layers in the library's current fp32-accurate arithmetic (x2h: two fp16 "
+                         "terms per operand, three products; WTPSE_X3_TERMS=3: x3, three bf16 terms, six products); bf16: BASELINE.json configs[1]'s stated dtype — those layers with ONE bf16 term per operand and one "
                          "MFMA product, fp32 accumulation (wtpse_x3_terms(1)); outside the 1e-4 parity bar, reported as its own line only")
     ap.add_argument("--bn-sync", type=int, default=0, help="1: BatchNorm statistics over the global batch (parity mode)")
     ap.add_argument("--launch", choices=["eager", "plan", "graph"], default=None,
