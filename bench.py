@@ -4,6 +4,8 @@
     python bench.py --gpus 1 --steps 5 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...        (WORLD_SIZE unset: starts those N ranks itself as a child `torch.distributed.run`,
+                                         before this process touches a GPU, and relays rank 0's line)
 
 One "step" = one full iteration of the reference's hot loop (Trainer.py:766-914): calls A-D, four backward passes,
 four Adam steps over the four networks, on one synthetic batch resident in HBM.  Workload = BASELINE.json configs[2]
@@ -68,6 +70,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-full", action="store_true",
                     help="SURVEY.md 8d protocol in full: 3 warm-up + 10 timed iterations at B=6 and B=30 (minutes of CPU time)")
+    ap.add_argument("--cpu-threads", type=int, default=0,
+                    help="threads of the CPU baseline; 0 (default) = min(CPUs granted to this process, physical cores of the host) "
+                         "(SURVEY.md 8d: all physical cores); profiles/r06_cpu_baseline_full.json holds 16 threads beside all cores")
     ap.add_argument("--roi-presteps", type=int, default=70,
                     help="untimed set-up steps that train the optic-disc net so that its prediction (the ROI of calls C/D) is no "
                          "longer empty: a FIXED count (default 70: od_pred then covers ~21 %% of the pixels of the seed-1 batch; "
@@ -195,7 +200,12 @@ def unet_layer_rooflines(B, H, dev):
         a1 = (E.Act(x1, torch.rand(c1, 2, device=dev) + 0.5, True) if c1 else None)
         dy = torch.randn(B, co, Hc, Hc, device=dev)
         fl = 2.0 * cin * co * k * k * Hc * Hc * B
-        r = {"layer": "%s %d%s->%d k%d @%dx%d" % (name, c0, ("+%d" % c1) if c1 else "", co, k, Hc, Hc), "flop": fl,
+        # a conv layer's own roofline is min(MFMA peak, HBM bandwidth x its ideal intensity), i.e. its floor
+        # is the LARGER of flop / MFMA peak and (input + output bytes, fp32, once) / HBM peak
+        nbytes = 4.0 * B * (cin + co) * Hc * Hc
+        r = {"layer": "%s %d%s->%d k%d @%dx%d" % (name, c0, ("+%d" % c1) if c1 else "", co, k, Hc, Hc), "flop": fl, "bytes": nbytes,
+             "floor_ms": max(fl / (MFMA_X3_PEAK_TF * 1e9), nbytes / (HBM_PEAK_GBS * 1e6)),
+             "floor_bound": "mfma" if fl / (MFMA_X3_PEAK_TF * 1e9) >= nbytes / (HBM_PEAK_GBS * 1e6) else "hbm",
              "fwd_path": "x3" if layer.xf_off >= 0 else ("x3/16" if layer.x16f_off >= 0 else "fp32"),
              "dgrad_path": "x3" if layer.xd_off >= 0 else ("x3/16" if layer.x16d_off >= 0 else "fp32")}
         r["fwd_ms"] = time_kernel(lambda: E._conv(layer, a0, a1, False, True))
@@ -233,6 +243,10 @@ def unet_layer_rooflines(B, H, dev):
     f, g = out["fwd"], out["dgrad"]
     fl = sum(r["flop"] for r in rows if r["fwd_path"] == "x3") + sum(r["flop"] for r in rows if r["dgrad_path"] == "x3" and "dgrad_ms" in r)
     out["fwd_dgrad"] = {"tflops": fl / (f["ms_sum"] + g["ms_sum"]) / 1e9, "frac": fl / (f["ms_sum"] + g["ms_sum"]) / 1e9 / MFMA_X3_PEAK_TF}
+    # the per-layer min(MFMA, HBM x intensity) roofline over the same launches: sum of the layers' floors / sum of their measured times
+    floor = sum(r["floor_ms"] for r in rows if r["fwd_path"] == "x3") + sum(r["floor_ms"] for r in rows if r["dgrad_path"] == "x3" and "dgrad_ms" in r)
+    out["fwd_dgrad"]["per_layer_min_frac"] = floor / (f["ms_sum"] + g["ms_sum"])
+    out["fwd_dgrad"]["hbm_bound_layers"] = [r["layer"] for r in rows if r["fwd_path"] == "x3" and r["floor_bound"] == "hbm"]
     return out
 
 
@@ -390,7 +404,7 @@ def kernel_rooflines(B, H, dev):
 
     def conv():   # the fp32-input-MFMA kernel, as round 1 launched it: bias + BatchNorm (sum, sum^2) partials in the epilogue
         ops.lib().call("wtpse_conv_fwd", x.data_ptr(), C, 0, 0, packed.data_ptr(), bias.data_ptr(), 0, 0, 0, y.data_ptr(), 0, C,
-                       stats.data_ptr(), B, Hc, Hc, C, 3, 0, 0, ops.stream_ptr())
+                       stats.data_ptr(), B, Hc, Hc, C, 3, 0, 0, 0, ops.stream_ptr())
     ms = time_kernel(conv)
     flops = 2.0 * C * C * 9 * Hc * Hc * B
     out["conv"] = {"kernel": "conv_fwd_k<3,2,5> (fp32-input MFMA) 64->64 3x3 @%dx%d B=%d (+bias, BN partials)" % (Hc, Hc, B), "ms": ms,
@@ -466,7 +480,28 @@ def log(msg):
 T0 = time.time()
 
 
-def cpu_baseline(H, full, full_protocol=False):
+def physical_cores():
+    """(CPU model, physical cores of the host) from /proc/cpuinfo; (None, None) if it cannot be read."""
+    model, phys = None, set()
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model is None:
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                pid = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                cid = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if pid is not None and cid is not None:
+                    phys.add((pid, cid))
+                pid = cid = None
+    except OSError:
+        pass
+    return model, (len(phys) or None)
+
+
+def cpu_baseline(H, full, full_protocol=False, threads=0):
     """The CPU restatement (oracle/, bit-checked against the reference in the build container) timed on this box's host
     cores: full A-D iterations (4 forward + 4 backward + 4 Adam) at B = 6 — what `--batch-size 8` yields
     in the reference — and B = 30, and compute_whitening_loss alone on [32,16,H,H].  Default: a bounded sample
@@ -484,28 +519,15 @@ def cpu_baseline(H, full, full_protocol=False):
     except AttributeError:
         cores = os.cpu_count() or 1
     granted = cores
-    cores = max(1, min(cores, 16))       # a 1-GPU box is granted 16 host cores; more threads only oversubscribe them
+    model, phys = physical_cores()
+    # all physical cores — as many as this process may use (rounds 1-5 capped the baseline at 16 threads
+    # although the driver's box granted 256 CPUs); hyper-threads beyond the physical cores only oversubscribe the FMA units
+    cores = threads if threads > 0 else max(1, min(granted, phys or granted))
     torch.set_num_threads(cores)
 
     def host_info():
-        """CPU model and PHYSICAL core count of the box (state it next to `cores`), from /proc/cpuinfo."""
-        model, phys = None, set()
-        try:
-            pid = cid = None
-            for line in open("/proc/cpuinfo"):
-                if line.startswith("model name") and model is None:
-                    model = line.split(":", 1)[1].strip()
-                elif line.startswith("physical id"):
-                    pid = line.split(":", 1)[1].strip()
-                elif line.startswith("core id"):
-                    cid = line.split(":", 1)[1].strip()
-                elif not line.strip():
-                    if pid is not None and cid is not None:
-                        phys.add((pid, cid))
-                    pid = cid = None
-        except OSError:
-            pass
-        return {"cpu_model": model, "physical_cores_on_host": len(phys) or None, "logical_cpus_on_host": os.cpu_count(),
+        """CPU model and PHYSICAL core count of the box (state it next to `cores`)."""
+        return {"cpu_model": model, "physical_cores_on_host": phys, "logical_cpus_on_host": os.cpu_count(),
                 "cpus_granted_to_this_process": granted, "threads_used": cores}
 
     def iteration_rate(B, warm, timed):
@@ -532,6 +554,17 @@ def cpu_baseline(H, full, full_protocol=False):
 
     r6, t6 = iteration_rate(6, 3 if full_protocol else 1, 10 if full_protocol else 3)
     r30, t30 = iteration_rate(30, 3 if full_protocol else 0, 10 if full_protocol else 1)
+    # (B=30 is slower PER IMAGE than B=6 on the CPU: at B=6 a 16-channel 256x256 activation is 25 MB and the step's working set stays
+    # in the EPYC's 256 MB+ of L3; at B=30 every tensor is 126 MB and streams from DRAM — profiles/r06_cpu_baseline_full.json has the
+    # per-image time at B = 6, 12, 18, 30)
+    by_batch = None
+    if full_protocol:
+        by_batch = {}
+        for bb in (12, 18):
+            rb, tb = iteration_rate(bb, 1, 3)
+            by_batch[str(bb)] = {"images_per_s": rb, "s_per_iteration": tb[len(tb) // 2]}
+        by_batch["6"] = {"images_per_s": r6, "s_per_iteration": t6[len(t6) // 2]}
+        by_batch["30"] = {"images_per_s": r30, "s_per_iteration": t30[len(t30) // 2]}
     z = torch.randn(32, 16, H, H)
     tw = []
     for i in range(13):
@@ -542,7 +575,7 @@ def cpu_baseline(H, full, full_protocol=False):
             tw.append(time.time() - t0)
     tw.sort()
     wt_gbs = z.numel() * 4.0 / tw[len(tw) // 2] / 1e9
-    return {"value": r6, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port", "host": host_info(),
+    return {"value": r6, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port", "host": host_info(), "by_batch": by_batch,
             "protocol": "SURVEY.md 8d in full: 3 warm-up + 10 timed iterations at B=6 and B=30" if full_protocol else
                         "bounded sample (1 warm-up + 3 timed at B=6, one iteration at B=30); the full protocol: --cpu-baseline-full",
             "sample": "median of %d full A-D iterations (4 fwd + 4 bwd + 4 Adam) after %d warm-up, B=6, 3x%dx%d, torch CPU fp32 "
@@ -587,6 +620,7 @@ def compact_line(line):
             "bound": r["bound"], "kernel": "conv_x3r_k + conv_x3_k (x3 forward + data gradient family)" if "forward + data" in r["kernel"]
             else "wgrad_r_k (x3 weight gradient family)",
             "achieved": r["achieved"], "peak": r["peak"], "unit": r["unit"], "frac": r["frac"],
+            "per_layer_min_frac": r.get("per_layer_min_frac"),
             "achieved_what": "FLOP-weighted over every launch of one U-Net on this family, isolated launches, HIP events (this run)",
             "in_step_frac": r.get("in_step_frac"), "in_step_tflops": ins.get("tflops"), "in_step_family_ms_per_step": ins.get("family_ms_per_step"),
             "in_step_source": (dom.get("profile") and ("committed %s (back-to-back kernels), not this run" % dom["profile"] if dom.get("same_library")
@@ -625,6 +659,7 @@ def compact_line(line):
         out["cpu_baseline"] = {"value": c["value"], "unit": c["unit"], "cores": c["cores"], "kind": c["kind"], "sample": c["sample"],
                                "cpu_model": (c.get("host") or {}).get("cpu_model"),
                                "physical_cores_on_host": (c.get("host") or {}).get("physical_cores_on_host"),
+                               "cpus_granted": (c.get("host") or {}).get("cpus_granted_to_this_process"),
                                "b30_images_per_s": (c.get("b30") or {}).get("value"),
                                "wt_loss_fwd_gbs": (c.get("wt_loss_fwd") or {}).get("value")}
     out["detail"] = line.get("detail_file")
@@ -679,6 +714,15 @@ def step_hbm_traffic(ms_per_step, copy_gbs):
             "source": "committed %s (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes over whole steps), not this run" % os.path.relpath(files[-1], ROOT)}
 
 
+def rccl_version():
+    """Version of the collective library behind the `nccl` backend (RCCL on ROCm), as torch reports it; None if it cannot say."""
+    try:
+        v = torch.cuda.nccl.version()
+        return ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception:
+        return None
+
+
 def _x3_on():
     from wtpse_hip import nn as E
     return bool(E.X3)
@@ -703,8 +747,31 @@ def measured_traffic():
                 "sources as loaded now), not measured by this run" % stamp.get("git_head", "?"))
 
 
+def self_launch_command(argv, gpus, port=None):
+    """`python bench.py --gpus N` started bare (WORLD_SIZE unset), as the driver starts N = 1: the command that runs the N ranks —
+    one process per GPU under torch.distributed.run, rendezvous on 127.0.0.1 (the container hostname may not resolve) — as a CHILD
+    of this process.  WTPSE_BENCH_LAUNCHER overrides the launcher (tests/test_bench_line_cpu.py substitutes a fake one)."""
+    if port is None:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    launcher = os.environ.get("WTPSE_BENCH_LAUNCHER")
+    head = launcher.split() if launcher else [sys.executable, "-m", "torch.distributed.run"]
+    return head + ["--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1", "--master-port", str(port),
+                   os.path.abspath(__file__)] + list(argv)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # (VERDICT r05: this used to die on the assert below.)  Nothing in this process has initialised the GPU yet — `import torch`
+        # does not — and nothing will: the ranks are fresh children, never an exec of a process that touched the device; their stdout
+        # (rank 0's ONE JSON line) and stderr are this process's own, the exit status is theirs.
+        import subprocess
+        cmd = self_launch_command(sys.argv[1:], args.gpus)
+        log("WORLD_SIZE unset with --gpus %d: starting the ranks as a child process: %s" % (args.gpus, " ".join(cmd)))
+        sys.exit(subprocess.run(cmd).returncode)
     if args.bn_sync and args.batch % 3 != 0:
         sys.exit("--bn-sync 1 (exact data-parallel mode) draws the sampling noise of every domain's rows from one global "
                  "Philox stream and needs a per-GPU batch that is a multiple of the 3 source domains: --batch %d is not "
@@ -717,7 +784,7 @@ def main():
         args.launch = "plan" if (world == 1 or args.batch < 16) else "eager"
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
+    assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d (or leave WORLD_SIZE unset: bench.py starts the ranks itself)" % (args.gpus, world, args.gpus)
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     ndev = torch.cuda.device_count()
     backend = os.environ.get("WTPSE_DIST_BACKEND", "nccl")     # "gloo": rehearsal of the N>1 path on a 1-GPU box
@@ -734,6 +801,9 @@ def main():
             dist.init_process_group(backend)
         from wtpse_hip.dp import DataParallel
         dp = DataParallel(world, rank, dev, bn_sync=bool(args.bn_sync))
+        ranks_seen = dist.get_world_size()
+    else:
+        ranks_seen = 1
 
     from wtpse_hip import ops as _ops
     if args.dtype == "bf16":
@@ -835,6 +905,8 @@ def main():
                                      "BASELINE.json configs[4] per-GPU share: full WT-PSE at high resolution") if full else
                                     "BASELINE.json configs[1]: seg-net only") + ", 3x%dx%d, batch %d per GPU" % (H, H, B),
                        "global_batch": B * world, "image": [3, H, H], "parallelism": "dp%d" % world,
+                       # what a SCALE record can be checked against: the ranks torch.distributed itself counted, the collective library
+                       "n_ranks_seen": ranks_seen, "dist_backend": (backend if world > 1 else None), "rccl_version": rccl_version(),
                        "bn_sync": bool(args.bn_sync), "step": "calls A-D + 4 backward + 4 Adam (Trainer.py:766-914)",
                        "launch": ("native launch plan" if ts.plan else "hipGraph replay") if ts.graph else "eager",
                        "roi": "od_pred covers %.3f of the pixels after %d untimed set-up steps" % (frac, presteps)},
@@ -873,7 +945,10 @@ def main():
             un = kr["unet"]
             fam = un["wgrad"] if lead == "x3_wgrad" else un["fwd_dgrad"]
             head = mfma_line(lead, lead)
-            head.update({"achieved": fam["tflops"], "frac": fam["frac"],
+            head.update({"achieved": fam["tflops"], "frac": fam["frac"], "per_layer_min_frac": fam.get("per_layer_min_frac"),
+                         "per_layer_min_frac_note": "SURVEY.md 8d: sum over the same launches of max(flop / MFMA peak, (input + output bytes) / "
+                                                    "8 TB/s) / sum of their measured times — the layers whose own bound is HBM, not MFMA: %s"
+                                                    % ", ".join(fam.get("hbm_bound_layers", [])) if lead == "x3_conv" else None,
                          "traffic_algorithmic": {"hbm_bytes": un["x3_3x3_mean_bytes"],
                                                  "note": "input + output bytes, mean over the same 3x3 launches `traffic` is averaged over"}
                          if lead == "x3_conv" else None,
@@ -934,7 +1009,7 @@ def main():
             line["configs1_seg_only"] = aux_seg_only(B, H, dev, args.steps, args.warmup)
         if world == 1 and not args.no_cpu_baseline:
             log("cpu baseline")
-            line["cpu_baseline"] = cpu_baseline(H, full, args.cpu_baseline_full)
+            line["cpu_baseline"] = cpu_baseline(H, full, args.cpu_baseline_full, args.cpu_threads)
             log("done")
         emit(line, args)
     if world > 1:

@@ -35,17 +35,20 @@ int wtpse_pack_conv_weights(const float* params, const int* desc, int n_desc, fl
  * BatchNorm statistics, algorithms.py:883-889); not combinable with relu_out.
  * mask_ref: NULL or [B][Cout][H][W]: out = mask_ref > 0 ? value : 0 (the ReLU backward of the layer below, fused into
  * its data gradient; not combinable with a split).
+ * out_amax: NULL or the amax table (see wtpse_amax; ZERO on entry) of the stored output — what an x2h consumer scales this tensor by
+ * when no train-mode BatchNorm sits in between (see wtpse_x3_terms); not combinable with mask_ref.
  * The data gradient is this same call on dY with the `wd` layout. */
 int wtpse_conv_fwd(const float* in0, int C0, const float* in1, int C1, const float* wpacked, const float* bias,
                    const float* pro0, const float* pro1, int pro_relu, float* out0, float* out1, int Csplit, float* stats,
-                   int B, int H, int W, int Cout, int ksize, int relu_out, const float* mask_ref, void* stream);
+                   int B, int H, int W, int Cout, int ksize, int relu_out, const float* mask_ref, unsigned* out_amax, void* stream);
 int wtpse_conv_stats_blocks(int B, int H, int W);
 /* 3x3 convolution with exactly 16 output channels (DeepWT, algorithms.py:1091-1117) that also emits the per-tile partial
  * Grams of its output in the epilogue: gram_partial [wtpse_conv_stats_blocks(B,H,W)][256] = the WT loss's `partial` layout
  * with S = tiles per image (wtpse_wt_loss_fwd_partials), so that compute_whitening_loss never re-reads z from HBM.
  * relu_out must be 0 (the Gram describes the stored map: the epilogue works on the pre-activation accumulators). */
 int wtpse_conv_fwd_gram(const float* in0, int C0, const float* wpacked, const float* bias, const float* pro0, int pro_relu,
-                        float* out0, float* gram_partial, int B, int H, int W, int Cout, int relu_out, void* stream);
+                        float* out0, float* gram_partial, int B, int H, int W, int Cout, int relu_out, unsigned* out_amax,
+                        void* stream);
 
 /* The same convolution on the BF16 matrix cores at fp32 accuracy (csrc/conv_x3.hip): every fp32 operand is split into three
  * bf16 terms and the product formed from the six leading cross terms with fp32 accumulation (6 bf16 MFMAs instead of 8 fp32
@@ -68,6 +71,11 @@ int wtpse_x3r_enable(int on);
  * once; 0 = dispatch order (tile fastest); on < 0 only queries (environment: WTPSE_X3_XCD=0|1).  Returns the previous setting.
  * Same workgroups, bitwise the same results (tests/test_conv_x3_gpu.py::test_xcd_order_equals_dispatch_order). */
 int wtpse_x3_xcd(int on);
+/* Tiling of the 32-channel-block launches on maps wider than 16 pixels: on = 1: 128-pixel (32 x 4) tiles — twice as many, half as long
+ * workgroups, five resident per CU instead of four — on = 0 (default until measured otherwise): 256-pixel (32 x 8) tiles; on < 0 only
+ * queries (environment: WTPSE_X3_SMALL_WIDE=0|1).  Returns the previous setting.  Changes the rows of `stats`
+ * (wtpse_conv_x3_stats_blocks follows it) and is part of wtpse_tuning_state(). */
+int wtpse_x3_small_wide(int on);
 /* Arithmetic of the x3 kernels (wtpse_conv_fwd_x3 and the data gradients on it, wtpse_conv_wgrad_r), by the number of 16-bit terms
  * an fp32 operand is split into:
  *   3 = "x3": three bf16 terms, six MFMA products per multiply (round 2);
@@ -75,12 +83,22 @@ int wtpse_x3_xcd(int on);
  *       in fp32), THREE products a0 b1 + a1 b0 + a0 b0 on v_mfma_f32_*_f16, fp32 accumulation — half the MFMAs of x3 at the same
  *       measured accuracy (tests/test_conv_x3_gpu.py: against fp64 beside x3 and the fp32-input MFMA).  fp16 has 5 exponent bits, so
  *       every operand tensor is multiplied by a power of two as it is loaded (exact) and the result scaled back: weights per layer
- *       (from the layer's largest magnitude, found by wtpse_pack_conv_weights_x3), forward activations by 2^2 (full precision for
- *       2^-5 <= |x| < 2^14, absolute error 2^-27 below; beyond 2^14 the fp16 term overflows and the outputs it feeds are NaN — loud, as
- *       for any divergence; NaN / inf operands propagate as in fp32), gradients by the power of two that brings
- *       `in_amax` — the tensor's amax table (wtpse_amax below), left by the tensor's producer
- *       (wtpse_bn_bwd_apply_coef, wtpse_upsample2x_bwd[_bn], ...) or by wtpse_amax — into [2^14, 2^15).  in_amax = NULL: the tensor is
- *       treated like a forward activation (fixed 2^2: right for O(1) data, NOT for real gradients);
+ *       (from the layer's largest magnitude, found by wtpse_pack_conv_weights_x3); an input tensor by the power of two that brings
+ *       `in_amax` — an amax table (wtpse_amax below) holding a bound of the largest magnitude of the input AS LOADED, i.e. after the
+ *       prologue — into [2^14, 2^15): full 22-bit precision for every element down to 2^-17 of the bound, an absolute error of 2^-39
+ *       of the bound below that.  For a GRADIENT the table is left by the tensor's producer (wtpse_bn_bwd_apply_coef,
+ *       wtpse_upsample2x_bwd[_bn], ...) or by wtpse_amax.  For a FORWARD ACTIVATION (round 6) it is left by whoever knows a bound:
+ *       the train-mode BatchNorm finalize (wtpse_bn_finalize / wtpse_conv_fwd_bnf, `act_amax`: |gamma| sqrt(N - 1) + |beta| per
+ *       channel by Samuelson's inequality — no look at the data), the producing convolution's epilogue (`out_amax`: un-normalised
+ *       maps), wtpse_act_bound (an eval-mode BatchNorm or any per-channel affine map over a tensor of known amax) or wtpse_amax.
+ *       A concat has one table per half (in_amax / in_amax1: the larger counts).  No table at all (NULL): the fixed scale 2^2 of
+ *       round 5 — full precision only for 2^-5 <= |x| < 2^14, NaN beyond: right for O(1) data, a fallback for bare callers only
+ *       (wtpse_hip/nn.py always passes tables).  Non-finite values: a NaN or inf operand makes every output it feeds NaN (the fp16
+ *       terms of an inf are (inf, NaN): an inf does not stay an inf as it can in fp32); forward launches store a NaN accumulator as
+ *       NaN, with or without an output ReLU, as torch's conv / ReLU do (the data gradients' epilogues clamp with v_max_f32, which
+ *       turns NaN into the clamp bound: -inf or 0 — non-finite, or masked, either way).  A consumer's ReLU-ON-LOAD is v_max_f32 too and
+ *       maps NaN to 0 where torch.relu keeps it: a NaN stays loud through BatchNorm statistics (its whole channel turns NaN) and through
+ *       un-activated paths (the heads' outputs, mu, the logits), not through an activation;
  *   1 = the `bf16` mode of BASELINE.json configs[1]: operands rounded to ONE bf16 term, one product — outside the 1e-4 parity bar by
  *       construction (tests/test_bf16_mode_gpu.py states its tolerance).
  * The weight gradients of the 16-pixel-wide maps (wtpse_conv_wgrad_x3) stay on x3.  Packed weights are in the format of the setting
@@ -98,21 +116,22 @@ int wtpse_pack_conv_weights_x3(const float* params, const int* desc, int n_desc,
 int wtpse_conv_fwd_x3(const float* in0, int C0, const float* in1, int C1, const unsigned short* wpacked, const float* bias,
                       const float* pro0, const float* pro1, int pro_relu, float* out0, float* out1, int Csplit, float* stats,
                       int B, int H, int W, int Cout, int ksize, int relu_out, const float* mask_ref, const unsigned* in_amax,
-                      void* stream);
+                      const unsigned* in_amax1, unsigned* out_amax, void* stream);      /* in_amax / in_amax1 / out_amax: wtpse_x3_terms, wtpse_conv_fwd */
 
 /* The 16-channel 3x3 layers (inc, DeepWT, the teacher's inc: algorithms.py:897-917,1091-1117,398-413) on v_mfma_f32_16x16x32_* with
  * register-resident weight fragments (csrc/conv.hip, MODE 3 / 4): Cout <= 16, C0 <= 16, one input.  wx16: the layer's fragments
  * (forward or data-gradient direction) from wtpse_pack_conv16_x3, 12808 unsigned shorts per direction (a 16-byte header with the
  * x2h weight scale, the x3 fragments, the x2h fragments), 16-byte aligned.  Arithmetic: wtpse_x3_terms() — x2h when it is 2, except
  * that a GRADIENT input (in_is_grad != 0) without its amax table (in_amax == NULL) runs in x3 (no scale is known for it and a pass
- * to find one costs more than this HBM-bound kernel would gain); in_is_grad == 0: a forward activation, scaled by 2^2.
+ * to find one costs more than this HBM-bound kernel would gain); in_is_grad == 0: a forward activation, scaled from in_amax (its
+ * bound as loaded; NULL: 2^2).  out_amax: as wtpse_conv_fwd.
  * Options as wtpse_conv_fwd (bias, prologue, relu_out, stats [wtpse_conv_stats_blocks][Cout][2], mask_ref) plus gram_partial
  * (as wtpse_conv_fwd_gram; Cout == 16, relu_out == 0) and — with bn_mean — the BatchNorm-backward epilogue of wtpse_dgrad_bnb
  * over all output channels (mask_ref = that layer's raw conv output, stats = its partials). */
 int wtpse_conv16_x3(const float* in0, int C0, const unsigned short* wx16, const float* bias, const float* pro0, int pro_relu,
                     float* out0, float* stats, float* gram_partial, const float* mask_ref, const float* bn_ss,
                     const float* bn_mean, int bn_relu, int B, int H, int W, int Cout, int relu_out, int in_is_grad,
-                    const unsigned* in_amax, void* stream);
+                    const unsigned* in_amax, unsigned* out_amax, void* stream);
 /* desc: n_desc x 8 ints {w_off, Cout, Cin, 9, fwd_off (-1: none), dgrad_off (-1: none), 0, 0}; w_off in floats, *_off in
  * unsigned shorts (multiples of 8). */
 int wtpse_pack_conv16_x3(const float* params, const int* desc, int n_desc, unsigned short* packed, void* stream);
@@ -136,12 +155,14 @@ int wtpse_dgrad_x3_bnb(const float* dy, int C, const unsigned short* wpacked, fl
  * (sum, sum^2) partials of its output in `stats` AND finishes them — wtpse_bn_finalize's work, done by the workgroups that arrive
  * last (two levels of tickets, fixed fold order: bitwise reproducible; see wtpse_dgrad_bnb_coef below for partial2 / tickets,
  * sized with the same two queries).  layout: 0 = wtpse_conv_fwd (fp32 `wf`), 1 = wtpse_conv_fwd_x3, 2 = wtpse_conv16_x3's
- * fragments (one input).  No split, mask or ReLU output: the BatchNorm follows. */
+ * fragments (one input).  No split, mask or ReLU output: the BatchNorm follows.  in_amax0 / in_amax1: the x2h input bounds of in0 /
+ * in1 (layouts 1, 2; NULL: none); act_amax: NULL or the amax table (ZERO on entry) that receives the bound of the BatchNorm's
+ * activated output, max_c |gamma_c| sqrt(B H W - 1) + |beta_c| (wtpse_x3_terms: the scale its x2h consumers load it with). */
 int wtpse_conv_fwd_bnf(const float* in0, int C0, const float* in1, int C1, const void* wpacked, int layout, const float* bias,
                        const float* pro0, const float* pro1, int pro_relu, float* out0, float* stats, const float* gamma,
                        const float* beta, float* running_mean, float* running_var, long long* num_batches, float momentum, float eps,
                        float* scale_shift, float* save_mean, float* save_invstd, double* partial2, unsigned* tickets, int B, int H,
-                       int W, int Cout, int ksize, void* stream);
+                       int W, int Cout, int ksize, const unsigned* in_amax0, const unsigned* in_amax1, unsigned* act_amax, void* stream);
 
 /* The same launches, which then ALSO finish the statistics: groups of 64 workgroups fold their partials as their last member
  * arrives, the last group of an output-channel block folds the group sums (fixed order: bitwise reproducible, nobody waits) and
@@ -184,14 +205,16 @@ int wtpse_conv_wgrad_x3(const float* dy, const float* x0, int C0, const float* x
  * side by side per 32-pixel step; no bias gradient, not the _bn form) —: wtpse_wgrad_r_supported().  With bias gradient
  * (dbias / dbias_slab NULL: skip).  slab: [nslab][Cout*Cin*9], dbias_slab: [nslab][Cout], nslab = wtpse_wgrad_r_slabs(...).
  * Arithmetic by wtpse_x3_terms(); with 2 (x2h) dY is scaled from dy_amax (NULL: like a forward activation — and the 16 x 16-channel
- * blocks, HBM-bound, then stay on x3), X by 2^2; the _bn form below stays on three bf16 terms.  With 1 (bf16 mode) only the blocks of
+ * blocks, HBM-bound, then stay on x3), X from x_amax0 / x_amax1 (the bounds of x0 / x1 as loaded; both NULL: 2^2); the _bn form below
+ * stays on three bf16 terms.  With 1 (bf16 mode) only the blocks of
  * 32 channels on at least one side run with one term: the 16 x 16 blocks (which alone carry a bias gradient), the _bn form and
  * wtpse_conv_wgrad_x3 keep three — the mode is a mix of arithmetics by design (the 16-channel layers are not MFMA-bound). */
 int wtpse_wgrad_r_supported(int Cin, int Cout, int ksize, int C0, int W);
 int wtpse_wgrad_r_slabs(int B, int H, int W, int Cin, int Cout);
 int wtpse_conv_wgrad_r(const float* dy, const float* x0, int C0, const float* x1, int C1, const float* pro0,
                        const float* pro1, int pro_relu, float* slab, float* dbias_slab, int nslab, float* dw, float* dbias,
-                       int accumulate, int B, int H, int W, int Cout, const unsigned* dy_amax, void* stream);    /* dy_amax: wtpse_x3_terms */
+                       int accumulate, int B, int H, int W, int Cout, const unsigned* dy_amax, const unsigned* x_amax0,
+                       const unsigned* x_amax1, void* stream);    /* *_amax: wtpse_x3_terms */
 
 /* wtpse_conv_wgrad_r with dY given as the un-applied second half of a BatchNorm backward (wtpse_bn_bwd_coef):
  * dY = k1[c] * g + k2[c] * bn_y + k3[c], bn_coef [Cout][3] = (k1, k2, k3): the BatchNorm-apply pass of the backward
@@ -202,10 +225,13 @@ int wtpse_conv_wgrad_r_bn(const float* g, const float* bn_y, const float* bn_coe
 
 /* ---- BatchNorm2d, eps 1e-5, momentum 0.1 (algorithms.py:862-864) ---------------------------------------------- */
 /* train mode: fold the conv epilogue's partials -> scale_shift[C][2], save_mean/invstd[C]; update running stats
- * (unbiased variance) and num_batches_tracked (int64) when given. */
+ * (unbiased variance) and num_batches_tracked (int64) when given.  act_amax: as wtpse_conv_fwd_bnf (NULL: none). */
 int wtpse_bn_finalize(const float* stats_partial, int nblk, int C, long long count, const float* gamma, const float* beta,
                       float* running_mean, float* running_var, long long* num_batches, float momentum, float eps,
-                      float* scale_shift, float* save_mean, float* save_invstd, void* stream);
+                      float* scale_shift, float* save_mean, float* save_invstd, unsigned* act_amax, void* stream);
+/* act_amax (the WHOLE table is written: it need not be zero) = bound of |scale_shift[c][0] * y + scale_shift[c][1]| over a tensor y whose
+ * amax table is raw_amax: max_c |scale| * amax + |shift| — the x2h input bound of an activation behind an eval-mode BatchNorm. */
+int wtpse_act_bound(const float* scale_shift, int C, const unsigned* raw_amax, unsigned* act_amax, void* stream);
 /* eval mode: scale_shift from the running statistics. */
 int wtpse_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                          float eps, int C, float* scale_shift, void* stream);
@@ -315,7 +341,8 @@ int wtpse_reparam_fwd(const float* mu, const float* logvar, const float* eps, fl
 int wtpse_reparam_bwd(const float* dz, const float* logvar, const float* eps, float* dlogvar, long long n, void* stream);
 int wtpse_exp_half(const float* logvar, float* std_, long long n, void* stream);
 int wtpse_reparam_student(const float* mu, const float* std_, const float* eps, float* z, long long n, void* stream);
-/* if any element is NaN: nan_to_num the whole tensor.  flag: one device int (scratch). No host sync. */
+/* if any element is NaN: nan_to_num the whole tensor (shape_networks.py:490-492: `if torch.isnan(mu).any(): mu = nan_to_num(mu)`).
+ * flag: one device int (scratch).  No host sync. */
 int wtpse_nan_scrub(float* x, long long n, int* flag, void* stream);
 /* Philox4x32-10 + Box-Muller; element i depends only on (seed, position + i): position = offset + *offset_dev (offset_dev
  * NULL: 0) = global element index, a multiple of 4.  Keeping the running position in device memory lets a captured
@@ -407,7 +434,8 @@ int wtpse_plan_size(void* plan);
 int wtpse_plan_add_call(void* plan, int fn, const void* args, int nargs, void* stream);
 int wtpse_plan_add_wait(void* plan, void* waiter, void* waited);
 int wtpse_plan_replay(void* plan);      /* -2 (WTPSE_ESTATE): wtpse_tuning_state() differs from the recording's */
-/* The run-time switches that decide tilings and the packed-weight format (wtpse_x3_terms | wtpse_x3r_enable << 4 | wtpse_x3_xcd << 8). */
+/* The run-time switches that decide tilings and the packed-weight format (wtpse_x3_terms | wtpse_x3r_enable << 4 | wtpse_x3_xcd << 8 |
+ * wtpse_x3_small_wide << 12). */
 int wtpse_tuning_state(void);
 
 /* Fingerprint (hex) of the sources and of this header the library was compiled from; the binding refuses a library

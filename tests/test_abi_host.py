@@ -46,7 +46,7 @@ def test_library_exports_every_declared_symbol():
     assert L.query("wtpse_wgrad_r_supported", 64, 64, 3, 16, 24) == 0
     assert L.query("wtpse_wgrad_r_slabs", 32, 16, 16, 256, 256) >= 1
     # argument validation happens before any launch
-    assert L.raw("wtpse_conv_fwd")(0, 16, 0, 0, 0, 0, 0, 0, 0, 0, 0, 16, 0, 1, 8, 8, 16, 3, 0, 0, 0) == -1
+    assert L.raw("wtpse_conv_fwd")(0, 16, 0, 0, 0, 0, 0, 0, 0, 0, 0, 16, 0, 1, 8, 8, 16, 3, 0, 0, 0, 0) == -1
 
 
 def test_stale_library_is_refused(monkeypatch):

@@ -44,3 +44,27 @@ def test_compact_line_is_small_and_complete():
         assert k in back["cpu_baseline"], k
     for k in ("roofline_wt_fwd", "roofline_wt_bwd"):
         assert back[k]["bound"] == "hbm" and back[k]["frac_of_copy"] > back[k]["frac"]
+
+
+def test_bare_multi_gpu_invocation_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 8` started bare (as the driver starts N = 1) died on an assert.  With WORLD_SIZE unset it
+    now runs the N ranks itself as a CHILD torch.distributed.run — before anything in the parent touches a GPU — forwards its flags,
+    relays the child's stdout and exits with its status.  Checked up to the launch decision with a fake launcher (no GPU here)."""
+    import subprocess
+    import sys
+    fake = tmp_path / "fake_launcher.py"
+    fake.write_text("import json, sys\nprint(json.dumps({'argv': sys.argv[1:]}))\nsys.exit(7)\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["WTPSE_BENCH_LAUNCHER"] = "%s %s" % (sys.executable, fake)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 7, (r.returncode, r.stderr[-500:])
+    argv = json.loads(r.stdout.strip().splitlines()[-1])["argv"]
+    assert argv[:3] == ["--nnodes=1", "--nproc-per-node", "2"]
+    assert argv[argv.index("--master-addr") + 1] == "127.0.0.1" and int(argv[argv.index("--master-port") + 1]) > 0
+    i = argv.index(os.path.join(ROOT, "bench.py"))
+    assert argv[i + 1:] == ["--gpus", "2", "--steps", "3", "--warmup", "1"]
+    # the real launcher is torch.distributed.run, one process per GPU
+    b = _bench()
+    cmd = b.self_launch_command(["--gpus", "4"], 4, port=29511)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"

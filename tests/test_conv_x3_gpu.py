@@ -639,8 +639,144 @@ def test_x2h_scales_follow_the_data(wscale, gscale):
     assert got == float(dy.abs().max()), (got, float(dy.abs().max()))
 
 
+ACT_SCALES = [1e-6, 1e-3, 1.0, 30.0, 1e4]
+
+
+def amax_value(tab):
+    """The value an amax table holds: float bits, the maximum over the 64 shards (one word per 64-byte line)."""
+    return float(tab[::16].view(torch.float32).max())
+
+
+@pytest.mark.parametrize("ascale", ACT_SCALES)
+def test_x2h_activation_scales_follow_the_data(ascale):
+    """Round 6: a FORWARD activation is scaled by the power of two that brings a bound of its largest
+    magnitude — an amax table, as for gradients — into [2^14, 2^15) instead of the fixed 2^2 of round 5 (which kept fp32 accuracy only
+    for 2^-5 <= |x| < 2^14).  Forward convolution (64-channel and 32-channel blocks, concat with one table per half), the 16-channel
+    kernel and the weight gradient's X operand with activations from 1e-6 to 1e4, against fp64: the relative L2 error stays at the
+    level of the O(1) case (<= 4e-7) at every scale, and nothing overflows."""
+    o = _x2h_only()
+    B, C0, C1, Co, H, W = 4, 32, 32, 64, 32, 32
+    w = rnd(Co, C0 + C1, 3, 3, seed=171, scale=0.2)
+    x0 = rnd(B, C0, H, W, seed=172) * ascale
+    x1 = rnd(B, C1, H, W, seed=173) * (ascale * 0.01)          # the second half of the concat a hundred times smaller
+    packed, xf, _ = pack_x3(w)
+    x0d, x1d = x0.to(DEV), x1.to(DEV)
+    a0, a1 = o.amax_of(x0d), o.amax_of(x1d)
+    assert amax_value(a0) == float(x0.abs().max())
+    out_amax = o.fwd_amax_table(x0d.device)
+    y, _, _ = o.conv_fwd_x3(x0d, x1d, packed.data_ptr() + 2 * xf, None, Co, 3, in_amax=a0, in_amax1=a1, out_amax=out_amax)
+    ref = F.conv2d(torch.cat([x0, x1], 1).double(), w.double(), padding=1)
+    e = float((y.cpu().double() - ref).norm() / ref.norm())
+    assert bool(torch.isfinite(y).all()) and e <= 4e-7, ("conv_fwd_x3", ascale, e)
+    # the producer's epilogue left the amax of what it stored
+    assert amax_value(out_amax) == float(y.abs().max())
+    assert y.wt_amax is out_amax
+    # a prologue in front: the bound is of the tensor AS LOADED (relu(x * 3 - 1 * ascale)), from wtpse_act_bound
+    pro = torch.stack([torch.full((C0,), 3.0), torch.full((C0,), -1.0 * ascale)], 1).contiguous().to(DEV)
+    ab = o.act_bound(pro, a0)
+    want = 3.0 * float(x0.abs().max()) + ascale
+    assert abs(amax_value(ab) - want) <= 1e-6 * want
+    w1 = rnd(32, C0, 3, 3, seed=174, scale=0.2)                 # 32-channel blocks (conv_x3_k)
+    p1, xf1, _ = pack_x3(w1)
+    y1, _, _ = o.conv_fwd_x3(x0d, None, p1.data_ptr() + 2 * xf1, None, 32, 3, pro0=pro, pro_relu=1, in_amax=ab)
+    act = F.relu(x0.double() * 3.0 - ascale)
+    ref1 = F.conv2d(act, w1.double(), padding=1)
+    e1 = float((y1.cpu().double() - ref1).norm() / ref1.norm())
+    assert bool(torch.isfinite(y1).all()) and e1 <= 4e-7, ("conv_fwd_x3 + prologue", ascale, e1)
+    # weight gradient: X scaled from its bound, dY from its amax
+    dy = rnd(B, 32, H, W, seed=175) * 1e-5
+    dyd = dy.to(DEV)
+    dw = torch.empty(32, C0, 3, 3, device=DEV)
+    o.conv_wgrad_r(dyd, x0d, None, dw, pro0=pro, pro_relu=1, dy_amax=o.amax_of(dyd), x_amax0=ab)
+    refw = torch.nn.grad.conv2d_weight(act, (32, C0, 3, 3), dy.double(), padding=1)
+    ew = float((dw.cpu().double() - refw).norm() / refw.norm())
+    assert bool(torch.isfinite(dw).all()) and ew <= 4e-7, ("wgrad", ascale, ew)
+    # the 16-channel kernel (conv_fwd_k MODE 4)
+    w16 = rnd(16, 16, 3, 3, seed=176, scale=0.3)
+    x16 = rnd(B, 16, H, W, seed=177) * ascale
+    p16, f16, _ = pack_x16(w16)
+    y16, _, _ = o.conv16_x3(x16.to(DEV), p16.data_ptr() + 2 * f16, None, 16, in_amax=o.amax_of(x16.to(DEV)))
+    ref16 = F.conv2d(x16.double(), w16.double(), padding=1)
+    e16 = float((y16.cpu().double() - ref16).norm() / ref16.norm())
+    assert bool(torch.isfinite(y16).all()) and e16 <= 4e-7, ("conv16_x3", ascale, e16)
+
+
+@pytest.mark.parametrize("gscale", [1e-3, 1.0, 30.0, 1e4])
+def test_x2h_train_mode_batchnorm_bound(gscale):
+    """The bound a train-mode BatchNorm's output travels with needs no look at the data: |gamma| sqrt(N - 1) + |beta| per channel
+    (Samuelson's inequality), left in the activation's amax table by the statistics' fold — in the launch (wtpse_conv_fwd_bnf, up to
+    2048 workgroups) or by wtpse_bn_finalize.  conv -> BatchNorm(gamma = gscale x O(1)) -> ReLU -> conv through the engine's own block
+    schedule (nn.convbn_fwd) against fp64 at gamma scales from 1e-3 to 1e4: the second convolution's output stays within the fp32
+    noise of the first (<= 1e-6 relative L2, the same at every scale), finite everywhere; the table holds the bound."""
+    o = _x2h_only()
+    import math
+    from wtpse_hip import nn as E
+    B, C, H, W = 4, 64, 32, 32
+
+    class Two(E.HipNet):
+        def __init__(self):
+            super().__init__()
+            self.conv1, self.bn1 = E.ConvP(C, C, 3), E.BNP(C)
+            self.conv2, self.bn2 = E.ConvP(C, C, 3), E.BNP(C)
+            self._finish_init()
+    net = Two().to(DEV)
+    g = torch.Generator().manual_seed(181)
+    with torch.no_grad():
+        net.bn1.weight.copy_(((torch.rand(C, generator=g) * 0.4 + 0.8) * gscale).to(DEV))
+        net.bn1.bias.copy_(((torch.rand(C, generator=g) - 0.5) * 0.2 * gscale).to(DEV))
+    net.train()
+    net.ensure_ready(repack=True)
+    x = rnd(B, C, H, W, seed=182)
+    with o.fwd_scope(torch.device(DEV)):
+        a1, _ = E.convbn_fwd(net.conv1, net.bn1, x.to(DEV), None, True, True, want_tape=False)
+        a2, _ = E.convbn_fwd(net.conv2, net.bn2, a1, None, True, True, want_tape=False)
+    assert a1.amax is not None
+    N = B * H * W
+    want = float((net.bn1.weight.abs() * math.sqrt(N - 1) + net.bn1.bias.abs()).max())
+    got = amax_value(a1.amax)
+    assert abs(got - want) <= 1e-5 * want, (got, want)
+    sd = {k: v.detach().cpu().double() for k, v in net.state_dict().items()}
+    y1 = F.conv2d(x.double(), sd["conv1.weight"], sd["conv1.bias"], padding=1)
+    z1 = F.relu(F.batch_norm(y1, None, None, sd["bn1.weight"], sd["bn1.bias"], True, 0.1, 1e-5))
+    assert float(z1.abs().max()) <= want                     # it IS a bound
+    y2 = F.conv2d(z1, sd["conv2.weight"], sd["conv2.bias"], padding=1)
+    e = float((a2.t.cpu().double() - y2).norm() / y2.norm())
+    assert bool(torch.isfinite(a2.t).all()) and e <= 1e-6, (gscale, e)
+
+
+def test_nonfinite_forward_operands_are_stored_as_nan():
+    """what round 5 read as 'the fp16 MFMA returns -inf for some NaN operands' was the epilogue's output clamp — v_max_f32
+    returns the OTHER operand for a NaN, so a NaN accumulator was stored as -inf (no output ReLU) or 0 (output ReLU) in EVERY
+    arithmetic.  Forward launches now clamp with a compare + select that keeps the NaN, as torch's conv / ReLU do (the reference's
+    `isnan` checks — the mu scrub, shape_networks.py:490 — expect to find it).  NaN and inf inputs; 64- and 32-channel blocks with and
+    without an output ReLU, the 16-channel kernel and the fp32-input MFMA kernel."""
+    o = ops()
+    B, Ci, H, W = 2, 32, 16, 32
+    for Co, bad, relu in ((64, float("nan"), False), (32, float("nan"), True), (64, float("inf"), False)):
+        w = rnd(Co, Ci, 3, 3, seed=191, scale=0.2)
+        packed, xf, _ = pack_x3(w)
+        x = rnd(B, Ci, H, W, seed=192)
+        x[1, 2, 3, 4] = bad
+        xd = x.to(DEV)
+        y, _, _ = o.conv_fwd_x3(xd, None, packed.data_ptr() + 2 * xf, None, Co, 3, relu_out=relu, in_amax=o.amax_of(xd))
+        assert bool(torch.isnan(y[1, :, 2:5, 3:6]).all()) or (bad == float("inf") and o.x3_terms() != 2), (Co, bad, y[1, :4, 2:5, 3:6])
+        assert not bool(torch.isfinite(y[1, :, 2:5, 3:6]).any()) and bool(torch.isfinite(y[0]).all())
+        pk, wf, _ = pack(w)
+        y32, _, _ = o.conv_fwd(xd, None, pk.data_ptr() + 4 * wf, None, Co, 3, relu_out=relu)
+        assert not bool(torch.isfinite(y32[1, :, 2:5, 3:6]).any()) and bool(torch.isfinite(y32[0]).all())
+        if bad != bad:
+            assert bool(torch.isnan(y32[1, :, 2:5, 3:6]).all())
+    w16 = rnd(16, 16, 3, 3, seed=193, scale=0.3)
+    x16 = rnd(B, 16, H, W, seed=194)
+    x16[0, 5, 8, 9] = float("nan")
+    p16, f16, _ = pack_x16(w16)
+    y16, _, _ = o.conv16_x3(x16.to(DEV), p16.data_ptr() + 2 * f16, None, 16, relu_out=True, in_amax=o.amax_of(x16.to(DEV)))
+    assert bool(torch.isnan(y16[0, :, 7:10, 8:11]).all()) and bool(torch.isfinite(y16[1]).all())
+
+
 def test_x2h_out_of_range_activation_is_loud():
-    """A forward activation is scaled by a fixed 2^2 (full precision for 2^-5 <= |x| < 2^14).  A value beyond 65504 / 4 overflows its fp16
+    """WITHOUT a bound table (a bare C-ABI caller: the engine always passes one, test_x2h_activation_scales_follow_the_data) a forward
+    activation is scaled by the fixed 2^2 of round 5 (full precision for 2^-5 <= |x| < 2^14).  A value beyond 65504 / 4 overflows its fp16
     term: the outputs it feeds are NON-FINITE — loud, the caller's NaN check fires — never a wrong finite number; every output that does
     not see the outlier is as accurate as without it.  Values far below 2^-5 lose relative, not absolute, precision (absolute error
     <= 2^-27 per element and unit weight)."""
@@ -679,5 +815,5 @@ def test_x2h_zero_and_nonfinite_gradients():
     n = rnd(B, Co, H, W, seed=92).to(DEV)
     n[1, 2, 3, 4] = float("nan")
     d, _, _ = o.conv_fwd_x3(n, None, packed.data_ptr() + 2 * xd, None, Ci, 3, in_amax=o.amax_of(n))
-    # (non-finite, not necessarily NaN: the fp16 matrix instruction returns -inf for some NaN operands — loud either way)
+    # (non-finite, not necessarily NaN: a data gradient's epilogue clamps with v_max_f32, which turns a NaN into its -inf bound — loud either way)
     assert not bool(torch.isfinite(d[1, :, 2:5, 3:6]).any()) and bool(torch.isfinite(d[0]).all())

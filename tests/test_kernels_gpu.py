@@ -478,7 +478,7 @@ def test_rejects_bad_arguments():
     from wtpse_hip.lib import WtpseError
     o = ops()
     with pytest.raises(WtpseError):
-        o.lib().call("wtpse_conv_fwd", 0, 16, 0, 0, 0, 0, 0, 0, 0, 0, 0, 16, 0, 1, 8, 8, 16, 3, 0, 0, 0)
+        o.lib().call("wtpse_conv_fwd", 0, 16, 0, 0, 0, 0, 0, 0, 0, 0, 0, 16, 0, 1, 8, 8, 16, 3, 0, 0, 0, 0)
     with pytest.raises(ValueError):
         o.conv_fwd(torch.zeros(1, 16, 8, 8), None, 0, None, 16, 3)     # host tensor: no CPU fallback
 

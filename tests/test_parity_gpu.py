@@ -82,7 +82,7 @@ def check_grads_vs_checksums(module, g, prefix, min_seen, kink_probe=None):
     (every entry within 8 % of the tensor's mean |grad| — at most one per tensor up to 3x that — pooled median within 1 %).  It is coarse on purpose: the
     32x32 fixtures reach 2x2 feature maps (BatchNorm over 12-28 values) and sit on kinks (ReLU, max-pool argmax,
     |G_ij|), so the reference's own fp32 gradients are only good to 0.3-6 % against an fp64 run of the same graph
-    (measured with tests/diag_grads.py).  The tight, self-calibrating gradient check is test_gradients_calibrated."""
+    (measured with tools/probe/diag_grads.py).  The tight, self-calibrating gradient check is test_gradients_calibrated."""
     seen, pooled, band, kinked = 0, [], None, 0
     for k, p in module.named_parameters():
         key = prefix + k
@@ -139,6 +139,7 @@ def oracle_grads(fn, sds, dtype):
     return [{k: sd[k].grad.double() for k in sd if not O.is_buffer(k) and sd[k].grad is not None} for sd in cast]
 
 
+NEARLY_CANCELLING = ("wt_model.DoubleConv2.double_conv.2.bias",)     # 16 elements, each a 781x cancelling sum over the whole gradient field
 CAL = 3.0      # the HIP path may be at most this many times as far from the fp64 evaluation as the reference's own fp32 CPU path
 CAL_KINK = 10.0  # ... on the 32x32 / 64x64 fixtures at B=6, where kink flips (not rounding) set both distances: see below
 
@@ -198,8 +199,11 @@ def assert_calibrated(module, g32, g64, what, cal=CAL, probes=None, strict=False
         # (round 5: the absolute cap binds only where the yardstick itself keeps it — on [3-1-32] the reference's own fp32 runs on
         # inputs perturbed by <= 1e-5 move this 16-element, nearly cancelling tensor by 5.5e-2 from the fp64 value: no fp32
         # implementation can be asked to stay within 2e-2 there.  profiles/r05_x2h_parity.md)
-        if worst[0] > 2e-2 and worst[0] > worst[1]:
-            msgs.append(f"{worst[2]}: HIP {worst[0]:.3e} vs CPU-fp32 {worst[1]:.3e}")
+        # (round 6, ADVICE r05: that allowance is for THAT tensor only — wt_model.DoubleConv2.double_conv.2.bias, the bias behind the WT
+        # loss — every other tensor keeps the plain 2e-2 cap)
+        for h, c, k in per:
+            if h > 2e-2 and not (k.endswith(NEARLY_CANCELLING) and h <= c):
+                msgs.append(f"{k}: HIP {h:.3e} vs CPU-fp32 {c:.3e} (cap 2e-2)")
         return med, msgs
 
     runs0 = list(g32) if isinstance(g32, (list, tuple)) else [g32]
@@ -277,6 +281,71 @@ def test_blocks_vs_golden(golden_dir, name, bi):
         ye, _ = E.convd_fwd(h.blk, x, False, want_tape=False)
     else:
         ye, _ = E.convu_fwd(h.blk, x, prev, False, want_tape=False)
+    close(ye.dense(), g[name + ".y_eval"], what="y_eval")
+
+
+def test_convu_first_near_kink_fixture(golden_dir):
+    """VERDICT r05 weak 2a / ADVICE r05: round 5 regenerated the block fixtures with input seeds that keep every ReLU unit of the
+    reference run away from its kink, and dropped the old `convu_first` case, in which ONE unit of the block's output sits within
+    fp32 rounding of zero (x2h flips it where x3 and the CPU's fp32 do not: 218 gradient elements differed, all in that unit's 3x3
+    footprint).  The old reference fixture is kept (tests/golden/blocks_near_kink.npz: the reference's arrays for seeds 302 / 402 /
+    502, bcfe95d) and judged here with the kink MEASURED: the units whose ReLU decision differs from the reference's are found from
+    the outputs (at most two, each with a reference pre-activation below 1e-5), their 3x3 footprints are masked in the two data
+    gradients, and everything else — the outputs, every other gradient element, the BatchNorm buffers, the eval-mode output — must
+    meet the tolerances of test_blocks_vs_golden: nothing else moved."""
+    from wtpse_hip import nn as E
+    g = np.load(os.path.join(golden_dir, "blocks_near_kink.npz"))
+    B, H, bi, name = 4, 16, 2, "convu_first"
+
+    class Holder(E.HipNet):
+        def __init__(self, blk):
+            super().__init__()
+            self.blk = blk
+            self._finish_init()
+
+    h = Holder(E.ConvUBlock(64, first=True)).to(DEV)
+    fill_state_dict(h.blk, SEED_W + 20 + bi)
+    h.ensure_ready(repack=True)
+    x = make_noise(300 + bi, (B, 64, H // 2, H // 2)).to(DEV)
+    prev = make_noise(400 + bi, (B, 32, H, H)).to(DEV)
+    y, tape = E.convu_fwd(h.blk, x, prev, True)
+    y = y.dense()
+    yr = torch.from_numpy(g[name + ".y"])
+    close(y, yr, what="y")
+    flips = ((y.cpu() > 0) != (yr > 0)).nonzero().tolist()
+    assert len(flips) <= 2, "more ReLU decisions differ from the reference than one near-kink unit explains: %s" % flips[:8]
+    for b, c, r, col in flips:
+        assert max(float(y[b, c, r, col].abs()), float(yr[b, c, r, col].abs())) < 1e-5, (b, c, r, col)
+    print("near-kink fixture: %d unit(s) decided differently from the reference: %s" % (len(flips), flips))
+    dy = make_noise(500 + bi, tuple(y.shape)).to(DEV)
+    h.begin_backward()
+    dx, dprev = E.convu_bwd(h.blk, tape, dy)
+    h.end_backward()
+    keep_p = torch.ones(tuple(dprev.shape), dtype=torch.bool)
+    keep_x = torch.ones(tuple(dx.shape), dtype=torch.bool)
+    for b, c, r, col in flips:
+        keep_p[b, :, max(r - 1, 0):r + 2, max(col - 1, 0):col + 2] = False
+        # the same footprint behind the bilinear x2 upsampling (two low-resolution neighbours per side) and the 1x1 conv
+        keep_x[b, :, max((r - 1) // 2 - 1, 0):(r + 1) // 2 + 2, max((col - 1) // 2 - 1, 0):(col + 1) // 2 + 2] = False
+    dpr, dxr = torch.from_numpy(g[name + ".dprev"]), torch.from_numpy(g[name + ".dx"])
+    close(torch.where(keep_p, dprev.cpu(), dpr), dpr, rtol=1e-3, atol=2e-4, what="dprev outside the flipped units' footprints")
+    close(torch.where(keep_x, dx.cpu(), dxr), dxr, rtol=1e-3, atol=2e-4, what="dx outside the flipped units' footprints")
+    for k, p in h.blk.named_parameters():
+        if is_prebn_bias(k):
+            continue
+        ref = g[f"{name}.g.{k}"]
+        got = p.grad.detach().cpu().clone()
+        if k.startswith(("conv3.", "bn3.")):
+            # a flipped unit of conv3's output channel c moves the parameter gradients of THAT channel by one pixel's worth (|dy| x
+            # |activation| of one of 1024: 0.14 at scale 143 in conv3.weight[36]); every other row must be at the block tests' tolerance
+            for _, c, _, _ in flips:
+                got[c] = torch.from_numpy(np.asarray(ref))[c]
+        close(got, ref, rtol=2e-3, atol=3e-4 * max(1.0, float(np.abs(ref).max())), what="g." + k)
+    for k, b in h.blk.named_buffers():
+        close(b.float(), g[f"{name}.buf.{k}"].astype(np.float32), rtol=1e-4, atol=1e-5, what="buf." + k)
+    h.blk.eval()
+    h.eval()
+    ye, _ = E.convu_fwd(h.blk, x, prev, False, want_tape=False)
     close(ye.dense(), g[name + ".y_eval"], what="y_eval")
 
 
@@ -794,6 +863,128 @@ def test_update_256_vs_oracle():
         d_hip = O.dice_coefficient((torch.sigmoid(pred[b, 0]) > 0.75).cpu().numpy(), od[b, 0].numpy())
         d_ref = O.dice_coefficient((torch.sigmoid(ref_pred[b, 0]) > 0.75).numpy(), od[b, 0].numpy())
         assert abs(d_hip - d_ref) <= 1e-4, (b, d_hip, d_ref)
+
+
+def _off_unit_statistics(net, seed):
+    """BatchNorm parameters and running statistics AWAY from the filler's O(1) (gamma in [0.8, 1.2], running_var in [0.6, 1.4]): whole
+    blocks with gamma x 1e-3 and x 30, running variances over two decades, running means three times wider — what separates a trained
+    checkpoint from a fresh one (every fixture lived in the O(1) regime, where round 5's fixed activation scale was right)."""
+    from wtpse_hip import nn as E
+    g = torch.Generator().manual_seed(seed)
+    small, large = ("down2.", "prior_dist.down3.", "up1."), ("up3.", "prior_dist.up2.", "down4.")
+    with torch.no_grad():
+        for name, m in net.named_modules():
+            if not isinstance(m, E.BNP):
+                continue
+            f = 1e-3 if any(name.startswith(p) for p in small) else 30.0 if any(name.startswith(p) for p in large) else 1.0
+            m.weight.mul_(f)
+            m.bias.mul_(f)
+            m.running_var.mul_((10.0 ** (torch.rand(m.c, generator=g) * 2.0 - 1.0)).to(m.running_var.device))
+            m.running_mean.mul_(3.0)
+    net.invalidate_packed()
+
+
+def _rescale_blocks(net, plan):
+    """Function-preserving rescaling: the BatchNorm of a conv + BatchNorm (+ReLU) layer gets gamma, beta x f and the convolution that
+    consumes its output gets its weights x 1/f (ReLU, max-pool and bilinear upsampling are positively homogeneous, f > 0): the network
+    computes the same function with the same conditioning, but the activation between the two layers is f times larger and the
+    consumer's weights f times smaller.  plan: {block prefix: f}; within a ConvD block bn1 -> conv2 and bn2 -> conv3, within a ConvU
+    block bn1 -> conv2 and bn2 -> the second half of conv3's input channels (cat(prev, y), algorithms.py:955)."""
+    mods = dict(net.named_modules())
+    with torch.no_grad():
+        for prefix, f in plan.items():
+            blk = mods[prefix]
+            pairs = []
+            if hasattr(blk, "conv1"):
+                pairs.append((blk.bn1, blk.conv2, None))
+            lo = blk.conv3.cin - blk.bn2.c if blk.conv3.cin != blk.bn2.c else None      # ConvU: y is the second half
+            pairs.append((blk.bn2, blk.conv3, lo))
+            for bn, conv, lo in pairs:
+                bn.weight.mul_(f)
+                bn.bias.mul_(f)
+                if lo is None:
+                    conv.weight.mul_(1.0 / f)
+                else:
+                    conv.weight[:, lo:].mul_(1.0 / f)
+    net.invalidate_packed()
+
+
+RESCALE = {"down2": 1e-3, "up3": 30.0, "down4": 1e4, "up1": 1e-5, "prior_dist.down3": 1e-4, "prior_dist.up2": 3e3, "inc": 64.0}
+
+
+@pytest.mark.parametrize("H", [64, 256])
+def test_update_predict_rescaled_blocks_vs_oracle(H):
+    """Round 6: activations far from O(1) at the plain 1e-4 bar.  Whole blocks are rescaled function-preservingly
+    (_rescale_blocks: gamma, beta x f, the consumer's weights / f, f from 1e-5 to 1e4), so the reference computes the same, equally
+    well-conditioned function — but the tensors between the rescaled layers are up to 1e4 and down to 1e-5 of their usual size.  Round
+    5's fixed 2^2 input scale lost relative precision below 2^-5 and overflowed to NaN above 2^14 there; the data-driven scale (the
+    Samuelson bound behind a train-mode BatchNorm, the stored data's amax behind an eval-mode one) must hold the bar at every f.
+    Train-mode update() and eval-mode predict() against the CPU oracle on the same state dict."""
+    B, pb = 6, 2
+    img, od, oc = make_inputs(177, B, H, H)
+    eps = make_noise(178, (B, 1, H, H))
+    main, shape, _, _ = build_nets(pb)
+    _rescale_blocks(main, RESCALE)
+    _rescale_blocks(shape, {k: v for k, v in RESCALE.items() if not k.startswith("prior_dist") and k != "inc"})
+    sd_main = {k: v.detach().cpu().clone() for k, v in main.state_dict().items()}
+    sd_shape = {k: v.detach().cpu().clone() for k, v in shape.state_dict().items()}
+    main.train()
+    main.set_noise([eps])
+    with torch.no_grad():
+        out, _, _, ins, dom = main.update(img.to(DEV), od.to(DEV), two_stage_inputs=img.to(DEV), two_step=True)
+        ref_out, _, _, ref_ins, ref_dom = O.wt_pse_update(dict(sd_main), HP, img, od, img, True, eps, 3, pb)
+    assert bool(torch.isfinite(out).all())
+    close(out, ref_out, atol=TOL, what="logits, rescaled blocks")
+    close(ins, ref_ins, rtol=1e-4, atol=1e-6, what="ins, rescaled blocks")
+    close(dom, ref_dom, rtol=1e-3, atol=1e-6, what="dom, rescaled blocks")
+    main.load_state_dict(sd_main)            # (the train-mode call advanced the running statistics)
+    main.eval(); shape.eval()
+    with torch.no_grad():
+        pred, att = main.predict(shape, img.to(DEV))
+        ref_pred, ref_att = O.wt_pse_predict(sd_main, sd_shape, HP, img, False)
+    assert bool(torch.isfinite(pred).all())
+    close(pred, ref_pred, atol=TOL, what="predict, rescaled blocks")
+    close(att, ref_att, atol=TOL, what="attention, rescaled blocks")
+
+
+@pytest.mark.parametrize("H", [64, 256])
+def test_update_predict_off_unit_statistics_vs_oracle(H):
+    """The same question with parameters that are NOT function-preserving: whole blocks with BatchNorm gammas x 1e-3 and x 30, running
+    statistics over two decades (_off_unit_statistics).  A gamma of 1e-3 in front of a convolution whose bias is O(0.1) makes the next
+    BatchNorm subtract a mean a hundred times larger than the signal: the REFERENCE's own fp32 evaluation is then 9e-4 .. 2e-3 away
+    from its fp64 evaluation on these inputs (measured: tools/probe/offunit_diag.py), so the 1e-4 bar is not a property any fp32
+    implementation has here.  Calibrated criterion instead, as for the gradients: against the oracle in fp64, the HIP path may be at
+    most as far as the reference's fp32 path is (or 1e-4 of the output scale, whichever is larger); and nothing may be non-finite."""
+    B, pb = 6, 2
+    img, od, oc = make_inputs(177, B, H, H)
+    eps = make_noise(178, (B, 1, H, H))
+    main, shape, _, _ = build_nets(pb)
+    _off_unit_statistics(main, 5)
+    _off_unit_statistics(shape, 6)
+    sd_main = {k: v.detach().cpu().clone() for k, v in main.state_dict().items()}
+    sd_shape = {k: v.detach().cpu().clone() for k, v in shape.state_dict().items()}
+    to64 = lambda d: {k: (v.double() if v.is_floating_point() else v) for k, v in d.items()}
+    main.train()
+    main.set_noise([eps])
+    with torch.no_grad():
+        out = main.update(img.to(DEV), od.to(DEV), two_stage_inputs=img.to(DEV), two_step=True)[0]
+        r32 = O.wt_pse_update(dict(sd_main), HP, img, od, img, True, eps, 3, pb)[0]
+        heartbeat("off-unit oracle fp64")
+        r64 = O.wt_pse_update(to64(sd_main), HP, img.double(), od.double(), img.double(), True, eps.double(), 3, pb)[0]
+    assert bool(torch.isfinite(out).all())
+    e_hip, e_ref = float((out.cpu().double() - r64).abs().max()), float((r32.double() - r64).abs().max())
+    print("update, off-unit statistics: |HIP - fp64| %.3e, |reference fp32 - fp64| %.3e, scale %.3g" % (e_hip, e_ref, float(r64.abs().max())))
+    assert e_hip <= max(TOL * float(r64.abs().max()), e_ref), (e_hip, e_ref)
+    main.load_state_dict(sd_main)
+    main.eval(); shape.eval()
+    with torch.no_grad():
+        pred = main.predict(shape, img.to(DEV))[0]
+        p32 = O.wt_pse_predict(sd_main, sd_shape, HP, img, False)[0]
+        p64 = O.wt_pse_predict(to64(sd_main), to64(sd_shape), HP, img.double(), False)[0]
+    assert bool(torch.isfinite(pred).all())
+    e_hip, e_ref = float((pred.cpu().double() - p64).abs().max()), float((p32.double() - p64).abs().max())
+    print("predict, off-unit statistics: |HIP - fp64| %.3e, |reference fp32 - fp64| %.3e, scale %.3g" % (e_hip, e_ref, float(p64.abs().max())))
+    assert e_hip <= max(TOL * float(p64.abs().max()), e_ref), (e_hip, e_ref)
 
 
 def test_update_predict_256_B32_vs_oracle():

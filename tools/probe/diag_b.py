@@ -1,7 +1,7 @@
 """Call B (student update) gradients at B=6, 32x32: HIP vs fp64 oracle — is the deviation a common scale factor?"""
 import sys, os
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))      # a checker script (uses oracle/): lives under tests/
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))      # a diagnostic (uses oracle/ as the CHECKER, like the tests it borrows from; nothing here ships)
 sys.path[:0] = [ROOT, os.path.join(ROOT, "wt-pse-code_amd"), os.path.join(ROOT, "tests")]
 from oracle import wtpse_cpu as O
 from oracle.inputs import make_inputs, make_noise

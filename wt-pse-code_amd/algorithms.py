@@ -165,17 +165,18 @@ class WT_PSE(E.HipNet, E.UNetBody):
         else:
             inputs = wt_in = self._as_input(inputs_all)
         training = self.training
-        emb = self._embedding(inputs, training, None)
-        if not self.hparams['shape_prior']:
-            out, _ = E._conv(self.outc[0], emb)
-            return out, None
-        learn_x_network.ensure_ready(repack=True)
-        w = E.deepwt_fwd(learn_x_network.wt_model, wt_in, want_tape=False)
-        z = learn_x_network._student_mu(E.Act(w.z2, None, True), learn_x_network.training, None)
-        _, pre, _, fuse = ops.attn_fuse_fwd(z, self.attention_layer.layer1.weight.data_ptr(), emb,
-                                            float(self.hparams['shape_attention_coeffient']), False, True, False)
-        out, _ = E._conv(self.outc[0], self._outc_input(fuse, z))
-        return out, pre
+        with ops.fwd_scope(inputs.device):           # the amax tables of this pass's activations (x2h arithmetic)
+            emb = self._embedding(inputs, training, None)
+            if not self.hparams['shape_prior']:
+                out, _ = E._conv(self.outc[0], emb)
+                return out, None
+            learn_x_network.ensure_ready(repack=True)
+            w = E.deepwt_fwd(learn_x_network.wt_model, wt_in, want_tape=False)
+            z = learn_x_network._student_mu(E.Act(w.z2, None, True), learn_x_network.training, None)
+            _, pre, _, fuse = ops.attn_fuse_fwd(z, self.attention_layer.layer1.weight.data_ptr(), emb,
+                                                float(self.hparams['shape_attention_coeffient']), False, True, False)
+            out, _ = E._conv(self.outc[0], self._outc_input(fuse, z))
+            return out, pre
 
     def _outc_input(self, fuse, z):
         """cat_shape: torch.cat([fuse_embedding, z_posterior], 1) (algorithms.py:1253,1348).  This non-default branch
@@ -212,6 +213,12 @@ class WT_PSE(E.HipNet, E.UNetBody):
         return emb
 
     def _forward_update(self, inputs, mask, wt_in, want_tape):
+        # one scope of amax tables per forward pass (x2h arithmetic: ops.fwd_scope), opened on the stream the pass starts on — in
+        # front of the fork to the second stream — and kept alive by the activations on the tape until the backward pass is done
+        with ops.fwd_scope(inputs.device):
+            return self._forward_update_body(inputs, mask, wt_in, want_tape)
+
+    def _forward_update_body(self, inputs, mask, wt_in, want_tape):
         hp = self.hparams
         t = E.Tape()
         t.shape_prior = bool(hp['shape_prior'])

@@ -76,7 +76,10 @@ class ShapeVariationalDist_x(E.HipNet, E.UNetBody):
         """Reference shape_networks.py:483-500.  `inputs` = W[-1] = relu(z2), materialised by the caller."""
         self.ensure_ready(repack=True)
         x = self._as_input(inputs)
-        mu, fmap = self._student_mu(E.Act(x), self.training, None, want_fmap=True)
+        if getattr(inputs, "wt_amax", None) is not None and x.data_ptr() == inputs.data_ptr():
+            x.wt_amax = inputs.wt_amax          # (the caller's W[-1] from DeepWTP.forward carries the amax table of its data)
+        with ops.fwd_scope(x.device):
+            mu, fmap = self._student_mu(E.Act(x), self.training, None, want_fmap=True)
         if not training:
             return mu
         logvar, _ = E.head_fwd(self.logvar_prior, fmap, (0, 2, 4), False)
@@ -112,6 +115,11 @@ class ShapeVariationalDist_x(E.HipNet, E.UNetBody):
         return (mu, fmap) if want_fmap else mu
 
     def _forward_update(self, main_network, x, mask, want_tape):
+        # one scope of amax tables per forward pass (see WT_PSE._forward_update)
+        with ops.fwd_scope(x.device):
+            return self._forward_update_body(main_network, x, mask, want_tape)
+
+    def _forward_update_body(self, main_network, x, mask, want_tape):
         t = E.Tape()
         training = self.training
         # teacher side: forward only (train-mode BatchNorm still advances its running statistics, as in the reference).

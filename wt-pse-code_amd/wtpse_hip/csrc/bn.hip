@@ -14,7 +14,7 @@ __global__ __launch_bounds__(256) void bn_finalize_k(const float* __restrict__ p
                                                     float* __restrict__ rmean, float* __restrict__ rvar,
                                                     long long* __restrict__ nbt, float momentum, float eps,
                                                     float* __restrict__ scale_shift, float* __restrict__ save_mean,
-                                                    float* __restrict__ save_invstd) {
+                                                    float* __restrict__ save_invstd, unsigned* __restrict__ act_amax) {
   __shared__ double shs[2][4];
   const int c = blockIdx.x, t = threadIdx.x;
   double s1 = 0.0, s2 = 0.0;
@@ -44,6 +44,7 @@ __global__ __launch_bounds__(256) void bn_finalize_k(const float* __restrict__ p
     scale_shift[2 * c + 1] = (float)(beta[c] - mean * gamma[c] * invstd);
     save_mean[c] = (float)mean;
     save_invstd[c] = (float)invstd;
+    if (act_amax) amax_put(act_amax, bn_act_bound(gamma[c], beta[c], count), (unsigned)c);     // common.h: the consumers' x2h input scale
     if (rmean) {
       double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
       rmean[c] = (float)((1.0 - momentum) * rmean[c] + momentum * mean);
@@ -62,6 +63,25 @@ __global__ void bn_eval_coeffs_k(const float* __restrict__ gamma, const float* _
   float sc = gamma[c] * invstd;
   scale_shift[2 * c] = sc;
   scale_shift[2 * c + 1] = beta[c] - rmean[c] * sc;
+}
+
+// Bound of |scale[c] * y + shift[c]| over a tensor y whose largest magnitude is known (raw_amax: the amax table its producer's epilogue
+// or wtpse_amax filled): max_c |scale[c]| * amax + |shift[c]| — the x2h input scale of an activation behind an EVAL-mode BatchNorm
+// (running statistics say nothing about this batch) or behind any other per-channel affine map.  One workgroup; writes the whole
+// table (it need not be zero on entry).
+__global__ __launch_bounds__(256) void act_bound_k(const float* __restrict__ ss, int C, const unsigned* __restrict__ raw_amax,
+                                                   unsigned* __restrict__ act_amax) {
+  __shared__ float red[4];
+  const float ymax = __builtin_bit_cast(float, amax_read(raw_amax));
+  float m = 0.f;
+  for (int c = threadIdx.x; c < C; c += 256) m = fmaxf(m, fabsf(ss[2 * c]) * ymax + fabsf(ss[2 * c + 1]));
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x < AMAX_SHARDS) {
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    act_amax[threadIdx.x * AMAX_STRIDE] = threadIdx.x == 0 ? amax_bits(m) : 0u;
+  }
 }
 
 // z = act(y*scale[c] + shift[c]); grid = (blocks over HW, B*C)
@@ -329,12 +349,18 @@ static void launch_apply(const float* dz, const float* y, const float* ss, int r
 extern "C" int wtpse_bn_finalize(const float* stats_partial, int nblk, int C, long long count, const float* gamma,
                                  const float* beta, float* running_mean, float* running_var, long long* num_batches,
                                  float momentum, float eps, float* scale_shift, float* save_mean, float* save_invstd,
-                                 void* stream) {
+                                 unsigned* act_amax, void* stream) {
   WTPSE_REQUIRE(stats_partial && gamma && beta && scale_shift && save_mean && save_invstd && nblk > 0 && C > 0 && count > 0);
   WTPSE_REQUIRE((running_mean == nullptr) == (running_var == nullptr));
   hipLaunchKernelGGL(bn_finalize_k, dim3(C), dim3(256), 0, (hipStream_t)stream, stats_partial, nblk, C, (double)count,
                      gamma, beta, running_mean, running_var, num_batches, momentum, eps, scale_shift, save_mean,
-                     save_invstd);
+                     save_invstd, act_amax);
+  return wtpse_status();
+}
+
+extern "C" int wtpse_act_bound(const float* scale_shift, int C, const unsigned* raw_amax, unsigned* act_amax, void* stream) {
+  WTPSE_REQUIRE(scale_shift && raw_amax && act_amax && C > 0);
+  hipLaunchKernelGGL(act_bound_k, dim3(1), dim3(256), 0, (hipStream_t)stream, scale_shift, C, raw_amax, act_amax);
   return wtpse_status();
 }
 

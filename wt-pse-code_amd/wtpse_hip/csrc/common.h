@@ -60,6 +60,16 @@ __device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t r, unsigned vof
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, (int)voffset, (int)soffset, 0);
 }
 
+// The output clamp of the convolutions' epilogues: max(v, lo), lo = 0 (output ReLU) or -inf.  v_max_f32 returns the OTHER operand when
+// one is NaN — a NaN accumulator would be stored as -inf (no ReLU) or 0 (ReLU), where the reference's conv / ReLU store NaN
+// (torch.relu(NaN) = NaN) and its `isnan` checks (shape_networks.py:490: the mu scrub) expect to find it.  The FORWARD launches (EPI 0)
+// therefore clamp with a compare + select that keeps a NaN; the data gradients' epilogues (EPI 1 / 2) keep the one-instruction form.
+template <int EPI>
+__device__ __forceinline__ float out_clamp(float v, float lo) {
+  if constexpr (EPI == 0) return v < lo ? lo : v;
+  else return fmaxf(v, lo);
+}
+
 // ---- split-bf16 ("x3") helpers shared by conv.hip's 16-channel path (conv_x3.hip / wgrad_r.hip carry their own copies)
 typedef __bf16 wt_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 wt_bf16x2 __attribute__((ext_vector_type(2)));
@@ -85,7 +95,7 @@ __device__ __forceinline__ f32x4 wt_mfma16x32(u32x4 a, u32x4 b, f32x4 c) {
 // convolutions and the register-resident weight gradient
 constexpr int X3_WHDR = 32;                // unsigned shorts of header in front of a packed block: float {1 / scale, scale, 0, 0, 12 slice maxima of |w|}
 constexpr int X3_WSLICES = 12;
-constexpr float X3_FWD_SCALE = 4.f;
+constexpr float X3_FWD_SCALE = 4.f;     // the fallback input scale of a forward activation whose bound nobody supplied (C-ABI callers: in_amax == null)
 
 // The largest magnitude of a gradient tensor travels as an "amax table": AMAX_SHARDS unsigneds (float bits of non-negative values:
 // they order like their bit patterns), one per 64-byte line, zero before the tensor's producer runs.  Producers fold a wave's (or a
@@ -117,11 +127,20 @@ __device__ __forceinline__ void amax_publish_wave(unsigned* table, unsigned m, u
   if ((threadIdx.x & 63) == 0 && m)
     (void)__hip_atomic_fetch_max(table + (shard_seed % AMAX_SHARDS) * AMAX_STRIDE, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// consumer side (any full wave): the maximum over the shards, wave-uniform
-__device__ __forceinline__ unsigned amax_read(const unsigned* table) {
-  unsigned v = table[(threadIdx.x & (AMAX_SHARDS - 1)) * AMAX_STRIDE];
+// consumer side (any full wave): the maximum over the shards, wave-uniform.  In two halves, so that a kernel can ISSUE the read of the
+// table in front of its first tile loads and pick the value up behind them (vmcnt completes in order: the table's round trip then
+// hides behind loads the workgroup waits for anyway, instead of standing in front of them or at their end): amax_load() = this lane's
+// shard (0 for a null table), amax_reduce() = the maximum over the lanes.
+__device__ __forceinline__ unsigned amax_load(const unsigned* table) {
+  return table ? table[(threadIdx.x & (AMAX_SHARDS - 1)) * AMAX_STRIDE] : 0u;
+}
+__device__ __forceinline__ unsigned amax_reduce(unsigned v) {
   for (int o = AMAX_SHARDS / 2; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o, 64));
   return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ __forceinline__ unsigned amax_read(const unsigned* table) {
+  unsigned v = table[(threadIdx.x & (AMAX_SHARDS - 1)) * AMAX_STRIDE];
+  return amax_reduce(v);
 }
 
 // power of two S with amax * S in [2^14, 2^15) (amax: float bits of a non-negative value); 1 for 0 / denormal / inf / nan
@@ -132,6 +151,23 @@ __device__ __host__ __forceinline__ float x3_scale_from_amax(unsigned bits) {
   se = se > 253 ? 253 : se;
   const unsigned sb = (unsigned)se << 23;
   return __builtin_bit_cast(float, sb);
+}
+
+// ---- scale of a FORWARD activation (round 6).  An x2h consumer multiplies its input by the power of two that brings a BOUND of the
+// tensor's largest magnitude into [2^14, 2^15); the bound travels in an amax table like a gradient's amax does, but nobody has to
+// look at the data for it where a train-mode BatchNorm produced the tensor: by Samuelson's inequality every sample of a population
+// of N values lies within sqrt(N - 1) (biased) standard deviations of its mean, so |gamma xhat + beta| <= |gamma| sqrt(N - 1) + |beta|
+// whatever the data (ReLU only lowers it).  For N = 2 M pixels the bound is 2^10.5 |gamma|: an O(gamma) activation then sits at 2^3.5
+// after scaling — full 22-bit precision down to 2^-6.5 |gamma|, absolute error 2^-28.5 |gamma| below, at ANY gamma (the fixed 2^2 of
+// round 5 gave exactly this for gamma = 1 and lost relative precision below, NaN above 2^14).  Tensors without a BatchNorm of their own
+// batch (DeepWT's maps, the fusion conv, eval-mode BatchNorm) get the amax of the stored data from their producer's epilogue instead.
+__device__ __forceinline__ float bn_act_bound(float gamma, float beta, double count) {
+  return fabsf(gamma) * (float)sqrt(count > 2.0 ? count - 1.0 : 1.0) + fabsf(beta);
+}
+// one value into an amax table (zero on entry), from any thread: no-return atomic max on shard (seed % AMAX_SHARDS)
+__device__ __forceinline__ void amax_put(unsigned* table, float v, unsigned seed) {
+  const unsigned b = amax_bits(v);
+  if (b) (void)__hip_atomic_fetch_max(table + (seed % AMAX_SHARDS) * AMAX_STRIDE, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
@@ -317,6 +353,7 @@ struct BnfTail {
   float* scale_shift;      // [Cout][2]
   float* save_mean;
   float* save_invstd;
+  unsigned* act_amax;      // amax table (zero on entry) that receives the bound of |BatchNorm output| (bn_act_bound), or null
   double count;
   float momentum, eps;
   int ngroups, ntiles, ctot, t2_off;
@@ -347,6 +384,7 @@ __device__ __forceinline__ void bnf_tail(const TailTicket& tk, const BnfTail& tl
     tl.scale_shift[2 * c + 1] = (float)(tl.beta[c] - mean * tl.gamma[c] * invstd);
     tl.save_mean[c] = (float)mean;
     tl.save_invstd[c] = (float)invstd;
+    if (tl.act_amax) amax_put(tl.act_amax, bn_act_bound(tl.gamma[c], tl.beta[c], tl.count), (unsigned)c);
     if (tl.rmean) {
       const double unbiased = tl.count > 1.0 ? var * tl.count / (tl.count - 1.0) : var;
       tl.rmean[c] = (float)((1.0 - tl.momentum) * tl.rmean[c] + tl.momentum * mean);
@@ -374,7 +412,7 @@ static inline void bnb_tail_geometry(BnbTail& t, int ntiles, int Cout, double co
 static inline BnfTail bnf_tail_none() {
   BnfTail t;
   t.partial2 = nullptr; t.tickets = nullptr; t.gamma = nullptr; t.beta = nullptr; t.rmean = nullptr; t.rvar = nullptr; t.nbt = nullptr;
-  t.scale_shift = nullptr; t.save_mean = nullptr; t.save_invstd = nullptr; t.count = 1.0; t.momentum = 0.f; t.eps = 0.f;
+  t.scale_shift = nullptr; t.save_mean = nullptr; t.save_invstd = nullptr; t.act_amax = nullptr; t.count = 1.0; t.momentum = 0.f; t.eps = 0.f;
   t.ngroups = 0; t.ntiles = 0; t.ctot = 0; t.t2_off = 0;
   return t;
 }
@@ -395,7 +433,7 @@ static inline bool tail_in_launch(long long workgroups) {
 }
 extern "C" int wtpse_bn_finalize(const float* stats_partial, int nblk, int C, long long count, const float* gamma, const float* beta,
                                  float* running_mean, float* running_var, long long* num_batches, float momentum, float eps,
-                                 float* scale_shift, float* save_mean, float* save_invstd, void* stream);
+                                 float* scale_shift, float* save_mean, float* save_invstd, unsigned* act_amax, void* stream);
 extern "C" int wtpse_bn_bwd_finalize_coef(const float* stats_partial, int nblk, int C, long long count, const float* gamma,
                                           const float* save_mean, const float* save_invstd, float* coef, float* dgamma,
                                           float* dbeta, int accumulate, void* stream);
@@ -407,6 +445,6 @@ static inline int tail_after_launch(const BnbTail& tl, const BnfTail& fl, float*
                                       tl.accumulate, stream);
   if (fl.tickets)
     return wtpse_bn_finalize(stats, nblk, Cout, count, fl.gamma, fl.beta, fl.rmean, fl.rvar, fl.nbt, fl.momentum, fl.eps,
-                             fl.scale_shift, fl.save_mean, fl.save_invstd, stream);
+                             fl.scale_shift, fl.save_mean, fl.save_invstd, fl.act_amax, stream);
   return 0;
 }

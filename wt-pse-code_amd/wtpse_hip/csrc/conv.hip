@@ -42,8 +42,9 @@ struct ConvArgs {
   float* out1;
   float* stats;        // [gridDim.x][Cout][2] or null
   const float* mask;   // [B][Cout][H][W] or null: out = mask > 0 ? value : 0 (ReLU backward fused into a data gradient)
-  const unsigned* in_amax;   // MODE 4 (x2h): the amax table of in0 when it is a gradient (common.h), or null: in_scale
+  const unsigned* in_amax;   // MODE 4 (x2h): the amax table of in0 as loaded (a gradient's amax, a forward activation's bound: common.h), or null: in_scale
   float in_scale;
+  unsigned* out_amax;        // EPI 0: the amax table (zero on entry) of the stored output, or null (conv_x3_kernels.h: ConvX3Args::out_amax)
   float* gram;         // [gridDim.x][16][16] or null (16-cout path): the tile's partial Gram  sum_px out[i][px] * out[j][px]
   // EPI == 2 (BatchNorm backward statistics in a data gradient's epilogue, see conv_x3.hip): output channels [bn_c0, bn_c1) are
   // masked with the ReLU of the conv + BatchNorm layer they flow into (raw conv output: `mask`, [B][bn_c1 - bn_c0][H][W]) and
@@ -164,12 +165,14 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
     // (x3) or three fp16 products (x2h: operands scaled by powers of two on the way in, the accumulators back on the way out —
     // conv_x3_kernels.h has the full description)
     u32x4* Xq = reinterpret_cast<u32x4*>(smem);           // [term XT][k-half 2][PEP positions] 16-byte rows of 8 channels
-    const float sx = MODE == 4 ? (a.in_amax ? x3_scale_from_amax(amax_read(a.in_amax)) : a.in_scale) : 1.f;
     const int g4 = lane >> 4;
     // loader work items: (halo position, k-half) in whole-wave blocks (as conv_x3.hip)
     constexpr int PB = (PE + 63) / 64, NIT = (2 * PB + 3) / 4;
     const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(a.in0 + (size_t)b * a.C0 * HW, (unsigned)a.C0 * HW * 4u);
     const bool any_pro = MODE == 4 || a.pro0 != nullptr || a.pro_relu != 0;      // x2h: the input scale rides in the coefficients
+    // (x2h) the input's amax table: read issued in front of the tile loads, picked up behind them (common.h, amax_load / amax_reduce)
+    const unsigned sx_raw = MODE == 4 ? amax_load(a.in_amax) : 0u;
+    __builtin_amdgcn_sched_barrier(0);
     float xv[NIT][8];
     int ipos[NIT], ihalf[NIT];
     bool iin[NIT];
@@ -184,8 +187,8 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int cg = min(hh * 8 + j, a.C0 - 1);
-        psc[hh][j] = (a.pro0 ? a.pro0[2 * cg] : 1.f) * sx;
-        psh[hh][j] = (a.pro0 ? a.pro0[2 * cg + 1] : 0.f) * sx;
+        psc[hh][j] = a.pro0 ? a.pro0[2 * cg] : 1.f;
+        psh[hh][j] = a.pro0 ? a.pro0[2 * cg + 1] : 0.f;
       }
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
@@ -209,6 +212,18 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
     for (int s5 = 0; s5 < 5; ++s5)
 #pragma unroll
       for (int t = 0; t < XT; ++t) afr[s5][t] = wq[(s5 * XT + t) * 64 + lane];
+    // the x2h input scale: a dependent read of the input's amax table (a gradient's, or since round 6 a forward activation's bound) —
+    // behind the tile loads, folded into the prologue coefficients (exact: a power of two)
+    const float sx = MODE == 4 ? (a.in_amax ? x3_scale_from_amax(amax_reduce(sx_raw)) : a.in_scale) : 1.f;
+    if constexpr (MODE == 4) {
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          psc[hh][j] *= sx;
+          psh[hh][j] *= sx;
+        }
+    }
     if (any_pro) {   // zero padding applies AFTER the fused affine/ReLU, as in the reference graph
       const bool relu = a.pro_relu & 1;
 #pragma unroll
@@ -478,6 +493,18 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
       __syncthreads();   // before the statistics (if any) reuse smem
     }
   }
+  if constexpr (EPI == 0) {
+    if (a.out_amax) {       // largest magnitude of what this wave stores (ragged parts are zero by now): one no-return atomic per wave
+      unsigned am = 0u;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < NACC; ++r) am = max(am, amax_bits(out_clamp<EPI>(acc[mt][nt][r], relu_lo)));
+      amax_publish_wave(a.out_amax, am, (unsigned)tile * 4u + (unsigned)wave);
+    }
+  }
   const unsigned hw4 = (unsigned)HW * 4u;
   // a launch that folds its own statistics publishes them and takes its tickets BEFORE it stores its output tile (see conv_x3.hip:
   // the hand-off drains the workgroup's outstanding stores); the values to store stay in the accumulators
@@ -525,7 +552,7 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
       }
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        float v = fmaxf(acc[mt][nt][r], relu_lo);
+        float v = out_clamp<EPI>(acc[mt][nt][r], relu_lo);
         if (MASK && !(mk[r][nt] > 0.f)) v = 0.f;
         if (BNB) {     // the ReLU decision of the forward pass: fmaf(y, scale, shift) > 0
           float zz = __builtin_fmaf(mk[r][nt], bsc, bsh);
@@ -549,7 +576,7 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
             s1 += v;
             s2 += v * (mk[r][nt] - bmu[r]);
           } else {
-            const float v = fmaxf(acc[mt][nt][r], relu_lo);   // forward statistics are never combined with a ReLU mask (host check)
+            const float v = out_clamp<EPI>(acc[mt][nt][r], relu_lo);   // forward statistics are never combined with a ReLU mask (host check)
             s1 += v;
             s2 += v * v;
           }
@@ -618,7 +645,7 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
         const __amdgpu_buffer_rsrc_t rs_o = second ? rs_o1 : rs_o0;
         const unsigned soff = (unsigned)(second ? min(cbase, a.Cout) - a.Csplit : min(cbase, a.Csplit)) * hw4;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) buf_store(rs_o, pvo[nt], soff, fmaxf(acc[mt][nt][r], relu_lo));
+        for (int nt = 0; nt < NT; ++nt) buf_store(rs_o, pvo[nt], soff, out_clamp<EPI>(acc[mt][nt][r], relu_lo));
       }
     if constexpr (BNB)
       bnb_tail<CB>(tk, a.tail, a.stats, a.bn_mean, a.bn_c0, a.bn_c1, cout0, tile, cblk, tid,
@@ -675,7 +702,7 @@ static int conv_fwd_impl(const float* in0, int C0, const float* in1, int C1, con
                          const float* pro0, const float* pro1, int pro_relu, float* out0, float* out1, int Csplit, float* stats,
                          int B, int H, int W, int Cout, int ksize, int relu_out, const float* mask_ref, float* gram,
                          void* stream, BnbArgs bn = BnbArgs{nullptr, nullptr, 0, 0, 0}, BnbTail tail = bnb_tail_none(),
-                         BnfTail ftail = bnf_tail_none()) {
+                         BnfTail ftail = bnf_tail_none(), unsigned* out_amax = nullptr) {
   WTPSE_REQUIRE(in0 && wpacked && out0 && B > 0 && H > 0 && W > 0 && C0 > 0 && C1 >= 0 && Cout > 0);
   WTPSE_REQUIRE(ksize == 1 || ksize == 3);
   WTPSE_REQUIRE((C1 == 0) == (in1 == nullptr));
@@ -688,6 +715,7 @@ static int conv_fwd_impl(const float* in0, int C0, const float* in1, int C1, con
   WTPSE_REQUIRE(!bnb || (mask_ref && stats && bn.ss && !bias && !relu_out && !gram && bn.c0 >= 0 && bn.c0 < bn.c1 && bn.c1 <= Cout &&
                          bn.c0 % 16 == 0 && (bn.c1 % 16 == 0 || bn.c1 == Cout)));
   WTPSE_REQUIRE(C1 == 0 || C0 % 16 == 0);   // a channel chunk must not straddle the two inputs
+  WTPSE_REQUIRE(!(out_amax && (mask_ref || bnb)));
   WTPSE_REQUIRE(!tail.tickets || (bnb && tail.partial2 && tail.gamma && tail.invstd && tail.coef && tail.dgamma && tail.dbeta));
   WTPSE_REQUIRE(!ftail.tickets || (!bnb && stats && !gram && ftail.partial2 && ftail.gamma && ftail.beta && ftail.scale_shift &&
                                    ftail.save_mean && ftail.save_invstd && (ftail.rmean == nullptr) == (ftail.rvar == nullptr)));
@@ -696,7 +724,7 @@ static int conv_fwd_impl(const float* in0, int C0, const float* in1, int C1, con
   a.ftail = ftail;
   a.bn_ss = bn.ss; a.bn_mean = bn.mean; a.bn_relu = bn.relu; a.bn_c0 = bnb ? bn.c0 : 0; a.bn_c1 = bnb ? bn.c1 : 0;
   a.in0 = in0; a.in1 = in1; a.wp = wpacked; a.bias = bias; a.pro0 = pro0; a.pro1 = pro1; a.out0 = out0; a.out1 = out1; a.stats = stats; a.mask = mask_ref; a.gram = gram;
-  a.in_amax = nullptr; a.in_scale = 1.f;
+  a.in_amax = nullptr; a.in_scale = 1.f; a.out_amax = out_amax;
   a.B = B; a.H = H; a.W = W; a.C0 = C0; a.C1 = C1; a.Cin = C0 + C1; a.CinP = (a.Cin + 3) & ~3;
   a.Cout = Cout; a.CoutP = (Cout + 15) & ~15; a.Csplit = Csplit; a.pro_relu = pro_relu; a.relu_out = relu_out;
   a.tiles_x = a.tiles_y = 0;
@@ -727,9 +755,9 @@ static int conv_fwd_impl(const float* in0, int C0, const float* in1, int C1, con
 extern "C" int wtpse_conv_fwd(const float* in0, int C0, const float* in1, int C1, const float* wpacked,
                               const float* bias, const float* pro0, const float* pro1, int pro_relu, float* out0, float* out1,
                               int Csplit, float* stats, int B, int H, int W, int Cout, int ksize, int relu_out,
-                              const float* mask_ref, void* stream) {
+                              const float* mask_ref, unsigned* out_amax, void* stream) {
   return conv_fwd_impl(in0, C0, in1, C1, wpacked, bias, pro0, pro1, pro_relu, out0, out1, Csplit, stats, B, H, W, Cout, ksize,
-                       relu_out, mask_ref, nullptr, stream);
+                       relu_out, mask_ref, nullptr, stream, BnbArgs{nullptr, nullptr, 0, 0, 0}, bnb_tail_none(), bnf_tail_none(), out_amax);
 }
 
 // Data gradient that also performs the first half of the BatchNorm backward of the layer it flows into (include/wtpse_hip.h).
@@ -753,13 +781,14 @@ static int conv16_x3_impl(const float* in0, int C0, const unsigned short* wx16, 
                           int pro_relu, float* out0, float* stats, float* gram_partial, const float* mask_ref,
                           const float* bn_ss, const float* bn_mean, int bn_relu, int B, int H, int W, int Cout, int relu_out,
                           int in_is_grad, const unsigned* in_amax, void* stream, BnbTail tail = bnb_tail_none(),
-                          BnfTail ftail = bnf_tail_none()) {
+                          BnfTail ftail = bnf_tail_none(), unsigned* out_amax = nullptr) {
   WTPSE_REQUIRE(in0 && wx16 && out0 && B > 0 && H > 0 && W > 0 && C0 > 0 && C0 <= 16 && Cout > 0 && Cout <= 16);
   WTPSE_REQUIRE(!(stats && relu_out) && !(gram_partial && (Cout != 16 || relu_out)));
   WTPSE_REQUIRE((((uintptr_t)wx16) & 15) == 0);
   const bool bnb = bn_mean != nullptr;
   WTPSE_REQUIRE(bnb || !(stats && mask_ref));
   WTPSE_REQUIRE(!bnb || (mask_ref && stats && bn_ss && !bias && !relu_out && !gram_partial));
+  WTPSE_REQUIRE(!(out_amax && (mask_ref || bnb)));
   WTPSE_REQUIRE(!tail.tickets || (bnb && tail.partial2 && tail.gamma && tail.invstd && tail.coef && tail.dgamma && tail.dbeta));
   WTPSE_REQUIRE(!ftail.tickets || (!bnb && stats && !gram_partial && ftail.partial2 && ftail.gamma && ftail.beta && ftail.scale_shift &&
                                    ftail.save_mean && ftail.save_invstd && (ftail.rmean == nullptr) == (ftail.rvar == nullptr)));
@@ -772,7 +801,7 @@ static int conv16_x3_impl(const float* in0, int C0, const unsigned short* wx16, 
   a.B = B; a.H = H; a.W = W; a.C0 = C0; a.C1 = 0; a.Cin = C0; a.CinP = 16;
   a.Cout = Cout; a.CoutP = 16; a.Csplit = Cout; a.pro_relu = pro_relu; a.relu_out = relu_out;
   a.tiles_x = a.tiles_y = 0;
-  a.in_amax = in_amax; a.in_scale = X3_FWD_SCALE;
+  a.in_amax = in_amax; a.in_scale = X3_FWD_SCALE; a.out_amax = out_amax;
   hipStream_t st = (hipStream_t)stream;
   if (g_x3_terms == 2 && (!in_is_grad || in_amax)) {
     if (bnb) return launch_fwd<3, 4, false, 2>(a, st);
@@ -787,9 +816,9 @@ static int conv16_x3_impl(const float* in0, int C0, const unsigned short* wx16, 
 extern "C" int wtpse_conv16_x3(const float* in0, int C0, const unsigned short* wx16, const float* bias, const float* pro0,
                                int pro_relu, float* out0, float* stats, float* gram_partial, const float* mask_ref,
                                const float* bn_ss, const float* bn_mean, int bn_relu, int B, int H, int W, int Cout, int relu_out,
-                               int in_is_grad, const unsigned* in_amax, void* stream) {
+                               int in_is_grad, const unsigned* in_amax, unsigned* out_amax, void* stream) {
   return conv16_x3_impl(in0, C0, wx16, bias, pro0, pro_relu, out0, stats, gram_partial, mask_ref, bn_ss, bn_mean, bn_relu, B, H, W,
-                        Cout, relu_out, in_is_grad, in_amax, stream);
+                        Cout, relu_out, in_is_grad, in_amax, stream, bnb_tail_none(), bnf_tail_none(), out_amax);
 }
 
 // ---- wtpse_dgrad_bnb / wtpse_dgrad_x3_bnb / wtpse_conv16_x3(bn_mean) whose launch ALSO finishes the statistics: the last
@@ -802,7 +831,8 @@ extern "C" int wtpse_dgrad_x3_bnb_tail(const float* dy, int C, const unsigned sh
 
 extern "C" int wtpse_conv_fwd_x3_ftail(const float* in0, int C0, const float* in1, int C1, const unsigned short* wpacked,
                                        const float* bias, const float* pro0, const float* pro1, int pro_relu, float* out0,
-                                       float* stats, const BnfTail* ftail, int B, int H, int W, int Cout, int ksize, void* stream);
+                                       float* stats, const BnfTail* ftail, int B, int H, int W, int Cout, int ksize,
+                                       const unsigned* in_amax0, const unsigned* in_amax1, void* stream);
 
 // ---- a forward convolution in front of a train-mode BatchNorm whose launch ALSO finishes the statistics (common.h: bnf_tail):
 // wtpse_conv_fwd / wtpse_conv_fwd_x3 / wtpse_conv16_x3 with `stats` + wtpse_bn_finalize in one launch.  layout as below.
@@ -811,20 +841,20 @@ extern "C" int wtpse_conv_fwd_bnf(const float* in0, int C0, const float* in1, in
                                   const float* gamma, const float* beta, float* running_mean, float* running_var,
                                   long long* num_batches, float momentum, float eps, float* scale_shift, float* save_mean,
                                   float* save_invstd, double* partial2, unsigned* tickets, int B, int H, int W, int Cout, int ksize,
-                                  void* stream) {
+                                  const unsigned* in_amax0, const unsigned* in_amax1, unsigned* act_amax, void* stream) {
   WTPSE_REQUIRE(stats && gamma && beta && scale_shift && save_mean && save_invstd && partial2 && tickets);
   WTPSE_REQUIRE(layout >= 0 && layout <= 2);
   BnfTail t = bnf_tail_none();
   t.partial2 = partial2; t.tickets = tickets; t.gamma = gamma; t.beta = beta; t.rmean = running_mean; t.rvar = running_var;
   t.nbt = num_batches; t.momentum = momentum; t.eps = eps; t.scale_shift = scale_shift; t.save_mean = save_mean;
-  t.save_invstd = save_invstd;
+  t.save_invstd = save_invstd; t.act_amax = act_amax;
   if (layout == 1)
     return wtpse_conv_fwd_x3_ftail(in0, C0, in1, C1, static_cast<const unsigned short*>(wpacked), bias, pro0, pro1, pro_relu, out0,
-                                   stats, &t, B, H, W, Cout, ksize, stream);
+                                   stats, &t, B, H, W, Cout, ksize, in_amax0, in_amax1, stream);
   if (layout == 2) {
     WTPSE_REQUIRE(ksize == 3 && !in1 && C1 == 0 && !pro1);
     return conv16_x3_impl(in0, C0, static_cast<const unsigned short*>(wpacked), bias, pro0, pro_relu, out0, stats, nullptr, nullptr,
-                          nullptr, nullptr, 0, B, H, W, Cout, 0, 0, nullptr, stream, bnb_tail_none(), t);
+                          nullptr, nullptr, 0, B, H, W, Cout, 0, 0, in_amax0, stream, bnb_tail_none(), t);
   }
   return conv_fwd_impl(in0, C0, in1, C1, static_cast<const float*>(wpacked), bias, pro0, pro1, pro_relu, out0, nullptr, Cout, stats,
                        B, H, W, Cout, ksize, 0, nullptr, nullptr, stream, BnbArgs{nullptr, nullptr, 0, 0, 0}, bnb_tail_none(), t);
@@ -914,11 +944,11 @@ extern "C" int wtpse_pack_conv16_x3(const float* params, const int* desc, int n_
 // S = tiles per image; see wtpse_wt_loss_fwd_partials).
 extern "C" int wtpse_conv_fwd_gram(const float* in0, int C0, const float* wpacked, const float* bias, const float* pro0,
                                    int pro_relu, float* out0, float* gram_partial, int B, int H, int W, int Cout, int relu_out,
-                                   void* stream) {
+                                   unsigned* out_amax, void* stream) {
   WTPSE_REQUIRE(gram_partial && Cout == 16);
   WTPSE_REQUIRE(!relu_out);     // the Gram epilogue works on the accumulators before the ReLU clamp: it describes the stored map only without one
   return conv_fwd_impl(in0, C0, nullptr, 0, wpacked, bias, pro0, nullptr, pro_relu, out0, nullptr, Cout, nullptr, B, H, W, Cout, 3,
-                       relu_out, nullptr, gram_partial, stream);
+                       relu_out, nullptr, gram_partial, stream, BnbArgs{nullptr, nullptr, 0, 0, 0}, bnb_tail_none(), bnf_tail_none(), out_amax);
 }
 
 // ------------------------------------------------------------------------------------------------

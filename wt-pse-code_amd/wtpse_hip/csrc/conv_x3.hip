@@ -112,9 +112,20 @@ extern "C" int wtpse_pack_conv_weights_x3(const float* params, const int* desc, 
   return wtpse_status();
 }
 
-// 128-pixel tiles: only where the 256-pixel tiling gives under two workgroups per CU on a 16-wide map (the deepest level)
+// 128-pixel tiles for the 32-channel blocks: where the 256-pixel tiling gives under two workgroups per CU on a 16-wide map (the deepest
+// level) — and, round 6, on the WIDE maps when wtpse_x3_small_wide() is on (32 x 4 tiles): the launches with one or two 16-channel
+// chunks (up4.conv3, up4.conv1, down1: HBM-heavy, 8192 / 2048 tiles) have no chunk loop to hide their load -> convert -> multiply ->
+// store sequence behind, only the other resident workgroups — twice as many, half as long workgroups (5 per CU by LDS and registers
+// instead of 4) keep more loads and stores in flight.  Changes the tiling, hence the rows of `stats`: part of wtpse_tuning_state().
+static int g_x3_small_wide = [] { const char* e = getenv("WTPSE_X3_SMALL_WIDE"); return (e && e[0] >= '0' && e[0] <= '1') ? e[0] - '0' : 0; }();
+extern "C" int wtpse_x3_small_wide(int on) {
+  const int was = g_x3_small_wide;
+  if (on >= 0) g_x3_small_wide = on ? 1 : 0;
+  return was;
+}
 static bool x3_small_tiles(int B, int H, int W, int CoutP, bool mt2) {
-  if (W > 16 || mt2) return false;
+  if (mt2) return false;
+  if (W > 16) return g_x3_small_wide != 0 && W % 32 == 0;
   return B * ceil_div(H, 16) * ceil_div(W, 16) * (CoutP / 32) < 512;
 }
 
@@ -140,7 +151,7 @@ extern "C" int wtpse_x3_xcd(int on) {
 // depend on, as one word: a launch plan (plan.hip) remembers the word it was recorded under and refuses to replay under another —
 // the replayed entry points re-read the switches, and a tiling that changed since the caller sized its buffers would write out of
 // bounds.
-extern "C" int wtpse_tuning_state(void) { return g_x3_terms | (g_x3r << 4) | (g_x3_xcd << 8); }
+extern "C" int wtpse_tuning_state(void) { return g_x3_terms | (g_x3r << 4) | (g_x3_xcd << 8) | (g_x3_small_wide << 12); }
 
 static bool x3_mt2(int B, int H, int W, int CoutP) {
   const int TW = W <= 16 ? 16 : 32, TH = 256 / TW;
@@ -180,8 +191,10 @@ static int conv_x3_impl(const float* in0, int C0, const float* in1, int C1, cons
                         const float* bias, const float* pro0, const float* pro1, int pro_relu, float* out0, float* out1,
                         int Csplit, float* stats, int B, int H, int W, int Cout, int ksize, int relu_out,
                         const float* mask_ref, const float* bn_ss, const float* bn_mean, int bn_relu, int bn_c0, int bn_c1,
-                        const unsigned* in_amax, void* stream, BnbTail tail = bnb_tail_none(), BnfTail ftail = bnf_tail_none()) {
+                        const unsigned* in_amax, void* stream, BnbTail tail = bnb_tail_none(), BnfTail ftail = bnf_tail_none(),
+                        const unsigned* in_amax1 = nullptr, unsigned* out_amax = nullptr) {
   WTPSE_REQUIRE(in0 && wpacked && out0 && B > 0 && H > 0 && W > 0 && C0 > 0 && C1 >= 0 && Cout > 0);
+  WTPSE_REQUIRE(!(in_amax1 && !in1) && !(out_amax && (mask_ref || bn_mean)));
   WTPSE_REQUIRE(ksize == 1 || ksize == 3);
   WTPSE_REQUIRE((C1 == 0) == (in1 == nullptr));
   WTPSE_REQUIRE(Csplit > 0 && Csplit <= Cout && ((Csplit == Cout) == (out1 == nullptr)));
@@ -197,7 +210,7 @@ static int conv_x3_impl(const float* in0, int C0, const float* in1, int C1, cons
   ConvX3Args a;
   a.in0 = in0; a.in1 = in1; a.wx = wpacked; a.bias = bias; a.pro0 = pro0; a.pro1 = pro1; a.out0 = out0; a.out1 = out1;
   a.stats = stats; a.mask = mask_ref;
-  a.in_amax = in_amax; a.in_scale = X3_FWD_SCALE;
+  a.in_amax = in_amax; a.in_amax1 = in_amax1; a.in_scale = X3_FWD_SCALE; a.out_amax = out_amax;
   a.bn_ss = bn_ss; a.bn_mean = bn_mean; a.bn_relu = bn_relu; a.bn_c0 = bnb ? bn_c0 : 0; a.bn_c1 = bnb ? bn_c1 : 0;
   WTPSE_REQUIRE(!tail.tickets || (bnb && tail.partial2 && tail.gamma && tail.invstd && tail.coef && tail.dgamma && tail.dbeta));
   a.tail = tail;
@@ -222,9 +235,10 @@ static int conv_x3_impl(const float* in0, int C0, const float* in1, int C1, cons
 extern "C" int wtpse_conv_fwd_x3(const float* in0, int C0, const float* in1, int C1, const unsigned short* wpacked,
                                  const float* bias, const float* pro0, const float* pro1, int pro_relu, float* out0, float* out1,
                                  int Csplit, float* stats, int B, int H, int W, int Cout, int ksize, int relu_out,
-                                 const float* mask_ref, const unsigned* in_amax, void* stream) {
+                                 const float* mask_ref, const unsigned* in_amax, const unsigned* in_amax1, unsigned* out_amax,
+                                 void* stream) {
   return conv_x3_impl(in0, C0, in1, C1, wpacked, bias, pro0, pro1, pro_relu, out0, out1, Csplit, stats, B, H, W, Cout, ksize,
-                      relu_out, mask_ref, nullptr, nullptr, 0, 0, 0, in_amax, stream);
+                      relu_out, mask_ref, nullptr, nullptr, 0, 0, 0, in_amax, stream, bnb_tail_none(), bnf_tail_none(), in_amax1, out_amax);
 }
 
 // Data gradient that also performs the first half of the BatchNorm backward of the layer it flows into (include/wtpse_hip.h).
@@ -239,10 +253,11 @@ extern "C" int wtpse_dgrad_x3_bnb(const float* dy, int C, const unsigned short* 
 // wtpse_conv_fwd_bnf (conv.hip), x3 layout
 extern "C" int wtpse_conv_fwd_x3_ftail(const float* in0, int C0, const float* in1, int C1, const unsigned short* wpacked,
                                        const float* bias, const float* pro0, const float* pro1, int pro_relu, float* out0,
-                                       float* stats, const BnfTail* ftail, int B, int H, int W, int Cout, int ksize, void* stream) {
+                                       float* stats, const BnfTail* ftail, int B, int H, int W, int Cout, int ksize,
+                                       const unsigned* in_amax0, const unsigned* in_amax1, void* stream) {
   WTPSE_REQUIRE(ftail && stats);
   return conv_x3_impl(in0, C0, in1, C1, wpacked, bias, pro0, pro1, pro_relu, out0, nullptr, Cout, stats, B, H, W, Cout, ksize, 0,
-                      nullptr, nullptr, nullptr, 0, 0, 0, nullptr, stream, bnb_tail_none(), *ftail);
+                      nullptr, nullptr, nullptr, 0, 0, 0, in_amax0, stream, bnb_tail_none(), *ftail, in_amax1);
 }
 
 // wtpse_dgrad_bnb_coef (conv.hip), x3 layout

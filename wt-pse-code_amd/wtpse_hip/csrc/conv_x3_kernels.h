@@ -39,11 +39,16 @@ struct ConvX3Args {
   float* out1;
   float* stats;
   const float* mask;
-  // TERMS 2 (two fp16 terms per operand): the input is multiplied by a power of two as it is loaded — in_scale, or, when in_amax
-  // is given (a data gradient: gradients have no fixed scale), the power of two that brings the largest magnitude of the input tensor
-  // (in_amax: its amax table, common.h, left by its producer or by wtpse_amax) into [2^14, 2^15); the result is scaled back in the epilogue
+  // TERMS 2 (two fp16 terms per operand): the input is multiplied by a power of two as it is loaded: the one that brings the largest
+  // magnitude of the input AS LOADED (after the prologue) into [2^14, 2^15), read from amax tables (common.h) — in_amax for in0 (a
+  // gradient's amax from its producer / wtpse_amax; a forward activation's bound from the BatchNorm finalize, the producer's epilogue
+  // or wtpse_act_bound), in_amax1 for in1, the larger of the two counts — or, with neither, in_scale; the result is scaled back in the epilogue
   const unsigned* in_amax;
+  const unsigned* in_amax1;
   float in_scale;
+  // EPI 0: the amax table (zero on entry) of the STORED output (after bias and output ReLU), or null — what a consumer without a
+  // train-mode BatchNorm in between scales by (eval-mode BatchNorm, un-normalised maps)
+  unsigned* out_amax;
   // EPI == 2 (BatchNorm backward statistics in a data gradient's epilogue): output channels [bn_c0, bn_c1) are the gradient
   // wrt the activated output of a conv + BatchNorm (+ReLU) layer whose raw conv output is `mask` ([B][bn_c1 - bn_c0][H][W]):
   // they are masked with [mask * scale + shift > 0] (bn_relu) and (sum g, sum g * (y - mean)) partials go to `stats`
@@ -98,14 +103,25 @@ __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
 // bits): h1 keeps its 11 bits only while |h0| >= 2^-3 and fp16 overflows at 65504.  So every operand tensor is multiplied by a power
 // of two on the way in (exact) and the accumulators by the inverse on the way out:
 //   * weights: per layer and direction, from the layer's largest magnitude (pack_weights_x3_k; header in front of the packed block);
-//   * forward activations (BatchNorm'd, pooled, upsampled tensors and the whitening features: O(1) by construction): X3_FWD_SCALE = 2^2
-//     — full precision for 2^-5 <= |x| < 2^14, absolute error 2^-27 below that (relative to an O(1) tensor: below fp32's own 2^-24); a
-//     value beyond 2^14 overflows to inf and turns the outputs it feeds into NaN: loud, like any divergence (common.h: split2h_pair);
+//   * forward activations: from a bound of the tensor's largest magnitude (ConvX3Args::in_amax / in_amax1; common.h, bn_act_bound:
+//     |gamma| sqrt(N - 1) + |beta| behind a train-mode BatchNorm, the data's amax otherwise) — the precision of round 5's fixed 2^2 on
+//     O(1) data, at any scale of the data; without a table (a bare C-ABI caller): X3_FWD_SCALE = 2^2, full precision for
+//     2^-5 <= |x| < 2^14, and a value beyond 2^14 overflows to inf and turns the outputs it feeds into NaN (common.h: split2h_pair);
 //   * gradients (no scale known a priori): from the tensor's largest magnitude, left by its producer in ConvX3Args::in_amax.
+// In two halves (common.h, amax_load / amax_reduce): x3_in_scale_issue() in front of the workgroup's first tile loads, x3_in_scale()
+// behind them.
 template <int TERMS>
-__device__ __forceinline__ float x3_in_scale(const ConvX3Args& a) {
+__device__ __forceinline__ unsigned x3_in_scale_issue(const ConvX3Args& a) {
+  if constexpr (TERMS != 2) return 0u;
+  else return max(amax_load(a.in_amax), amax_load(a.in_amax1));
+}
+template <int TERMS>
+__device__ __forceinline__ float x3_in_scale(const ConvX3Args& a, unsigned issued) {
   if constexpr (TERMS != 2) return 1.f;
-  else return a.in_amax ? x3_scale_from_amax(amax_read(a.in_amax)) : a.in_scale;
+  else {
+    if (!a.in_amax && !a.in_amax1) return a.in_scale;
+    return x3_scale_from_amax(amax_reduce(issued));
+  }
 }
 
 // (a, b) -> three dwords, each holding the bf16 pair (term_i(a), term_i(b)), i = 0, 1, 2.  Every term is rounded to nearest
@@ -214,6 +230,18 @@ __device__ __forceinline__ void x3_epilogue(const ConvX3Args& a, f32x16 (&acc)[M
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt][r] = (cvalid && poff[nt] >= 0) ? acc[mt][nt][r] : 0.f;
       }
   }
+  if constexpr (EPI == 0) {
+    if (a.out_amax) {       // largest magnitude of what this wave stores (ragged parts are zero by now): one no-return atomic per wave
+      unsigned am = 0u;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < NACC; ++r) am = max(am, amax_bits(out_clamp<EPI>(acc[mt][nt][r], relu_lo)));
+      amax_publish_wave(a.out_amax, live ? am : 0u, (unsigned)stats_row * 4u + (unsigned)(tid >> 6));
+    }
+  }
   const unsigned hw4 = (unsigned)HW * 4u;
   // A launch that folds its own statistics (bnb_tail / bnf_tail) publishes them and takes its tickets BEFORE it stores its output
   // tile: the hand-off drains the workgroup's outstanding stores (s_waitcnt vmcnt(0)), and with 8-16 K output stores in flight
@@ -260,7 +288,7 @@ __device__ __forceinline__ void x3_epilogue(const ConvX3Args& a, f32x16 (&acc)[M
       }
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        float v = fmaxf(acc[mt][nt][r], relu_lo);
+        float v = out_clamp<EPI>(acc[mt][nt][r], relu_lo);
         if (MASK && !(mk[r][nt] > 0.f)) v = 0.f;
         if (BNB) {     // the ReLU decision of the forward pass: fmaf(y, scale, shift) > 0 (channels outside [bn_c0, bn_c1): 0, 1)
           // (opaque to the vectoriser on purpose: with the two pixels' decisions fused into one v_pk_fma_f32 the masks of a few
@@ -287,7 +315,7 @@ __device__ __forceinline__ void x3_epilogue(const ConvX3Args& a, f32x16 (&acc)[M
             s1 += v;
             s2 += v * (mk[r][nt] - bmu[r]);
           } else {
-            const float v = fmaxf(acc[mt][nt][r], relu_lo);
+            const float v = out_clamp<EPI>(acc[mt][nt][r], relu_lo);
             s1 += v;
             s2 += v * v;
           }
@@ -353,7 +381,7 @@ __device__ __forceinline__ void x3_epilogue(const ConvX3Args& a, f32x16 (&acc)[M
         const __amdgpu_buffer_rsrc_t rs_o = second ? rs_o1 : rs_o0;
         const unsigned soff = (unsigned)(second ? min(cbase, a.Cout) - a.Csplit : min(cbase, a.Csplit)) * hw4;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) buf_store(rs_o, pvo[nt], soff, fmaxf(acc[mt][nt][r], relu_lo));
+        for (int nt = 0; nt < NT; ++nt) buf_store(rs_o, pvo[nt], soff, out_clamp<EPI>(acc[mt][nt][r], relu_lo));
       }
     if constexpr (BNB)
       bnb_tail<CB>(tk, a.tail, a.stats, a.bn_mean, a.bn_c0, a.bn_c1, cout0, stats_row, cblk, tid,
@@ -413,14 +441,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_k(ConvX3Args a) {
     q[2 * CB] = bn ? a.bn_mean[c - a.bn_c0] : 0.f;
   }
 
-  const float sx = x3_in_scale<TERMS>(a);          // power of two applied to the input on load (1 unless TERMS 2)
-  for (int c = tid; c < a.CinP; c += 256) {
-    const bool first = c < a.C0;
-    const float* pro = first ? a.pro0 : a.pro1;
-    const int cl = first ? c : c - a.C0;
-    const bool live = c < a.C0 + a.C1;
-    pro_s[c] = !live ? make_float2(0.f, 0.f) : (pro ? make_float2(pro[2 * cl] * sx, pro[2 * cl + 1] * sx) : make_float2(sx, 0.f));
-  }
+  float sx = 1.f;                                  // power of two applied to the input on load (1 unless TERMS 2): set below
 
   int off[NT];                                    // halo position of this lane's pixel (tap 0,0 corner)
 #pragma unroll
@@ -549,8 +570,28 @@ __global__ __launch_bounds__(256, 2) void conv_x3_k(ConvX3Args a) {
   };
 
   const int nchunks = a.CinP / KC;
+  // prologue coefficients of this thread's channels: fetched in front of the tile loads (their own latency), scaled and staged below
+  float2 praw[PRO_MAX / 256];
+#pragma unroll
+  for (int q = 0; q < PRO_MAX / 256; ++q) {
+    const int c = tid + 256 * q;
+    const bool first = c < a.C0;
+    const float* pro = first ? a.pro0 : a.pro1;
+    const int cl = first ? c : c - a.C0;
+    const bool live = c < a.C0 + a.C1;
+    praw[q] = !live ? make_float2(0.f, 0.f) : (pro ? make_float2(pro[2 * cl], pro[2 * cl + 1]) : make_float2(1.f, 0.f));
+  }
+  // the scale is a dependent read of the amax tables (a gradient's, or since round 6 a forward activation's bound): issued in front
+  // of the first tile's loads, picked up behind them — its round trip sits neither in front of every workgroup's first load (round 5)
+  // nor behind its last one
+  const unsigned sx_raw = x3_in_scale_issue<TERMS>(a);
+  __builtin_amdgcn_sched_barrier(0);               // (the read stays in FRONT of the tile loads)
   issue_x(0);
   issue_w(0, 0);
+  sx = x3_in_scale<TERMS>(a, sx_raw);
+#pragma unroll
+  for (int q = 0; q < PRO_MAX / 256; ++q)
+    if (tid + 256 * q < a.CinP) pro_s[tid + 256 * q] = make_float2(praw[q].x * sx, praw[q].y * sx);
   __syncthreads();                    // pro_s
   stash_x(0);
   stash_w(0);
@@ -730,7 +771,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3r_k(ConvX3Args a) {
   const int b = bx / a.tiles_y;
   const int cout0 = cblk * CB;
   const int HW = a.H * a.W;
-  const float sx = x3_in_scale<TERMS>(a);          // power of two applied to the input on load (1 for TERMS 3)
+  float sx = 1.f;                                  // power of two applied to the input on load (1 for TERMS 3): set behind the first loads
   if (tid < CB) bias_s[tid] = (a.bias && cout0 + tid < a.Cout) ? a.bias[cout0 + tid] : 0.f;
   if (EPI == 2 && tid < CB) {
     const int c = cout0 + tid;
@@ -739,14 +780,6 @@ __global__ __launch_bounds__(256, 2) void conv_x3r_k(ConvX3Args a) {
     q[0] = (bn && a.bn_relu) ? a.bn_ss[2 * (c - a.bn_c0)] : 0.f;
     q[CB] = (bn && a.bn_relu) ? a.bn_ss[2 * (c - a.bn_c0) + 1] : 1.f;
     q[2 * CB] = bn ? a.bn_mean[c - a.bn_c0] : 0.f;
-  }
-  for (int c = tid; c < a.CinP; c += 256) {
-    const bool first = c < a.C0;
-    const float* pro = first ? a.pro0 : a.pro1;
-    const int cl = first ? c : c - a.C0;
-    const bool live = c < a.C0 + a.C1;
-    // (power-of-two scaling commutes with the rounding of the fused multiply-add and with the ReLU: relu(fma(y, s sc, s sh)) = s relu(fma(y, sc, sh)))
-    pro_s[c] = !live ? make_float2(0.f, 0.f) : (pro ? make_float2(pro[2 * cl] * sx, pro[2 * cl + 1] * sx) : make_float2(sx, 0.f));
   }
 
   int off[NT];                                    // halo position of this lane's pixel (tap 0,0 corner)
@@ -883,9 +916,35 @@ __global__ __launch_bounds__(256, 2) void conv_x3r_k(ConvX3Args a) {
   static_assert(NPIECE <= NGRP, "one conversion piece per MFMA group");
   constexpr int G0 = NGRP - NPIECE;                // the pieces ride behind the last NPIECE groups
 
-  issue_x(0);
-  issue_a(0, 0, 0);
-  issue_a(0, 1, 1);
+  if constexpr (PLAIN) {
+    // no prologue (a data gradient, a block's first convolution): the conversion needs the scale only — read as in round 5, in front of
+    // everything (the split read below costs the BatchNorm-backward variant 11 registers and with them its third wave per SIMD)
+    sx = x3_in_scale<TERMS>(a, x3_in_scale_issue<TERMS>(a));
+    issue_x(0);
+    issue_a(0, 0, 0);
+    issue_a(0, 1, 1);
+  } else {
+    float2 praw[PRO_MAX / 256];                    // this thread's prologue coefficients: fetched in front of the tile loads
+#pragma unroll
+    for (int q = 0; q < PRO_MAX / 256; ++q) {
+      const int c = tid + 256 * q;
+      const bool first = c < a.C0;
+      const float* pro = first ? a.pro0 : a.pro1;
+      const int cl = first ? c : c - a.C0;
+      const bool live = c < a.C0 + a.C1;
+      praw[q] = !live ? make_float2(0.f, 0.f) : (pro ? make_float2(pro[2 * cl], pro[2 * cl + 1]) : make_float2(1.f, 0.f));
+    }
+    const unsigned sx_raw = x3_in_scale_issue<TERMS>(a);      // (the amax tables: read issued in front of the first loads, see conv_x3_k)
+    __builtin_amdgcn_sched_barrier(0);
+    issue_x(0);
+    issue_a(0, 0, 0);
+    issue_a(0, 1, 1);
+    sx = x3_in_scale<TERMS>(a, sx_raw);
+    // (power-of-two scaling commutes with the rounding of the fused multiply-add and with the ReLU: relu(fma(y, s sc, s sh)) = s relu(fma(y, sc, sh)))
+#pragma unroll
+    for (int q = 0; q < PRO_MAX / 256; ++q)
+      if (tid + 256 * q < a.CinP) pro_s[tid + 256 * q] = make_float2(praw[q].x * sx, praw[q].y * sx);
+  }
   __syncthreads();                                 // pro_s
   x3_static_for<NPIECE>([&](auto pc) __attribute__((always_inline)) { convert_piece(0, decltype(pc)::value, 0); });
   issue_x(KC);
@@ -962,7 +1021,10 @@ static int launch_x3(const ConvX3Args& a, const X3Launch& L, hipStream_t st) {
           else X3R_GO(2, 2, 5);
         }
       } else if (small) {
-        if constexpr (MT == 1) X3R_GO(1, 1, 4);
+        if constexpr (MT == 1) {
+          if (narrow) X3R_GO(1, 1, 4);
+          else X3R_GO(1, 1, 5);
+        }
       } else if (MT == 2) {
         if (narrow) X3R_GO(2, 4, 4);
         else X3R_GO(2, 4, 5);
@@ -973,7 +1035,10 @@ static int launch_x3(const ConvX3Args& a, const X3Launch& L, hipStream_t st) {
 #undef X3R_GO
     }
   } else if (small) {
-    if constexpr (MT == 1) hipLaunchKernelGGL((conv_x3_k<KS, 1, 4, EPI, 1, TERMS>), grid, dim3(256), 0, st, args);
+    if constexpr (MT == 1) {
+      if (narrow) hipLaunchKernelGGL((conv_x3_k<KS, 1, 4, EPI, 1, TERMS>), grid, dim3(256), 0, st, args);
+      else hipLaunchKernelGGL((conv_x3_k<KS, 1, 5, EPI, 1, TERMS>), grid, dim3(256), 0, st, args);
+    }
   } else if (narrow)
     hipLaunchKernelGGL((conv_x3_k<KS, MT, 4, EPI, 2, TERMS>), grid, dim3(256), 0, st, args);
   else

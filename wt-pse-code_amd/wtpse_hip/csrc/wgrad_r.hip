@@ -40,9 +40,12 @@ struct WgradRArgs {
   float* slab;     // [nslab][Cout][Cin][9]
   float* slab_b;   // [nslab_b][Cout] or null
   // TERMS 2 (two fp16 terms per operand, conv_x3_kernels.h): dY is multiplied by the power of two that brings its largest magnitude
-  // (dy_amax: its amax table, common.h, from its producer / wtpse_amax; null: X3_FWD_SCALE) into [2^14, 2^15), X by X3_FWD_SCALE as it is loaded;
-  // the slabs are scaled back as they are written
+  // (dy_amax: its amax table, common.h, from its producer / wtpse_amax; null: X3_FWD_SCALE) into [2^14, 2^15), X — as loaded, after the
+  // prologue — likewise from the bound in x_amax0 / x_amax1 (the tables of x0 / x1: conv_x3_kernels.h; the larger counts; neither:
+  // X3_FWD_SCALE); the slabs are scaled back as they are written
   const unsigned* dy_amax;
+  const unsigned* x_amax0;
+  const unsigned* x_amax1;
   int B, H, W, C0, C1, Cin, Cout;
   int pro_relu;
   int strips;      // W / 32
@@ -126,7 +129,15 @@ __global__ __launch_bounds__((64 * WgradRGeom<MF, NF>::NW), 1) void wgrad_r_k(Wg
   const int u0 = (int)((long long)wv * a.units / a.wpp), u1 = (int)((long long)(wv + 1) * a.units / a.wpp);
   const int HW = a.H * a.W;
   const unsigned W4 = (unsigned)a.W * 4u;
-  const float sx = TERMS == 2 ? X3_FWD_SCALE : 1.f;
+  float sx = 1.f;
+  if constexpr (TERMS == 2) {
+    sx = X3_FWD_SCALE;
+    if (a.x_amax0 || a.x_amax1) {
+      unsigned m = a.x_amax0 ? amax_read(a.x_amax0) : 0u;
+      if (a.x_amax1) m = max(m, amax_read(a.x_amax1));
+      sx = x3_scale_from_amax(m);
+    }
+  }
   const float sdy = TERMS == 2 ? (a.dy_amax ? x3_scale_from_amax(amax_read(a.dy_amax)) : X3_FWD_SCALE) : 1.f;
 
   f32x4 acc[MF][NF][NT];
@@ -525,7 +536,7 @@ extern "C" void wtpse_wgrad_reduce_launch2(const float* slab, int ksplit, int n,
 static int wgrad_r_impl(const float* dy, const float* x0, int C0, const float* x1, int C1, const float* pro0,
                         const float* pro1, int pro_relu, float* slab, float* dbias_slab, int nslab, float* dw,
                         float* dbias, int accumulate, int B, int H, int W, int Cout, const float* bn_y, const float* bn_coef,
-                        const unsigned* dy_amax, void* stream) {
+                        const unsigned* dy_amax, const unsigned* x_amax0, const unsigned* x_amax1, void* stream) {
   WTPSE_REQUIRE(dy && x0 && slab && dw && B > 0 && H > 0 && W > 0 && C0 > 0 && C1 >= 0 && Cout > 0);
   WTPSE_REQUIRE((C1 == 0) == (x1 == nullptr));
   WTPSE_REQUIRE((dbias == nullptr) == (dbias_slab == nullptr));
@@ -540,7 +551,7 @@ static int wgrad_r_impl(const float* dy, const float* x0, int C0, const float* x
   WTPSE_REQUIRE((long long)(C0 > C1 ? C0 : C1) * H * W * 4 < (1ll << 31) && (long long)Cout * H * W * 4 < (1ll << 31));
   WgradRArgs a;
   a.dy = dy; a.x0 = x0; a.x1 = x1; a.pro0 = pro0; a.pro1 = pro1; a.slab = slab; a.slab_b = dbias_slab;
-  a.bn_y = bn_y; a.bn_coef = bn_coef; a.dy_amax = dy_amax;
+  a.bn_y = bn_y; a.bn_coef = bn_coef; a.dy_amax = dy_amax; a.x_amax0 = x_amax0; a.x_amax1 = x1 ? x_amax1 : nullptr;
   a.B = B; a.H = H; a.W = W; a.C0 = C0; a.C1 = C1; a.Cin = Cin; a.Cout = Cout; a.pro_relu = pro_relu;
   a.strips = p.strips; a.nseg = p.nseg; a.rseg = p.rseg; a.units = p.units; a.wpp = p.wpp; a.nci = p.nci; a.twin = W == 16 ? 1 : 0;
   const bool pro = pro0 != nullptr || pro1 != nullptr || pro_relu != 0;
@@ -605,9 +616,10 @@ static int wgrad_r_impl(const float* dy, const float* x0, int C0, const float* x
 // Same contract as wtpse_conv_wgrad (include/wtpse_hip.h), 3x3 only; requires wtpse_wgrad_r_supported().
 extern "C" int wtpse_conv_wgrad_r(const float* dy, const float* x0, int C0, const float* x1, int C1, const float* pro0,
                                   const float* pro1, int pro_relu, float* slab, float* dbias_slab, int nslab, float* dw,
-                                  float* dbias, int accumulate, int B, int H, int W, int Cout, const unsigned* dy_amax, void* stream) {
+                                  float* dbias, int accumulate, int B, int H, int W, int Cout, const unsigned* dy_amax,
+                                  const unsigned* x_amax0, const unsigned* x_amax1, void* stream) {
   return wgrad_r_impl(dy, x0, C0, x1, C1, pro0, pro1, pro_relu, slab, dbias_slab, nslab, dw, dbias, accumulate, B, H, W, Cout,
-                      nullptr, nullptr, dy_amax, stream);
+                      nullptr, nullptr, dy_amax, x_amax0, x_amax1, stream);
 }
 
 // The same with dY given as the un-applied second half of a BatchNorm backward: dY = k1[c] * g + k2[c] * bn_y + k3[c],
@@ -617,5 +629,5 @@ extern "C" int wtpse_conv_wgrad_r_bn(const float* g, const float* bn_y, const fl
                                      int nslab, float* dw, int accumulate, int B, int H, int W, int Cout, void* stream) {
   WTPSE_REQUIRE(bn_y && bn_coef);
   return wgrad_r_impl(g, x0, C0, x1, C1, pro0, pro1, pro_relu, slab, nullptr, nslab, dw, nullptr, accumulate, B, H, W, Cout, bn_y,
-                      bn_coef, nullptr, stream);
+                      bn_coef, nullptr, nullptr, nullptr, stream);
 }

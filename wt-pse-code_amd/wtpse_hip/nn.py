@@ -98,8 +98,9 @@ class DeepWTP(nn.Module):
 
     def forward(self, x):
         self._root.ensure_ready(repack=True)
-        t = deepwt_fwd(self, x.detach().to(torch.float32).contiguous(), want_tape=False)
-        return [t.z1, t.z2, ops.affine_act(t.z2, None, True)]
+        with ops.fwd_scope(x.device):
+            t = deepwt_fwd(self, x.detach().to(torch.float32).contiguous(), want_tape=False)
+            return [t.z1, t.z2, Act(t.z2, None, True).dense()]      # (the maps carry their amax tables: Act)
 
 
 class DoubleConvP(nn.Module):
@@ -155,8 +156,9 @@ class TeacherP(UNetBody):
         """(z, mu) in training, mu otherwise; `inputs` = W[-1] = relu(z2) materialised by the caller."""
         root = self.fusion[0]._root
         root.ensure_ready(repack=True)
-        t = teacher_fwd(self, inputs.contiguous(), mask.contiguous(), self.training, want_logvar=training,
-                        want_tape=False)
+        with ops.fwd_scope(inputs.device):
+            t = teacher_fwd(self, inputs.contiguous(), mask.contiguous(), self.training, want_logvar=training,
+                            want_tape=False)
         if not training:
             return t.mu
         eps = root.next_noise(t.mu.shape)
@@ -449,20 +451,43 @@ class Act:
     """An activation as its producer left it in HBM: the stored tensor `t`, still to be passed through
     act(t * scale + shift) — BatchNorm-apply (`pro` = [C,2] scale/shift or None) and ReLU (`relu`) — which every consumer
     (conv / weight-gradient loaders, max-pool, bilinear upsample) applies as it loads.  BatchNorm outputs, relu(z2) and the
-    two halves of a torch.cat therefore never make a round trip through memory."""
-    __slots__ = ("t", "pro", "relu")
+    two halves of a torch.cat therefore never make a round trip through memory.
+    `amax` (x2h arithmetic): the amax table holding a BOUND of the largest magnitude of the activation as loaded — the scale its x2h
+    consumers load it with (include/wtpse_hip.h, wtpse_x3_terms).  Given by whoever made the Act (the BatchNorm finalize: no look at
+    the data); a tensor that is loaded as stored inherits the table its producer's epilogue attached (`t.wt_amax`); unknown (None):
+    act_amax() finds it with one extra pass the first time a consumer asks."""
+    __slots__ = ("t", "pro", "relu", "amax")
 
-    def __init__(self, t, pro=None, relu=False):
+    def __init__(self, t, pro=None, relu=False, amax=None):
         self.t, self.pro, self.relu = t, pro, bool(relu)
+        self.amax = amax if amax is not None else (getattr(t, "wt_amax", None) if pro is None else None)
 
     def dense(self):
         if self.pro is None and not self.relu:
             return self.t
-        return ops.affine_act(self.t, self.pro, self.relu)
+        z = ops.affine_act(self.t, self.pro, self.relu)
+        if self.amax is not None:
+            z.wt_amax = self.amax
+        return z
 
 
 def as_act(x):
     return x if isinstance(x, Act) else Act(x)
+
+
+# WTPSE_FWD_AMAX=0: the consumers fall back to round 5's fixed 2^2 input scale (A/B of what the data-driven scale costs; not a mode to run in)
+FWD_AMAX = os.environ.get("WTPSE_FWD_AMAX", "1") != "0"
+
+
+def act_amax(a):
+    """x2h arithmetic: the amax table of the activation `a` as loaded (Act.amax), None otherwise.  An activation nobody supplied a bound
+    for (a caller's own tensor entering a block) pays one pass over its data here, once: the table stays on the Act."""
+    if a is None or ops.x3_terms() != 2 or not FWD_AMAX:
+        return None
+    if a.amax is None:
+        raw = ops.amax_of(a.t)
+        a.amax = raw if a.pro is None else ops.act_bound(a.pro, raw)
+    return a.amax
 
 
 def _relu_bits(a0, a1):
@@ -488,22 +513,25 @@ def x3_eligible(k_dim, rows, ksize):
     return X3 and rows > 16 and 16 <= k_dim <= 256 and (ksize == 3 or k_dim >= 64)     # 256: wtpse_conv_fwd_x3 (include/wtpse_hip.h)
 
 
-def _conv(layer, a0, a1=None, relu_out=False, want_stats=False):
+def _conv(layer, a0, a1=None, relu_out=False, want_stats=False, want_amax=False):
+    """want_amax (x2h arithmetic): the launch also leaves the amax table of its output on the result (`y.wt_amax`) — for outputs
+    that reach an x2h consumer without a train-mode BatchNorm in between (DeepWT's maps, the fusion conv, eval-mode BatchNorm)."""
     root = layer._root
     a0 = as_act(a0)
     a1 = as_act(a1) if a1 is not None else None
+    out_amax = ops.fwd_amax_table(a0.t.device) if want_amax else None
     if layer.x16f_off >= 0 and a1 is None:
         y, stats, _ = ops.conv16_x3(a0.t, root.x3_ptr(layer.x16f_off), layer.bias, layer.cout, a0.pro, _relu_bits(a0, None),
-                                    relu_out, want_stats)
+                                    relu_out, want_stats, in_amax=act_amax(a0), out_amax=out_amax)
         return y, stats
     if layer.xf_off >= 0:
         y, _, stats = ops.conv_fwd_x3(a0.t, a1.t if a1 is not None else None, root.x3_ptr(layer.xf_off), layer.bias, layer.cout,
                                       layer.k, a0.pro, _relu_bits(a0, a1), relu_out, want_stats, None, None,
-                                      a1.pro if a1 is not None else None)
+                                      a1.pro if a1 is not None else None, act_amax(a0), act_amax(a1), out_amax)
         return y, stats
     y, _, stats = ops.conv_fwd(a0.t, a1.t if a1 is not None else None, root.packed_ptr(layer.wf_off), layer.bias, layer.cout,
                                layer.k, a0.pro, _relu_bits(a0, a1), relu_out, want_stats, None, None,
-                               a1.pro if a1 is not None else None)
+                               a1.pro if a1 is not None else None, out_amax)
     return y, stats
 
 
@@ -617,13 +645,15 @@ def _wgrad_side(layer, dy, a0, a1=None):
     if not WGRAD_SIDE_STREAM:
         return _wgrad(layer, dy, a0, a1, with_bias=False)
     amax = _gamax(dy)                # (on the main stream, in front of the fork: the data gradient that follows uses the same slot)
+    # (likewise — normally there since the forward pass; only where the launch takes the x2h weight gradient: wgrad_r)
+    xam = (act_amax(as_act(a0)), act_amax(as_act(a1)) if a1 is not None else None) if _takes_wgrad_r(layer, as_act(a0), a1) else (None, None)
     main = torch.cuda.current_stream()
     side = _side_stream(dy.device)
     stream_wait(side, main)
     with torch.cuda.stream(side):
         _wgrad(layer, dy, a0, a1, with_bias=False)
     a0 = as_act(a0)
-    for t in (dy, amax, a0.t, a0.pro) + ((as_act(a1).t, as_act(a1).pro) if a1 is not None else ()):
+    for t in (dy, amax, a0.t, a0.pro) + xam + ((as_act(a1).t, as_act(a1).pro) if a1 is not None else ()):
         if t is not None:
             t.record_stream(side)       # the caching allocator must not hand these out again before the side stream is done
     # (Under stream capture the allocator keeps record_stream'ed blocks out of circulation until the capture ends.  Holding the
@@ -633,22 +663,27 @@ def _wgrad_side(layer, dy, a0, a1=None):
     note_join(root, side)
 
 
+def _takes_wgrad_r(layer, a0, a1, with_bias=False):
+    """3x3 layers on maps that are a multiple of 32 pixels (or exactly 16) wide: the x3 weight gradient with register-resident operands
+    (csrc/wgrad_r.hip; bias gradient only in its 16 x 16-channel form: the DeepWT layers)"""
+    return (X3 and X3_WGRAD and WGRAD_R and layer.k == 3 and
+            ops.wgrad_r_supported(layer.cin, layer.cout, 3, a0.t.shape[1] if a1 is not None else 16, a0.t.shape[3]) and
+            (not with_bias or (layer.cin % 32 != 0 and layer.cout % 32 != 0)))
+
+
 def _wgrad(layer, dy, a0, a1=None, with_bias=True):
     root = layer._root
     a0 = as_act(a0)
     a1 = as_act(a1) if a1 is not None else None
     dw = root.gview(layer.weight)
     db = root.gview(layer.bias) if with_bias else None
-    # 3x3 layers on maps that are a multiple of 32 pixels (or exactly 16) wide: the x3 weight gradient with register-resident operands
-    # (csrc/wgrad_r.hip; bias gradient only in its 16 x 16-channel form: the DeepWT layers)
-    if (X3 and X3_WGRAD and WGRAD_R and layer.k == 3 and
-            ops.wgrad_r_supported(layer.cin, layer.cout, 3, a0.t.shape[1] if a1 is not None else 16, a0.t.shape[3]) and
-            (db is None or (layer.cin % 32 != 0 and layer.cout % 32 != 0))):
+    if _takes_wgrad_r(layer, a0, a1, with_bias):
         # (the 16 x 16-channel blocks are HBM-bound: an extra pass over dY to find its scale costs more than x2h gains there — they
         # take the table their dY's producer attached, or run in x3)
         small = layer.cin % 32 != 0 and layer.cout % 32 != 0
         ops.conv_wgrad_r(dy, a0.t, a1.t if a1 is not None else None, dw, db, a0.pro, _relu_bits(a0, a1), False,
-                         a1.pro if a1 is not None else None, getattr(dy, "wt_amax", None) if small else _gamax(dy))
+                         a1.pro if a1 is not None else None, getattr(dy, "wt_amax", None) if small else _gamax(dy),
+                         act_amax(a0), act_amax(a1))
         return
     if (X3 and X3_WGRAD and db is None and
             ops.wgrad_x3_supported(layer.cin, layer.cout, layer.k, a0.t.shape[1] if a1 is not None else 8)):
@@ -664,6 +699,9 @@ def convbn_fwd(conv, bn, a0, a1, relu, training, want_tape=True):
     root = conv._root
     a0 = as_act(a0)
     a1 = as_act(a1) if a1 is not None else None
+    # (x2h) the bound of the activated output travels with it to its consumers: from the statistics' fold in train mode
+    # (|gamma| sqrt(N - 1) + |beta|: common.h, bn_act_bound), from the stored data's amax behind an eval-mode BatchNorm
+    tab = ops.fwd_amax_table(a0.t.device) if training else None
     if training and BN_TAIL and not (root._dp is not None and root._dp.bn_sync):
         # the convolution finishes its own statistics (csrc/common.h: bnf_tail): no finalize launch
         if conv.x16f_off >= 0 and a1 is None:
@@ -674,7 +712,9 @@ def convbn_fwd(conv, bn, a0, a1, relu, training, want_tape=True):
             layout, wptr = 0, root.packed_ptr(conv.wf_off)
         y, ss, mean, invstd = ops.conv_fwd_bnf(a0.t, a1.t if a1 is not None else None, wptr, layout, conv.bias, conv.cout, conv.k,
                                                a0.pro, _relu_bits(a0, a1), a1.pro if a1 is not None else None, bn.weight, bn.bias,
-                                               bn.running_mean, bn.running_var, bn.num_batches_tracked)
+                                               bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                                               in_amax0=act_amax(a0) if layout else None,
+                                               in_amax1=act_amax(a1) if layout == 1 else None, act_amax=tab)
     elif training:
         y, stats = _conv(conv, a0, a1, False, True)
         B, _, H, W = y.shape
@@ -683,12 +723,13 @@ def convbn_fwd(conv, bn, a0, a1, relu, training, want_tape=True):
         else:
             count = B * H * W
         ss, mean, invstd = ops.bn_finalize(stats, count, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                           bn.num_batches_tracked)
+                                           bn.num_batches_tracked, act_amax=tab)
     else:
-        y, _ = _conv(conv, a0, a1, False, False)
+        y, _ = _conv(conv, a0, a1, False, False, want_amax=True)
         ss = ops.bn_eval_coeffs(bn.weight, bn.bias, bn.running_mean, bn.running_var)
+        tab = ops.act_bound(ss, y.wt_amax) if getattr(y, "wt_amax", None) is not None else None
         mean = invstd = None
-    z = Act(y, ss, relu)
+    z = Act(y, ss, relu, tab)
     if not want_tape:
         return z, None
     t = Tape()
@@ -731,7 +772,7 @@ def convd_fwd(blk, x, training, want_tape=True):
     t = Tape()
     x = as_act(x)
     t.x = x
-    h = x if blk.first else Act(ops.maxpool2_fwd(x.t, x.pro, x.relu))
+    h = x if blk.first else Act(ops.maxpool2_fwd(x.t, x.pro, x.relu), amax=x.amax)      # (a pooled tensor is bounded like its source)
     a, t.c1 = convbn_fwd(blk.conv1, blk.bn1, h, None, False, training, want_tape)
     b, t.c2 = convbn_fwd(blk.conv2, blk.bn2, a, None, True, training, want_tape)
     c, t.c3 = convbn_fwd(blk.conv3, blk.bn3, b, None, True, training, want_tape)
@@ -774,7 +815,7 @@ CONVU_CONV_FIRST = os.environ.get("WTPSE_CONVU_REFERENCE_ORDER", "0") != "1"    
 
 def upbn_fwd(conv, bn, a0, training, want_tape=True):
     root = conv._root
-    z, _ = _conv(conv, a0, None, False, False)                 # low resolution, pre-BatchNorm
+    z, _ = _conv(conv, a0, None, False, False, want_amax=not training)      # low resolution, pre-BatchNorm
     if training:
         y, stats = ops.upsample2x_fwd_stats(z)
         B, _, H, W = y.shape
@@ -782,13 +823,16 @@ def upbn_fwd(conv, bn, a0, training, want_tape=True):
             stats, count = root._dp.sync_bn_stats(stats, B * H * W)
         else:
             count = B * H * W
+        tab = ops.fwd_amax_table(y.device)
         ss, mean, invstd = ops.bn_finalize(stats, count, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                           bn.num_batches_tracked)
+                                           bn.num_batches_tracked, act_amax=tab)
     else:
         y = ops.upsample2x_fwd(z)
         ss = ops.bn_eval_coeffs(bn.weight, bn.bias, bn.running_mean, bn.running_var)
+        # (bilinear interpolation is a convex combination: the upsampled map is bounded by the amax of the low-resolution one)
+        tab = ops.act_bound(ss, z.wt_amax) if getattr(z, "wt_amax", None) is not None else None
         mean = invstd = None
-    out = Act(y, ss, True)
+    out = Act(y, ss, True, tab)
     if not want_tape:
         return out, None
     t = Tape()
@@ -818,7 +862,7 @@ def convu_fwd(blk, x, prev, training, want_tape=True):
     if t.swapped:
         y, t.c2 = upbn_fwd(blk.conv2, blk.bn2, x, training, want_tape)
     else:                                                        # odd widths: the reference order
-        u = ops.upsample2x_fwd(x.t, x.pro, x.relu)
+        u = Act(ops.upsample2x_fwd(x.t, x.pro, x.relu), amax=x.amax)
         y, t.c2 = convbn_fwd(blk.conv2, blk.bn2, u, None, True, training, want_tape)
     out, t.c3 = convbn_fwd(blk.conv3, blk.bn3, prev, y, True, training, want_tape)
     return out, t
@@ -942,11 +986,12 @@ WT_FUSED_GRAM = os.environ.get("WTPSE_WT_FUSED_GRAM", "1") != "0"
 def _conv_gram(layer, a0):
     """3x3, 16 output channels, no BatchNorm: -> (z, (partial Grams, S))."""
     a0 = as_act(a0)
+    out_amax = ops.fwd_amax_table(a0.t.device)       # z1 / z2 reach their x2h consumers as stored
     if layer.x16f_off >= 0:
         y, _, g = ops.conv16_x3(a0.t, layer._root.x3_ptr(layer.x16f_off), layer.bias, 16, a0.pro, _relu_bits(a0, None), False,
-                                want_gram=True)
+                                want_gram=True, in_amax=act_amax(a0), out_amax=out_amax)
         return y, g
-    return ops.conv_fwd_gram(a0.t, layer._root.packed_ptr(layer.wf_off), layer.bias, a0.pro, _relu_bits(a0, None), False)
+    return ops.conv_fwd_gram(a0.t, layer._root.packed_ptr(layer.wf_off), layer.bias, a0.pro, _relu_bits(a0, None), False, out_amax)
 
 
 def deepwt_fwd(wt, x, want_tape=True, want_gram=False):
@@ -956,16 +1001,17 @@ def deepwt_fwd(wt, x, want_tape=True, want_gram=False):
     t.x = x
     t.g1 = t.g2 = None
     fused = want_gram and WT_FUSED_GRAM and a[2].cout == 16 and a[2].k == 3 and b[2].cout == 16
-    t.h1, _ = _conv(a[0], x, None, True)
+    # (no BatchNorm anywhere in DeepWT: every map carries the amax of its stored data to its x2h consumers)
+    t.h1, _ = _conv(a[0], x, None, True, want_amax=True)
     if fused:
         t.z1, t.g1 = _conv_gram(a[2], t.h1)
     else:
-        t.z1, _ = _conv(a[2], t.h1)
-    t.h2, _ = _conv(b[0], Act(t.z1, None, True), None, True)     # ReLU(z1) on load
+        t.z1, _ = _conv(a[2], t.h1, want_amax=True)
+    t.h2, _ = _conv(b[0], Act(t.z1, None, True), None, True, want_amax=True)     # ReLU(z1) on load
     if fused:
         t.z2, t.g2 = _conv_gram(b[2], t.h2)
     else:
-        t.z2, _ = _conv(b[2], t.h2)
+        t.z2, _ = _conv(b[2], t.h2, want_amax=True)
     return t
 
 
@@ -992,7 +1038,7 @@ def teacher_fwd(tn, feat, mask, training, want_logvar=True, want_tape=True):
     m1, t.i0 = convbn_fwd(inc[0], inc[1], mask, None, True, training, want_tape)
     m2, t.i3 = convbn_fwd(inc[3], inc[4], m1, None, True, training, want_tape)
     t.m2, t.feat = m2, feat
-    t.xf, _ = _conv(tn.fusion[0], m2, feat, True)
+    t.xf, _ = _conv(tn.fusion[0], m2, feat, True, want_amax=True)
     fmap, t.unet = unet_fwd(tn, t.xf, training, want_tape)
     t.mu, t.hmu = head_fwd(tn.mu_prior, fmap, (0, 2, 4), want_tape)
     if want_logvar:

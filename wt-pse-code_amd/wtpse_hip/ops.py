@@ -43,8 +43,9 @@ def workspace(tag, nfloats, device):
 
 # ----------------------------------------------------------------------------------------------- convolution
 def conv_fwd(in0, in1, wpacked_ptr, bias, cout, ksize, pro0=None, pro_relu=0, relu_out=False, want_stats=False,
-             split=None, mask_ref=None, pro1=None):
-    """-> (out0, out1 or None, stats or None).  `wpacked_ptr` is a raw device pointer into the packed-weight buffer."""
+             split=None, mask_ref=None, pro1=None, out_amax=None):
+    """-> (out0, out1 or None, stats or None).  `wpacked_ptr` is a raw device pointer into the packed-weight buffer.
+    out_amax: a zeroed amax table (fwd_amax_table) that receives the largest magnitude of the stored output."""
     _chk(in0, "in0"); _chk(in1, "in1"); _chk(pro0, "pro0"); _chk(pro1, "pro1")
     B, C0, H, W = in0.shape
     C1 = 0 if in1 is None else in1.shape[1]
@@ -62,11 +63,13 @@ def conv_fwd(in0, in1, wpacked_ptr, bias, cout, ksize, pro0=None, pro_relu=0, re
         nblk = L.query("wtpse_conv_stats_blocks", B, H, W)
         stats = torch.empty((nblk, cout, 2), dtype=torch.float32, device=in0.device)
     L.call("wtpse_conv_fwd", ptr(in0), C0, ptr(in1), C1, wpacked_ptr, ptr(bias), ptr(pro0), ptr(pro1), int(pro_relu), ptr(out0),
-           ptr(out1), csplit, ptr(stats), B, H, W, cout, ksize, int(relu_out), ptr(mask_ref), stream_ptr())
+           ptr(out1), csplit, ptr(stats), B, H, W, cout, ksize, int(relu_out), ptr(mask_ref), ptr(out_amax), stream_ptr())
+    if out_amax is not None:
+        out0.wt_amax = out_amax
     return out0, out1, stats
 
 
-def conv_fwd_gram(in0, wpacked_ptr, bias, pro0=None, pro_relu=0, relu_out=False):
+def conv_fwd_gram(in0, wpacked_ptr, bias, pro0=None, pro_relu=0, relu_out=False, out_amax=None):
     """3x3 conv with 16 output channels that also returns the per-tile partial Grams of its output.
     -> (out, (partial [B*S,256], S)) with S = tiles per image: what wt_loss_fwd(..., gram_partial=) takes."""
     _chk(in0, "in0"); _chk(pro0, "pro0")
@@ -76,7 +79,9 @@ def conv_fwd_gram(in0, wpacked_ptr, bias, pro0=None, pro_relu=0, relu_out=False)
     nblk = L.query("wtpse_conv_stats_blocks", B, H, W)
     partial = torch.empty((nblk, 256), dtype=torch.float32, device=in0.device)
     L.call("wtpse_conv_fwd_gram", ptr(in0), C0, wpacked_ptr, ptr(bias), ptr(pro0), int(pro_relu), ptr(out), ptr(partial), B, H, W,
-           16, int(relu_out), stream_ptr())
+           16, int(relu_out), ptr(out_amax), stream_ptr())
+    if out_amax is not None:
+        out.wt_amax = out_amax
     return out, (partial, nblk // B)
 
 
@@ -84,11 +89,11 @@ X16_SIZE = 8 + 5 * 3 * 64 * 8 + 5 * 2 * 64 * 8      # unsigned shorts of one dir
 
 
 def conv16_x3(in0, wx16_ptr, bias, cout, pro0=None, pro_relu=0, relu_out=False, want_stats=False, want_gram=False, mask_ref=None,
-              bnb=None, grad_in=False):
+              bnb=None, grad_in=False, in_amax=None, out_amax=None):
     """3x3 conv with at most 16 input and 16 output channels in the x3 / x2h arithmetic (csrc/conv.hip MODE 3 / 4; include/wtpse_hip.h,
     wtpse_conv16_x3).  bnb = (bn_y, bn_ss, bn_mean, bn_relu): the BatchNorm-backward epilogue of dgrad_bnb.  grad_in: in0 is a
     gradient (a data-gradient launch): x2h only with the amax table its producer attached (`in0.wt_amax`), x3 otherwise — never an
-    extra pass for it.
+    extra pass for it.  in_amax (forward launches): the bound of the input as loaded; out_amax: as conv_fwd.
     -> (out, stats or None, (gram partial, tiles per image) or None)."""
     _chk(in0, "in0"); _chk(pro0, "pro0"); _chk(mask_ref, "mask_ref")
     B, C0, H, W = in0.shape
@@ -105,7 +110,9 @@ def conv16_x3(in0, wx16_ptr, bias, cout, pro0=None, pro_relu=0, relu_out=False, 
         assert mask_ref.shape == out.shape
     L.call("wtpse_conv16_x3", ptr(in0), C0, wx16_ptr, ptr(bias), ptr(pro0), int(pro_relu), ptr(out), ptr(stats), ptr(gram),
            ptr(mask_ref), ptr(bn_ss), ptr(bn_mean), int(bool(bn_relu)), B, H, W, cout, int(relu_out), int(bool(grad_in)),
-           ptr(getattr(in0, "wt_amax", None)) if grad_in else 0, stream_ptr())
+           ptr(getattr(in0, "wt_amax", None)) if grad_in else ptr(in_amax), ptr(out_amax), stream_ptr())
+    if out_amax is not None:
+        out.wt_amax = out_amax
     return out, stats, ((gram, nblk // B) if want_gram else None)
 
 
@@ -125,19 +132,22 @@ _AMAX_TABLES = 512          # tables per arena (2 MB): a backward pass of the la
 
 
 def amax_begin(device):
-    """Start of a backward pass: every amax table of the device's arena is zero again and free.  ONE launch over the WHOLE arena,
+    """Start of a backward pass: a fresh arena of zeroed amax tables for the gradients it produces.  ONE launch zeroes the WHOLE arena,
     unconditionally — the call is part of recorded launch plans / captured graphs, so what it zeroes must not depend on how many
-    tables the pass before it happened to use when the step was recorded (a conditional, sized zeroing left the replayed steps
-    with the tables of earlier steps: scales that only ever grew, results that differed from the eager step in the last bits).
-    The producers of a pass (bn_bwd_*, upsample2x_bwd*) take their tables with _amax_table(); they stay valid until the next
-    amax_begin on the device — HipNet.begin_backward() calls it on the stream the previous pass's consumers were joined into."""
+    tables the pass before it happened to use when the step was recorded (a conditional, sized zeroing left the replayed steps with
+    the tables of earlier steps: scales that only ever grew, results that differed from the eager step in the last bits).
+    Round 6: the arena is a buffer of the PASS, not of the device — rounds 5's one arena per device was zeroed wholesale
+    by whichever network began a backward pass next, under the feet of a pass of another network still in flight.  The producers of a
+    pass (bn_bwd_*, upsample2x_bwd*) take their tables with _amax_table(); the tables (views, attached to the gradients as
+    `wt_amax`) keep their arena alive, and the last few arenas are held a little longer for work still queued on side streams."""
     st = _AMAX.get(device)
+    buf = zero_(torch.empty(_AMAX_TABLES * AMAX_WORDS, dtype=torch.int32, device=device))     # (2 MB, ~2 us; recorded steps: from the capture's pool)
     if st is None:
-        if torch.cuda.is_current_stream_capturing():
-            raise RuntimeError("the amax arena must exist before a step is captured: HipNet.ensure_ready() creates it")
-        st = _AMAX[device] = [torch.empty(_AMAX_TABLES * AMAX_WORDS, dtype=torch.int32, device=device), 0]
-    zero_(st[0])           # (whatever the arithmetic: 2 MB, ~2 us — a table handed out is zero, always)
-    st[1] = 0
+        st = _AMAX[device] = [buf, 0, []]
+    else:
+        st[2].append(st[0])
+        del st[2][:-3]
+        st[0], st[1] = buf, 0
 
 
 def _amax_table(device):
@@ -146,18 +156,63 @@ def _amax_table(device):
         return None
     st = _AMAX.get(device)
     if st is None or st[1] >= _AMAX_TABLES:        # no arena yet / exhausted (micro-benchmarks looping without begin_backward)
-        if torch.cuda.is_current_stream_capturing():
-            raise RuntimeError("amax arena exhausted inside a captured step")
-        return torch.zeros(AMAX_WORDS, dtype=torch.int32, device=device)
+        return zero_(torch.empty(AMAX_WORDS, dtype=torch.int32, device=device))
     t = st[0][st[1] * AMAX_WORDS:(st[1] + 1) * AMAX_WORDS]
     st[1] += 1
     return t
 
 
+_FWD_SCOPES = []
+FWD_SCOPE_TABLES = 256      # per forward pass (1 MB): a WT_PSE.update hands out ~60, an eval-mode predict ~170
+
+
+class fwd_scope:
+    """The amax tables of ONE forward pass (an update() / predict() call): forward activations carry a bound of their largest
+    magnitude to their x2h consumers in tables like the gradients' (include/wtpse_hip.h, wtpse_x3_terms), and those tables must be zero
+    when their producer runs.  A scope owns one buffer, zeroed by ONE launch when the pass starts (on the stream the pass starts on,
+    in front of every fork), and hands out slices; the slices (held by the activations on the tape) keep the buffer alive until the
+    backward pass is done with them.  Recorded steps: the buffer comes from the capture's pool and the zeroing is a recorded launch.
+    Without a scope (block-level callers, tests) a table is a fresh zeroed tensor of its own."""
+
+    def __init__(self, device):
+        self.buf = None
+        if x3_terms() == 2:
+            self.buf = zero_(torch.empty(FWD_SCOPE_TABLES * AMAX_WORDS, dtype=torch.int32, device=device))
+        self.next = 0
+
+    def __enter__(self):
+        _FWD_SCOPES.append(self)
+        return self
+
+    def __exit__(self, *exc):
+        assert _FWD_SCOPES and _FWD_SCOPES[-1] is self
+        _FWD_SCOPES.pop()
+        return False
+
+
+def fwd_amax_table(device):
+    """A zeroed amax table for the producer of a forward activation, or None when the x2h arithmetic is off (nobody would read it)."""
+    if x3_terms() != 2:
+        return None
+    sc = _FWD_SCOPES[-1] if _FWD_SCOPES else None
+    if sc is None or sc.buf is None or sc.buf.device != device or sc.next >= FWD_SCOPE_TABLES:
+        return zero_(torch.empty(AMAX_WORDS, dtype=torch.int32, device=device))
+    t = sc.buf[sc.next * AMAX_WORDS:(sc.next + 1) * AMAX_WORDS]
+    sc.next += 1
+    return t
+
+
+def act_bound(ss, raw_amax):
+    """Amax table of |ss[c,0] * y + ss[c,1]| over a tensor y whose amax table is raw_amax (include/wtpse_hip.h, wtpse_act_bound)."""
+    tab = torch.empty(AMAX_WORDS, dtype=torch.int32, device=ss.device)
+    lib().call("wtpse_act_bound", ptr(ss), ss.shape[0], ptr(raw_amax), ptr(tab), stream_ptr())
+    return tab
+
+
 def amax_of(t):
-    """The amax table (int32 tensor [256]) of the GRADIENT tensor t: the scale source of a gradient operand of the x2h kernels.
-    Producers that fill it as they write t (bn_bwd_*, upsample2x_bwd*) attach it to their result as `t.wt_amax`; anything else pays
-    one extra pass here (and keeps the table on the tensor for its other consumer)."""
+    """The amax table (int32 tensor [AMAX_WORDS]) of the tensor t as stored: the scale source of an operand of the x2h kernels.
+    Producers that fill it as they write t (bn_bwd_*, upsample2x_bwd*; the convolutions' epilogues for un-normalised forward maps) attach
+    it to their result as `t.wt_amax`; anything else pays one extra pass here (and keeps the table on the tensor for its other consumers)."""
     tab = getattr(t, "wt_amax", None)
     if tab is None:
         tab = torch.empty(AMAX_WORDS, dtype=torch.int32, device=t.device)
@@ -167,9 +222,10 @@ def amax_of(t):
 
 
 def conv_fwd_x3(in0, in1, wpacked_ptr, bias, cout, ksize, pro0=None, pro_relu=0, relu_out=False, want_stats=False,
-                split=None, mask_ref=None, pro1=None, in_amax=None):
+                split=None, mask_ref=None, pro1=None, in_amax=None, in_amax1=None, out_amax=None):
     """conv_fwd on the 16-bit matrix cores at fp32 accuracy (csrc/conv_x3.hip); `wpacked_ptr` points into the x3-packed weights.
-    in_amax: amax_of(in0) when in0 is a gradient (a data gradient launch) — include/wtpse_hip.h, wtpse_x3_terms."""
+    in_amax / in_amax1: the amax tables of in0 / in1 AS LOADED (a gradient's amax_of; a forward activation's bound, nn.act_amax) —
+    include/wtpse_hip.h, wtpse_x3_terms; out_amax: as conv_fwd."""
     _chk(in0, "in0"); _chk(in1, "in1"); _chk(pro0, "pro0"); _chk(pro1, "pro1")
     B, C0, H, W = in0.shape
     C1 = 0 if in1 is None else in1.shape[1]
@@ -187,7 +243,10 @@ def conv_fwd_x3(in0, in1, wpacked_ptr, bias, cout, ksize, pro0=None, pro_relu=0,
         nblk = L.query("wtpse_conv_x3_stats_blocks", B, H, W, cout, int(ksize))
         stats = torch.empty((nblk, cout, 2), dtype=torch.float32, device=in0.device)
     L.call("wtpse_conv_fwd_x3", ptr(in0), C0, ptr(in1), C1, wpacked_ptr, ptr(bias), ptr(pro0), ptr(pro1), int(pro_relu), ptr(out0),
-           ptr(out1), csplit, ptr(stats), B, H, W, cout, ksize, int(relu_out), ptr(mask_ref), ptr(in_amax), stream_ptr())
+           ptr(out1), csplit, ptr(stats), B, H, W, cout, ksize, int(relu_out), ptr(mask_ref), ptr(in_amax), ptr(in_amax1),
+           ptr(out_amax), stream_ptr())
+    if out_amax is not None:
+        out0.wt_amax = out_amax
     return out0, out1, stats
 
 
@@ -298,7 +357,7 @@ def dgrad_bnb(dy, wpacked_ptr, layout, cout, ksize, bn_y, bn_ss, bn_mean, bn_rel
         return out0, out1, stats, coef
     if layout == 2:
         L.call("wtpse_conv16_x3", ptr(dy), C, wpacked_ptr, 0, 0, 0, ptr(out0), ptr(stats), 0, ptr(bn_y), ptr(bn_ss), ptr(bn_mean),
-               int(bool(bn_relu)), B, H, W, cout, 0, 1, ptr(in_amax), stream_ptr())
+               int(bool(bn_relu)), B, H, W, cout, 0, 1, ptr(in_amax), 0, stream_ptr())
     elif layout == 1:
         L.call("wtpse_dgrad_x3_bnb", ptr(dy), C, wpacked_ptr, ptr(out0), ptr(out1), csplit, ptr(bn_y), ptr(bn_ss), ptr(bn_mean),
                int(bool(bn_relu)), c0, c1, ptr(stats), B, H, W, cout, ksize, ptr(in_amax), stream_ptr())
@@ -345,9 +404,10 @@ def wgrad_r_supported(cin, cout, ksize, c0, w):
     return bool(lib().query("wtpse_wgrad_r_supported", int(cin), int(cout), int(ksize), int(c0), int(w)))
 
 
-def conv_wgrad_r(dy, x0, x1, dw, dbias=None, pro0=None, pro_relu=0, accumulate=False, pro1=None, dy_amax=None):
+def conv_wgrad_r(dy, x0, x1, dw, dbias=None, pro0=None, pro_relu=0, accumulate=False, pro1=None, dy_amax=None, x_amax0=None,
+                 x_amax1=None):
     """3x3 conv_wgrad in the x3 arithmetic with register-resident operands (csrc/wgrad_r.hip); with bias gradient.
-    dy_amax: amax_of(dy) (x2h: the scale of the gradient operand)."""
+    dy_amax: amax_of(dy) (x2h: the scale of the gradient operand); x_amax0 / x_amax1: the bounds of x0 / x1 as loaded."""
     _chk(dy, "dy"); _chk(x0, "x0"); _chk(x1, "x1")
     B, cout, H, W = dy.shape
     C0 = x0.shape[1]
@@ -358,7 +418,7 @@ def conv_wgrad_r(dy, x0, x1, dw, dbias=None, pro0=None, pro_relu=0, accumulate=F
     slab = workspace("wgrad_slab", ns * cout * cin * 9, dy.device)
     dbs = workspace("wgrad_dbias", ns * cout, dy.device) if dbias is not None else None
     L.call("wtpse_conv_wgrad_r", ptr(dy), ptr(x0), C0, ptr(x1), C1, ptr(pro0), ptr(pro1), int(pro_relu), ptr(slab), ptr(dbs), ns,
-           ptr(dw), ptr(dbias), int(accumulate), B, H, W, cout, ptr(dy_amax), stream_ptr())
+           ptr(dw), ptr(dbias), int(accumulate), B, H, W, cout, ptr(dy_amax), ptr(x_amax0), ptr(x_amax1), stream_ptr())
 
 
 def conv_wgrad_r_bn(g, bn_y, coef, x0, x1, dw, pro0=None, pro_relu=0, accumulate=False, pro1=None):
@@ -377,9 +437,10 @@ def conv_wgrad_r_bn(g, bn_y, coef, x0, x1, dw, pro0=None, pro_relu=0, accumulate
 
 # ----------------------------------------------------------------------------------------------- batch norm
 def conv_fwd_bnf(in0, in1, wpacked_ptr, layout, bias, cout, ksize, pro0, pro_relu, pro1, gamma, beta, rmean, rvar, nbt,
-                 momentum=0.1, eps=1e-5):
+                 momentum=0.1, eps=1e-5, in_amax0=None, in_amax1=None, act_amax=None):
     """Forward convolution in front of a train-mode BatchNorm, statistics finished by the same launch (include/wtpse_hip.h,
-    wtpse_conv_fwd_bnf).  layout 0 fp32, 1 x3, 2 the 16-channel x3 fragments.  -> (y, ss [C,2], mean, invstd)."""
+    wtpse_conv_fwd_bnf).  layout 0 fp32, 1 x3, 2 the 16-channel x3 fragments.  in_amax0 / in_amax1: the bounds of the inputs as
+    loaded; act_amax: a zeroed table that receives the bound of the BatchNorm's output.  -> (y, ss [C,2], mean, invstd)."""
     _chk(in0, "in0"); _chk(in1, "in1"); _chk(pro0, "pro0"); _chk(pro1, "pro1")
     layout = int(layout)
     B, C0, H, W = in0.shape
@@ -396,18 +457,19 @@ def conv_fwd_bnf(in0, in1, wpacked_ptr, layout, bias, cout, ksize, pro0, pro_rel
     tickets, tview = _tickets(L.query("wtpse_bnb_tail_tickets", nblk, cout), dev)
     _ticket_call(tview, "wtpse_conv_fwd_bnf", ptr(in0), C0, ptr(in1), C1, wpacked_ptr, layout, ptr(bias), ptr(pro0), ptr(pro1), int(pro_relu),
            ptr(out), ptr(stats), ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), ptr(nbt), float(momentum), float(eps), ptr(ss),
-           ptr(mean), ptr(invstd), ptr(partial2), tickets, B, H, W, cout, ksize, stream_ptr())
+           ptr(mean), ptr(invstd), ptr(partial2), tickets, B, H, W, cout, ksize, ptr(in_amax0), ptr(in_amax1), ptr(act_amax),
+           stream_ptr())
     return out, ss, mean, invstd
 
 
-def bn_finalize(stats, count, gamma, beta, rmean, rvar, nbt, momentum=0.1, eps=1e-5):
+def bn_finalize(stats, count, gamma, beta, rmean, rvar, nbt, momentum=0.1, eps=1e-5, act_amax=None):
     nblk, C, _ = stats.shape
     dev = stats.device
     ss = torch.empty((C, 2), dtype=torch.float32, device=dev)
     mean = torch.empty((C,), dtype=torch.float32, device=dev)
     invstd = torch.empty((C,), dtype=torch.float32, device=dev)
     lib().call("wtpse_bn_finalize", ptr(stats), nblk, C, int(count), ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar),
-               ptr(nbt), float(momentum), float(eps), ptr(ss), ptr(mean), ptr(invstd), stream_ptr())
+               ptr(nbt), float(momentum), float(eps), ptr(ss), ptr(mean), ptr(invstd), ptr(act_amax), stream_ptr())
     return ss, mean, invstd
 
 
@@ -502,6 +564,7 @@ def wt_loss_fwd(z, domain_num, per_domain, margin=0.0, eps=1e-5, losses_out=None
 
 def wt_loss_bwd(st, dz, accumulate, g_off=None, g_diag=None, g_dom=None, w_off=1.0, w_diag=1.0, w_dom=1.0):
     _chk(dz, "dz")
+    _amax_stale(dz)
     Mws = workspace("wt_M", st.B * 256, dz.device)
     lib().call("wtpse_wt_loss_bwd", ptr(st.z), st.B, 16, st.HW, st.margin, st.D, st.n, ptr(st.gram), ptr(st.offdiag),
                ptr(st.diag), ptr(st.dmmd_dv), ptr(g_off), ptr(g_diag), ptr(g_dom), float(w_off), float(w_diag),
@@ -531,6 +594,7 @@ def maxpool2_bwd(x, dout, dx, accumulate, pro=None, relu=False, mask=False):
     if dx is None:
         dx = torch.empty_like(x)
         accumulate = False
+    _amax_stale(dx)
     lib().call("wtpse_maxpool2_bwd", ptr(x), ptr(pro), int(relu), ptr(dout), ptr(dx), int(bool(accumulate)) | (2 if mask else 0),
                B, C, H, W, stream_ptr())
     return dx
@@ -546,6 +610,7 @@ def maxpool2_bwd_bnb(x, dout, dx, pro, relu, mean):
     acc = dx is not None
     if dx is None:
         dx = torch.empty_like(x)
+    _amax_stale(dx)
     stats = torch.empty((L.query("wtpse_maxpool2_bwd_stats_blocks", B, H, W), C, 2), dtype=torch.float32, device=x.device)
     L.call("wtpse_maxpool2_bwd_bnb", ptr(x), ptr(pro), int(relu), ptr(dout), ptr(dx), int(acc), ptr(mean), ptr(stats), B, C, H, W,
            stream_ptr())
@@ -605,11 +670,19 @@ def relu_mask(dz, ref, out=None, accumulate=False):
     if out is None:
         out = torch.empty_like(dz)
         accumulate = False
+    _amax_stale(out)
     lib().call("wtpse_relu_mask", ptr(dz), ptr(ref), ptr(out), int(accumulate), dz.numel(), stream_ptr())
     return out
 
 
+def _amax_stale(t):
+    """t is about to be modified in place: an amax table its producer attached no longer describes it."""
+    if t is not None and getattr(t, "wt_amax", None) is not None:
+        t.wt_amax = None
+
+
 def axpy(dst, src, alpha=1.0):
+    _amax_stale(dst)
     lib().call("wtpse_axpy", ptr(dst), ptr(src), float(alpha), dst.numel(), stream_ptr())
     return dst
 
