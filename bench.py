@@ -24,7 +24,7 @@ import time
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-PKG = os.path.join(ROOT, "wt-pse-code_amd")
+PKG = os.environ.get("WTPSE_PKG_DIR") or os.path.join(ROOT, "wt-pse-code_amd")     # (WTPSE_PKG_DIR: same-box A/B against another build of the package)
 for p in (ROOT, PKG):
     if p not in sys.path:
         sys.path.insert(0, p)

@@ -18,10 +18,20 @@ __global__ __launch_bounds__(256) void bn_finalize_k(const float* __restrict__ p
   __shared__ double shs[2][4];
   const int c = blockIdx.x, t = threadIdx.x;
   double s1 = 0.0, s2 = 0.0;
-  for (int k = t; k < nblk; k += 256) {
-    float2 p2 = *reinterpret_cast<const float2*>(part + ((size_t)k * C + c) * 2);
-    s1 += p2.x;
-    s2 += p2.y;
+  // (eight loads in flight per thread — the same additions in the same order as one at a time: this launch sits between two
+  // convolutions of a dependency chain, 54 times per step, and spent its 9 us waiting for one strided load after another)
+  for (int k0 = t; k0 < nblk; k0 += 256 * 8) {
+    float2 p2[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = k0 + 256 * u;
+      p2[u] = k < nblk ? *reinterpret_cast<const float2*>(part + ((size_t)k * C + c) * 2) : make_float2(0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      s1 += p2[u].x;
+      s2 += p2[u].y;
+    }
   }
   for (int m = 1; m < 64; m <<= 1) {
     s1 += __shfl_xor(s1, m, 64);
@@ -178,10 +188,18 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_k(const float* __restrict
   __shared__ double shs[2][4];
   const int c = blockIdx.x, t = threadIdx.x;
   double s1 = 0.0, s2 = 0.0;
-  for (int k = t; k < nsplit; k += 256) {
-    const float2 p2 = *reinterpret_cast<const float2*>(partial + ((size_t)k * C + c) * 2);
-    s1 += p2.x;
-    s2 += p2.y;
+  for (int k0 = t; k0 < nsplit; k0 += 256 * 8) {      // (eight loads in flight per thread, same order of additions: see bn_finalize_k)
+    float2 p2[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = k0 + 256 * u;
+      p2[u] = k < nsplit ? *reinterpret_cast<const float2*>(partial + ((size_t)k * C + c) * 2) : make_float2(0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      s1 += p2[u].x;
+      s2 += p2[u].y;
+    }
   }
   for (int m = 1; m < 64; m <<= 1) {
     s1 += __shfl_xor(s1, m, 64);

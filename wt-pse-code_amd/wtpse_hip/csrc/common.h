@@ -105,13 +105,28 @@ constexpr float X3_FWD_SCALE = 4.f;     // the fallback input scale of a forward
 // atomics of a launch would queue for milliseconds.
 constexpr int AMAX_SHARDS = 64, AMAX_STRIDE = 16, AMAX_WORDS = AMAX_SHARDS * AMAX_STRIDE;
 __device__ __forceinline__ unsigned amax_bits(float v) { return __builtin_bit_cast(unsigned, v) & 0x7FFFFFFFu; }
+// Maximum over the 64 lanes of a FULL wave, wave-uniform (in a scalar register).  max is idempotent, so four DPP steps that each
+// fold a lane with a partner — xor 1 and xor 2 within a quad (quad_perm), the other quad of an 8-lane half (row_half_mirror), the
+// other half of the 16-lane row (row_mirror) — leave every lane of a row with the row's maximum, and four v_readlane + three s_max
+// finish it: ~12 cheap instructions where the xor butterfly of rounds 1-5 took six ds_bpermute round trips through the LDS crossbar
+// (each behind its own lgkmcnt wait) — in front of EVERY workgroup's first conversion in the x2h kernels, and behind every wave's
+// stores in the producers that publish an amax.
+__device__ __forceinline__ unsigned wave_umax(unsigned v) {
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false));      // quad_perm [1,0,3,2]
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false));      // quad_perm [2,3,0,1]
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false));     // row_half_mirror
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false));     // row_mirror
+  const unsigned r0 = (unsigned)__builtin_amdgcn_readlane((int)v, 0), r1 = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+  const unsigned r2 = (unsigned)__builtin_amdgcn_readlane((int)v, 32), r3 = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+  return max(max(r0, r1), max(r2, r3));
+}
 __device__ __forceinline__ unsigned amax_bits4(f32x4 v) {
   return max(max(amax_bits(v[0]), amax_bits(v[1])), max(amax_bits(v[2]), amax_bits(v[3])));
 }
 // every thread of the workgroup calls (blockDim.x a multiple of 64, at most 1024); m: the thread's own maximum
 __device__ __forceinline__ void amax_publish_block(unsigned* table, unsigned m, unsigned shard_seed) {
   __shared__ unsigned amax_red[16];
-  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+  m = wave_umax(m);
   const int nw = (int)(blockDim.x >> 6);
   if ((threadIdx.x & 63) == 0) amax_red[threadIdx.x >> 6] = m;
   __syncthreads();
@@ -123,7 +138,7 @@ __device__ __forceinline__ void amax_publish_block(unsigned* table, unsigned m, 
 // every lane of a full wave calls (no barrier, no LDS: for streaming kernels that run one small item per workgroup — a persistent,
 // one-atomic-per-workgroup form of the BatchNorm-backward apply pass measured 14-29 % slower than this)
 __device__ __forceinline__ void amax_publish_wave(unsigned* table, unsigned m, unsigned shard_seed) {
-  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+  m = wave_umax(m);
   if ((threadIdx.x & 63) == 0 && m)
     (void)__hip_atomic_fetch_max(table + (shard_seed % AMAX_SHARDS) * AMAX_STRIDE, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -135,8 +150,8 @@ __device__ __forceinline__ unsigned amax_load(const unsigned* table) {
   return table ? table[(threadIdx.x & (AMAX_SHARDS - 1)) * AMAX_STRIDE] : 0u;
 }
 __device__ __forceinline__ unsigned amax_reduce(unsigned v) {
-  for (int o = AMAX_SHARDS / 2; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o, 64));
-  return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+  static_assert(AMAX_SHARDS == 64, "one shard per lane");
+  return wave_umax(v);
 }
 __device__ __forceinline__ unsigned amax_read(const unsigned* table) {
   unsigned v = table[(threadIdx.x & (AMAX_SHARDS - 1)) * AMAX_STRIDE];
@@ -248,34 +263,49 @@ __device__ __forceinline__ TailTicket tail_begin(unsigned* tickets, int ngroups,
 }
 
 // -> true in the ONE workgroup of output-channel block `y` that arrives last; there sh[2 * crel + k] holds the fp64 totals of the
-// block's channels (threads tid < 2 CB: crel = tid >> 1, k = tid & 1).
+// block's channels (threads tid < 2 CB: crel = tid >> 1, k = tid & 1).  sh: 256 doubles of LDS scratch.
+// Round 6: both folds run with ALL their loads in flight at once.  The fold is the tail of the launch's critical path — nothing of
+// the launch is left to hide it behind — and rounds 3-5 walked a group's 64 partials in eight dependent rounds of eight agent-scope
+// loads on 2 CB of the 256 threads (the step-form launches measured 6-7 us longer than the plain ones: tools/probe/instep_gap.py).
+// Now the 256 threads form 256 / (2 CB) groups, each group takes a contiguous share of the 64 tiles (or of the group sums) with one
+// load per tile, all issued before the first is used; the groups' sums meet in LDS and are added in index order: still a fixed order,
+// whoever arrives when.
 template <int CB>
 __device__ __forceinline__ bool tail_fold(const TailTicket& tk, double* partial2, unsigned* tickets, int ngroups, int ntiles, int ctot,
                                           int t2_off, const float* stats, int c_lo, int c_hi, int cout0, int tile, int y, int tid,
                                           double* sh, int* flag_s) {
-  static_assert(CB * 2 <= 256, "one thread per (channel, sum)");
+  static_assert(CB * 2 <= 256 && 256 % (CB * 2) == 0, "one thread per (channel, sum) and share of the tiles");
+  constexpr int NP = 2 * CB;          // (channel, sum) pairs of the block
+  constexpr int NQ = 256 / NP;        // thread groups
+  constexpr int TPQ = 64 / NQ;        // tiles of a group of 64 per thread group
   const int Cst = c_hi - c_lo;
   const int grp = tile >> 6, g0 = grp << 6;
   const int gsize = min(64, ntiles - g0);
   if (tid == 0) *flag_s = tk.old == (unsigned)(gsize - 1);
   __syncthreads();
   if (!*flag_s) return false;
-  const int crel = tid >> 1, k = tid & 1, c = cout0 + crel;
-  const bool mine = tid < CB * 2 && c >= c_lo && c < c_hi;
+  const int pr = tid % NP, q = tid / NP;
+  const int crel = pr >> 1, k = pr & 1, c = cout0 + crel;
+  const bool mine = c >= c_lo && c < c_hi;
   {
     double s = 0.0;
     if (mine) {
       const float* p = stats + ((size_t)g0 * Cst + (c - c_lo)) * 2 + k;
-      int i = 0;
-      for (; i + 8 <= gsize; i += 8) {
-        float v[8];
+      // (unconditional loads at a clamped index, the tail of a short group dropped afterwards: a load inside a conditional comes
+      // out as a branch with its own s_waitcnt vmcnt(0) — 32 serialised round trips, measured slower than rounds 3-5's eight)
+      float v[TPQ];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = pub_load(p + (size_t)(i + u) * Cst * 2);
+      for (int u = 0; u < TPQ; ++u) v[u] = pub_load(p + (size_t)min(q * TPQ + u, gsize - 1) * Cst * 2);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) s += (double)v[u];
-      }
-      for (; i < gsize; ++i) s += (double)pub_load(p + (size_t)i * Cst * 2);
-      pub_store(partial2 + ((size_t)grp * ctot + c) * 2 + k, s);
+      for (int u = 0; u < TPQ; ++u) s += (q * TPQ + u < gsize) ? (double)v[u] : 0.0;
+    }
+    sh[q * NP + pr] = s;
+    __syncthreads();
+    if (q == 0 && mine) {
+      double t = sh[pr];
+#pragma unroll
+      for (int qq = 1; qq < NQ; ++qq) t += sh[qq * NP + pr];
+      pub_store(partial2 + ((size_t)grp * ctot + c) * 2 + k, t);
     }
     if (tid == 0) __hip_atomic_store(tickets + (size_t)y * ngroups + grp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -290,17 +320,26 @@ __device__ __forceinline__ bool tail_fold(const TailTicket& tk, double* partial2
   double s = 0.0;
   if (mine) {
     const double* p = partial2 + (size_t)c * 2 + k;
-    int i = 0;
-    for (; i + 8 <= ngroups; i += 8) {
+    const int per = (ngroups + NQ - 1) / NQ, i0 = q * per, i1 = min(ngroups, i0 + per);       // a contiguous share of the group sums
+    int i = i0;
+    for (; i + 8 <= i1; i += 8) {
       double v[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) v[u] = pub_load(p + (size_t)(i + u) * ctot * 2);
 #pragma unroll
       for (int u = 0; u < 8; ++u) s += v[u];
     }
-    for (; i < ngroups; ++i) s += pub_load(p + (size_t)i * ctot * 2);
+    for (; i < i1; ++i) s += pub_load(p + (size_t)i * ctot * 2);
   }
-  if (tid < CB * 2) sh[tid] = s;
+  __syncthreads();            // (every group is done reading the first fold's sh)
+  sh[q * NP + pr] = s;
+  __syncthreads();
+  if (q == 0) {
+    double t = sh[pr];
+#pragma unroll
+    for (int qq = 1; qq < NQ; ++qq) t += sh[qq * NP + pr];
+    sh[pr] = t;
+  }
   if (tid == 0) __hip_atomic_store(tickets + t2_off + y, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   return true;

@@ -649,10 +649,10 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
       }
     if constexpr (BNB)
       bnb_tail<CB>(tk, a.tail, a.stats, a.bn_mean, a.bn_c0, a.bn_c1, cout0, tile, cblk, tid,
-                   reinterpret_cast<double*>(red), reinterpret_cast<int*>(red + 4 * CB));
+                   reinterpret_cast<double*>(red), reinterpret_cast<int*>(red + 520));
     else
       bnf_tail<CB>(tk, a.ftail, a.stats, a.Cout, cout0, tile, cblk, tid, reinterpret_cast<double*>(red),
-                   reinterpret_cast<int*>(red + 4 * CB));
+                   reinterpret_cast<int*>(red + 520));
   }
 }
 

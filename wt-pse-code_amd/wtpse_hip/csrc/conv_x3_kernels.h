@@ -385,10 +385,10 @@ __device__ __forceinline__ void x3_epilogue(const ConvX3Args& a, f32x16 (&acc)[M
       }
     if constexpr (BNB)
       bnb_tail<CB>(tk, a.tail, a.stats, a.bn_mean, a.bn_c0, a.bn_c1, cout0, stats_row, cblk, tid,
-                   reinterpret_cast<double*>(red), reinterpret_cast<int*>(red + 4 * CB));
+                   reinterpret_cast<double*>(red), reinterpret_cast<int*>(red + 520));
     else
       bnf_tail<CB>(tk, a.ftail, a.stats, a.Cout, cout0, stats_row, cblk, tid, reinterpret_cast<double*>(red),
-                   reinterpret_cast<int*>(red + 4 * CB));
+                   reinterpret_cast<int*>(red + 520));
   }
 }
 
@@ -752,7 +752,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3r_k(ConvX3Args a) {
   constexpr int XS_U4 = 2 * TERMS * PEP;           // 16-byte slots of one input image
   constexpr int MAIN_U4 = 2 * XS_U4;
   constexpr int PRO_MAX = 512;
-  static_assert(MAIN_U4 * 4 >= PW * CB * 2 + 4 * CB + 4, "epilogue scratch aliases the operand images");
+  static_assert(MAIN_U4 * 4 >= PW * CB * 2 + 4 * CB + 4 && MAIN_U4 * 4 >= 524, "epilogue scratch (statistics, the tails' 256 doubles + flag) aliases the operand images");
   constexpr int DUMP_U4 = MAIN_U4 + CB / 4 + (EPI == 2 ? CB : 0);
   __shared__ u32x4v smem[DUMP_U4 + 64];
   __shared__ float2 pro_s[PRO_MAX];
