@@ -71,8 +71,9 @@ def parse():
     ap.add_argument("--cpu-baseline-full", action="store_true",
                     help="SURVEY.md 8d protocol in full: 3 warm-up + 10 timed iterations at B=6 and B=30 (minutes of CPU time)")
     ap.add_argument("--cpu-threads", type=int, default=0,
-                    help="threads of the CPU baseline; 0 (default) = min(CPUs granted to this process, physical cores of the host) "
-                         "(SURVEY.md 8d: all physical cores); profiles/r06_cpu_baseline_full.json holds 16 threads beside all cores")
+                    help="threads of the CPU baseline; 0 (default) = min(CPUs in the affinity mask, physical cores of the host, the cgroup's "
+                         "CPU-time quota) (SURVEY.md 8d: all physical cores the process may use); profiles/r06_cpu_baseline_threads.json: "
+                         "16 threads beside 128 on a box with a 16-core quota")
     ap.add_argument("--roi-presteps", type=int, default=70,
                     help="untimed set-up steps that train the optic-disc net so that its prediction (the ROI of calls C/D) is no "
                          "longer empty: a FIXED count (default 70: od_pred then covers ~21 %% of the pixels of the seed-1 batch; "
@@ -175,11 +176,19 @@ def seg_gflop_per_image(H):
 
 
 def unet_layer_rooflines(B, H, dev):
-    """Every convolution of one U-Net, launched through the step's own dispatch (nn._conv / _dgrad / _wgrad: BatchNorm+ReLU prologue
-    on the inputs, bias + BatchNorm partials forward, split output of the concat layers' data gradient), HIP events.  -> per-layer rows
-    and, for the layers that run in the x3 arithmetic (the MFMA-bound ones), the FLOP-WEIGHTED rate over ALL of them per direction —
-    not the four friendliest layers."""
+    """Every convolution of one U-Net, launched AS THE STEP LAUNCHES IT (round 6): forward with the BatchNorm+ReLU
+    prologue on the inputs, bias and the BatchNorm statistics of the output finished in the launch (nn.convbn_fwd; the 1x1 convs in
+    front of the upsampling: plain, their statistics come from the upsampling kernel); data gradient with the BatchNorm-backward
+    epilogue of the layer below — mask load of its raw output, the two reductions, the coefficient fold (nn._dgrad(below=); the first
+    convolution of a ConvD block feeds the max-pool backward: plain) —; weight gradient through nn._wgrad.  HIP events, operands
+    rotating through two sets (cold: inside a step no launch finds its operands in the Infinity Cache either).  Rounds 1-5 timed the
+    PLAIN launches here (no statistics fold, no BatchNorm-backward epilogue): 16 % / 32 % less work per forward / data-gradient launch
+    (tools/probe/instep_gap.py) — that, not clocks or cold operands (3-6 %), was the 19 % between the isolated and the in-step rate of
+    the family.  The plain timings stay in the rows (`*_plain_ms`).
+    -> per-layer rows and, for the layers on the x3 kernels (the MFMA-bound ones), the FLOP-WEIGHTED rate over ALL of them per
+    direction — not the four friendliest layers."""
     from wtpse_hip import nn as E
+    from wtpse_hip import ops
     rows = []
     for c0, c1, co, div, k, name in UNET_LAYERS:
         Hc = H // div
@@ -188,17 +197,33 @@ def unet_layer_rooflines(B, H, dev):
         class Holder(E.HipNet):
             def __init__(self):
                 super().__init__()
-                self.conv = E.ConvP(cin, co, k)
+                self.conv, self.bn = E.ConvP(cin, co, k), E.BNP(co)
+                self.bn_below = E.BNP(c1 if c1 else cin)
                 self._finish_init()
         net = Holder().to(dev)
+        net.train()
         net.ensure_ready(repack=True)
         layer = net.conv
-        x0 = torch.randn(B, c0, Hc, Hc, device=dev)
-        x1 = torch.randn(B, c1, Hc, Hc, device=dev) if c1 else None
         pro = c0 > 4
-        a0 = E.Act(x0, torch.rand(c0, 2, device=dev) + 0.5, True) if pro else E.Act(x0)
-        a1 = (E.Act(x1, torch.rand(c1, 2, device=dev) + 0.5, True) if c1 else None)
-        dy = torch.randn(B, co, Hc, Hc, device=dev)
+        sets = []
+        for i in range(2):
+            x0 = torch.randn(B, c0, Hc, Hc, device=dev)
+            x1 = torch.randn(B, c1, Hc, Hc, device=dev) if c1 else None
+            a0 = E.Act(x0, torch.rand(c0, 2, device=dev) + 0.5, True) if pro else E.Act(x0)
+            a1 = (E.Act(x1, torch.rand(c1, 2, device=dev) + 0.5, True) if c1 else None)
+            dy = torch.randn(B, co, Hc, Hc, device=dev)
+            E.act_amax(a0); E.act_amax(a1)
+            if ops.x3_terms() == 2:
+                ops.amax_of(dy)
+            sets.append((a0, a1, dy))
+        # the layer below, as the data gradient's BatchNorm-backward epilogue sees it (the second half of a concat, else all of the input)
+        cb = c1 if c1 else cin
+        below = E.Tape()
+        below.y = torch.randn(B, cb, Hc, Hc, device=dev)
+        below.ss = torch.rand(cb, 2, device=dev) + 0.5
+        below.mean = torch.randn(cb, device=dev) * 0.1
+        below.invstd = torch.rand(cb, device=dev) + 0.5
+        below.relu, below.bn = True, net.bn_below
         fl = 2.0 * cin * co * k * k * Hc * Hc * B
         # a conv layer's own roofline is min(MFMA peak, HBM bandwidth x its ideal intensity), i.e. its floor
         # is the LARGER of flop / MFMA peak and (input + output bytes, fp32, once) / HBM peak
@@ -208,16 +233,29 @@ def unet_layer_rooflines(B, H, dev):
              "floor_bound": "mfma" if fl / (MFMA_X3_PEAK_TF * 1e9) >= nbytes / (HBM_PEAK_GBS * 1e6) else "hbm",
              "fwd_path": "x3" if layer.xf_off >= 0 else ("x3/16" if layer.x16f_off >= 0 else "fp32"),
              "dgrad_path": "x3" if layer.xd_off >= 0 else ("x3/16" if layer.x16d_off >= 0 else "fp32")}
-        r["fwd_ms"] = time_kernel(lambda: E._conv(layer, a0, a1, False, True))
-        if cin > 4:
-            r["dgrad_ms"] = time_kernel(lambda: E._dgrad(layer, dy, c0 if c1 else None))
+        before_up = "before the upsampling" in name
+        dgrad_plain = name.startswith("down") and name.endswith("conv1")     # feeds the max-pool backward
+        with ops.fwd_scope(dev):
+            r["fwd_plain_ms"] = time_kernel([(lambda s=s_: E._conv(layer, s[0], s[1], False, True)) for s_ in sets])
+            if before_up:
+                r["fwd_ms"] = time_kernel([(lambda s=s_: E._conv(layer, s[0], None, False, False)) for s_ in sets])
+            else:
+                r["fwd_ms"] = time_kernel([(lambda s=s_: E.convbn_fwd(layer, net.bn, s[0], s[1], True, True, want_tape=False)) for s_ in sets])
         net.begin_backward()
-        r["wgrad_ms"] = time_kernel(lambda: E._wgrad(layer, dy, a0, a1, with_bias=False))
-        for d in ("fwd", "dgrad", "wgrad"):
+        if cin > 4:
+            split = c0 if c1 else None
+            r["dgrad_plain_ms"] = time_kernel([(lambda s=s_: E._dgrad(layer, s[2], split)) for s_ in sets])
+            if dgrad_plain:
+                r["dgrad_ms"] = r["dgrad_plain_ms"]
+            else:
+                r["dgrad_ms"] = time_kernel([(lambda s=s_: E._dgrad(layer, s[2], split, below0=None if c1 else below, below1=below if c1 else None))
+                                             for s_ in sets])
+        r["wgrad_ms"] = time_kernel([(lambda s=s_: E._wgrad(layer, s[2], s[0], s[1], with_bias=False)) for s_ in sets])
+        for d in ("fwd", "dgrad", "wgrad", "fwd_plain", "dgrad_plain"):
             if d + "_ms" in r:
                 r[d + "_tflops"] = fl / r[d + "_ms"] / 1e9
         rows.append(r)
-        del x0, x1, dy, net
+        del sets, below, net
     out = {"layers": rows}
     for d, pathkey in (("fwd", "fwd_path"), ("dgrad", "dgrad_path"), ("wgrad", "fwd_path")):
         sel = [r for r in rows if r[pathkey] == "x3" and d + "_ms" in r and (d != "wgrad" or "k3" in r["layer"])]
@@ -243,6 +281,10 @@ def unet_layer_rooflines(B, H, dev):
     f, g = out["fwd"], out["dgrad"]
     fl = sum(r["flop"] for r in rows if r["fwd_path"] == "x3") + sum(r["flop"] for r in rows if r["dgrad_path"] == "x3" and "dgrad_ms" in r)
     out["fwd_dgrad"] = {"tflops": fl / (f["ms_sum"] + g["ms_sum"]) / 1e9, "frac": fl / (f["ms_sum"] + g["ms_sum"]) / 1e9 / MFMA_X3_PEAK_TF}
+    # the same launches WITHOUT the step's fused epilogues (what rounds 1-5 reported as `roofline.achieved`)
+    pms = sum(r["fwd_plain_ms"] for r in rows if r["fwd_path"] == "x3") + sum(r["dgrad_plain_ms"] for r in rows if r["dgrad_path"] == "x3" and "dgrad_plain_ms" in r)
+    out["fwd_dgrad"]["plain_tflops"] = fl / pms / 1e9
+    out["fwd_dgrad"]["plain_frac"] = fl / pms / 1e9 / MFMA_X3_PEAK_TF
     # the per-layer min(MFMA, HBM x intensity) roofline over the same launches: sum of the layers' floors / sum of their measured times
     floor = sum(r["floor_ms"] for r in rows if r["fwd_path"] == "x3") + sum(r["floor_ms"] for r in rows if r["dgrad_path"] == "x3" and "dgrad_ms" in r)
     out["fwd_dgrad"]["per_layer_min_frac"] = floor / (f["ms_sum"] + g["ms_sum"])
@@ -501,6 +543,21 @@ def physical_cores():
     return model, (len(phys) or None)
 
 
+def cpu_quota():
+    """CPU-time quota of this process's cgroup in cores (cgroup v2 cpu.max / v1 cfs_quota_us), or None when there is none."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else max(1, int(round(float(q) / float(p))))
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else max(1, int(round(q / p)))
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(H, full, full_protocol=False, threads=0):
     """The CPU restatement (oracle/, bit-checked against the reference in the build container) timed on this box's host
     cores: full A-D iterations (4 forward + 4 backward + 4 Adam) at B = 6 — what `--batch-size 8` yields
@@ -520,15 +577,18 @@ def cpu_baseline(H, full, full_protocol=False, threads=0):
         cores = os.cpu_count() or 1
     granted = cores
     model, phys = physical_cores()
-    # all physical cores — as many as this process may use (rounds 1-5 capped the baseline at 16 threads
-    # although the driver's box granted 256 CPUs); hyper-threads beyond the physical cores only oversubscribe the FMA units
-    cores = threads if threads > 0 else max(1, min(granted, phys or granted))
+    quota = cpu_quota()
+    # all physical cores — as many as this process may USE.  The affinity mask of a 1-GPU box shows all 256 logical CPUs
+    # of the host, but its cgroup grants a CPU-TIME quota of 16 cores: with 128 threads the same iteration took 17.6 s
+    # instead of 2.2 s (0.34 vs 2.7 images/s, measured in round 6: profiles/r06_cpu_baseline_threads.json) — the threads queue for the
+    # quota.  Threads = min(affinity, physical cores, cgroup quota); all three are reported.
+    cores = threads if threads > 0 else max(1, min(granted, phys or granted, quota or granted))
     torch.set_num_threads(cores)
 
     def host_info():
         """CPU model and PHYSICAL core count of the box (state it next to `cores`)."""
         return {"cpu_model": model, "physical_cores_on_host": phys, "logical_cpus_on_host": os.cpu_count(),
-                "cpus_granted_to_this_process": granted, "threads_used": cores}
+                "cpus_granted_to_this_process": granted, "cgroup_cpu_quota_cores": quota, "threads_used": cores}
 
     def iteration_rate(B, warm, timed):
         pb = B // 3
@@ -621,7 +681,10 @@ def compact_line(line):
             else "wgrad_r_k (x3 weight gradient family)",
             "achieved": r["achieved"], "peak": r["peak"], "unit": r["unit"], "frac": r["frac"],
             "per_layer_min_frac": r.get("per_layer_min_frac"),
-            "achieved_what": "FLOP-weighted over every launch of one U-Net on this family, isolated launches, HIP events (this run)",
+            "achieved_what": "FLOP-weighted over every launch of one U-Net on this family AS THE STEP MAKES THEM (statistics fold / BatchNorm-backward "
+                             "epilogue in the launch, cold operands), HIP events, this run; plain_frac: the same launches without the fused epilogues "
+                             "(what rounds 1-5 reported)",
+            "plain_frac": r.get("plain_frac"),
             "in_step_frac": r.get("in_step_frac"), "in_step_tflops": ins.get("tflops"), "in_step_family_ms_per_step": ins.get("family_ms_per_step"),
             "in_step_source": (dom.get("profile") and ("committed %s (back-to-back kernels), not this run" % dom["profile"] if dom.get("same_library")
                                                        else "withheld: %s was measured on another library than the one loaded" % dom["profile"])),
@@ -660,6 +723,7 @@ def compact_line(line):
                                "cpu_model": (c.get("host") or {}).get("cpu_model"),
                                "physical_cores_on_host": (c.get("host") or {}).get("physical_cores_on_host"),
                                "cpus_granted": (c.get("host") or {}).get("cpus_granted_to_this_process"),
+                               "cgroup_quota_cores": (c.get("host") or {}).get("cgroup_cpu_quota_cores"),
                                "b30_images_per_s": (c.get("b30") or {}).get("value"),
                                "wt_loss_fwd_gbs": (c.get("wt_loss_fwd") or {}).get("value")}
     out["detail"] = line.get("detail_file")
@@ -946,6 +1010,7 @@ def main():
             fam = un["wgrad"] if lead == "x3_wgrad" else un["fwd_dgrad"]
             head = mfma_line(lead, lead)
             head.update({"achieved": fam["tflops"], "frac": fam["frac"], "per_layer_min_frac": fam.get("per_layer_min_frac"),
+                         "plain_frac": fam.get("plain_frac"), "plain_tflops": fam.get("plain_tflops"),
                          "per_layer_min_frac_note": "SURVEY.md 8d: sum over the same launches of max(flop / MFMA peak, (input + output bytes) / "
                                                     "8 TB/s) / sum of their measured times — the layers whose own bound is HBM, not MFMA: %s"
                                                     % ", ".join(fam.get("hbm_bound_layers", [])) if lead == "x3_conv" else None,

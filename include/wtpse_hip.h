@@ -168,7 +168,7 @@ int wtpse_conv_fwd_bnf(const float* in0, int C0, const float* in1, int C1, const
  * arrives, the last group of an output-channel block folds the group sums (fixed order: bitwise reproducible, nobody waits) and
  * writes coef [Cbn][3] = (k1, k2, k3) and dgamma / dbeta (+)= (accumulate) of the BatchNorm'd channels — what
  * wtpse_bn_bwd_from_stats does in its first launch.  wtpse_bn_bwd_apply_coef is then the whole rest of the BatchNorm backward.
- * (Launches of more than 2048 workgroups — WTPSE_TAIL_MAX_WGS — run that fold as a second launch inside the call instead: the
+ * (Launches of more than 8192 workgroups — WTPSE_TAIL_MAX_WGS; 2048 until round 6 — run that fold as a second launch inside the call instead: the
  * hand-off costs every workgroup ~2.5 us of lifetime, which beats a 6 us launch only where a CU sees few workgroups.)
  * layout: 0 = wtpse_dgrad_bnb (fp32 `wd`), 1 = wtpse_dgrad_x3_bnb, 2 = wtpse_conv16_x3's fragments (Csplit == Cout, all channels).
  * gamma / invstd: of the BatchNorm'd channels.  partial2: wtpse_bnb_tail_partial2(nblk, Cout) doubles of scratch; tickets:

@@ -705,7 +705,7 @@ def test_x2h_activation_scales_follow_the_data(ascale):
 def test_x2h_train_mode_batchnorm_bound(gscale):
     """The bound a train-mode BatchNorm's output travels with needs no look at the data: |gamma| sqrt(N - 1) + |beta| per channel
     (Samuelson's inequality), left in the activation's amax table by the statistics' fold — in the launch (wtpse_conv_fwd_bnf, up to
-    2048 workgroups) or by wtpse_bn_finalize.  conv -> BatchNorm(gamma = gscale x O(1)) -> ReLU -> conv through the engine's own block
+    8192 workgroups) or by wtpse_bn_finalize.  conv -> BatchNorm(gamma = gscale x O(1)) -> ReLU -> conv through the engine's own block
     schedule (nn.convbn_fwd) against fp64 at gamma scales from 1e-3 to 1e4: the second convolution's output stays within the fp32
     noise of the first (<= 1e-6 relative L2, the same at every scale), finite everywhere; the table holds the bound."""
     o = _x2h_only()

@@ -185,8 +185,9 @@ def _pack_x16(o, w):
     (1, 64, 32, 64, 3, 20), (1, 32, 16, 32, 3, 8), (1, 128, 8, 8, 1, 8), (0, 16, 32, 64, 3, 20), (0, 32, 16, 32, 3, 8),
     (2, 16, 32, 64, 3, 20),       # the 16-channel x3 kernel (csrc/conv.hip MODE 3): the sibling epilogue of the round-3 finding
     (2, 16, 256, 256, 3, 8),      # ... on the maps it runs on in a step (2048 workgroups)
-    (1, 64, 128, 128, 3, 32),     # the benchmark's batch: 2048 workgroups — the largest launch that folds its own statistics
-    (1, 32, 256, 256, 3, 32),     # 8192 workgroups: beyond the threshold, the stand-alone finalize kernel behind the launch
+    (1, 64, 128, 128, 3, 32),     # the benchmark's batch: 2048 workgroups (rounds 3-5: the largest launch that folds its own statistics)
+    (1, 32, 256, 256, 3, 32),     # 8192 workgroups: since round 6 the largest launch that folds its own statistics (two levels: 128 groups)
+    (1, 32, 256, 512, 3, 32),     # 16384 workgroups: beyond the threshold, the stand-alone finalize kernel behind the launch
 ])
 def test_dgrad_bnb_repeatable(layout, C, H, W, k, B):
     """The data gradient with the BatchNorm-backward epilogue, repeated on the same operands with the allocator's blocks

@@ -535,7 +535,7 @@ FULL_ORACLE = os.environ.get("WTPSE_FULL_ORACLE", "0") != "0"
 @pytest.mark.parametrize("tag", ["b32", "s512"])
 def test_gradients_vs_offline_oracle(golden_dir, tag):
     """The backward at the benchmark's own geometries — b32: B = 32, 10 rows per domain, 256x256 (BASELINE.json configs[2]: 8192-workgroup
-    launches, the weight gradient's unit / segment split, the stand-alone statistics finalize beyond 2048 workgroups and the in-launch
+    launches, the weight gradient's unit / segment split, the stand-alone statistics finalize beyond 8192 workgroups (2048 until round 6) and the in-launch
     fold below); s512: B = 3 at 512x512 (configs[4]'s per-image geometry) — against the CPU oracle evaluated OFFLINE
     (oracle/make_golden_grads.py -> tests/golden/grads_<tag>.npz: ten minutes and 30 GB of host per case, too slow for every run of the
     suite; `WTPSE_FULL_ORACLE=1` runs the same comparison against a live oracle: test_gradients_calibrated[32-10-256] / [3-1-512]).
@@ -638,7 +638,7 @@ def test_gradients_calibrated(B, pb, H):
     the instantiations the benchmark uses (weight gradients at ksplit 512 + slab fold, the big-map BatchNorm backward,
     the bilinear adjoint and the fused heads at full resolution); [32-10-256] IS the benchmark's geometry (BASELINE.json
     configs[2]: 8192-workgroup launches, the weight gradient's unit / segment split, statistics folded by the stand-alone finalize
-    beyond 2048 workgroups and by the launches' last workgroups below), [3-1-512] the per-image geometry of configs[4].  At
+    beyond 8192 workgroups and by the launches' last workgroups below), [3-1-512] the per-image geometry of configs[4].  At
     256x256 and 512x512 the per-tensor band is fixed (strict: every tensor, no probes)."""
     if (B >= 32 or H >= 512) and not FULL_ORACLE:
         pytest.skip("5 / 2 minutes of live CPU oracle: run by WTPSE_FULL_ORACLE=1; the default suite holds the same HIP gradients against "

@@ -8,23 +8,25 @@
 //             k1 = gamma*invstd,  k2 = -gamma*invstd^2*dgamma/N,  k3 = -k1*dbeta/N - k2*mean
 #include "common.h"
 
-// one workgroup per channel; partial sums are folded in fp64 in a fixed order
-__global__ __launch_bounds__(256) void bn_finalize_k(const float* __restrict__ part, int nblk, int C, double count,
+// one workgroup per channel; partial sums are folded in fp64 in a fixed order.  NT threads: 1024 for the launches with thousands of
+// partial rows (the 8192-tile convolutions, the upsampling kernels) — every row is then read in ONE round of eight loads per thread:
+// the launch sits between two convolutions of a dependency chain (54 + 40 times per step with its backward twin) and its 9 us were
+// four rounds of strided loads that miss this XCD's L2 (the partials were written by workgroups all over the chip)
+template <int NT>
+__global__ __launch_bounds__(NT) void bn_finalize_k(const float* __restrict__ part, int nblk, int C, double count,
                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
                                                     float* __restrict__ rmean, float* __restrict__ rvar,
                                                     long long* __restrict__ nbt, float momentum, float eps,
                                                     float* __restrict__ scale_shift, float* __restrict__ save_mean,
                                                     float* __restrict__ save_invstd, unsigned* __restrict__ act_amax) {
-  __shared__ double shs[2][4];
+  __shared__ double shs[2][NT / 64];
   const int c = blockIdx.x, t = threadIdx.x;
   double s1 = 0.0, s2 = 0.0;
-  // (eight loads in flight per thread — the same additions in the same order as one at a time: this launch sits between two
-  // convolutions of a dependency chain, 54 times per step, and spent its 9 us waiting for one strided load after another)
-  for (int k0 = t; k0 < nblk; k0 += 256 * 8) {
+  for (int k0 = t; k0 < nblk; k0 += NT * 8) {
     float2 p2[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const int k = k0 + 256 * u;
+      const int k = k0 + NT * u;
       p2[u] = k < nblk ? *reinterpret_cast<const float2*>(part + ((size_t)k * C + c) * 2) : make_float2(0.f, 0.f);
     }
 #pragma unroll
@@ -43,8 +45,12 @@ __global__ __launch_bounds__(256) void bn_finalize_k(const float* __restrict__ p
   }
   __syncthreads();
   if (t == 0) {
-    s1 = shs[0][0] + shs[0][1] + shs[0][2] + shs[0][3];
-    s2 = shs[1][0] + shs[1][1] + shs[1][2] + shs[1][3];
+    s1 = s2 = 0.0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) {
+      s1 += shs[0][w];
+      s2 += shs[1][w];
+    }
     double mean = s1 / count;
     double var = s2 / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -178,21 +184,22 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_k(const float* __restrict__
 // `global_sums` (optional, [C][2]): the same two sums over ALL ranks' elements (synchronised BatchNorm); the dy
 // coefficients then use them together with the global `count`, while dgamma/dbeta keep this rank's share (the
 // parameter-gradient all-reduce adds the shares up).  `sums_out` (optional) receives this rank's folded sums.
-__global__ __launch_bounds__(256) void bn_bwd_finalize_k(const float* __restrict__ partial, int nsplit, int C, double count,
+template <int NT>
+__global__ __launch_bounds__(NT) void bn_bwd_finalize_k(const float* __restrict__ partial, int nsplit, int C, double count,
                                                          const float* __restrict__ gamma, const float* __restrict__ mean,
                                                          const float* __restrict__ invstd, float* __restrict__ dgamma,
                                                          float* __restrict__ dbeta, int accumulate,
                                                          float* __restrict__ coef, const float* __restrict__ global_sums,
                                                          float* __restrict__ sums_out, int centred_s2) {
-  // one workgroup per channel; fp64 fold in a fixed order (lane-strided, butterfly, the four waves in order)
-  __shared__ double shs[2][4];
+  // one workgroup per channel; fp64 fold in a fixed order (lane-strided, butterfly, the waves in order); NT: see bn_finalize_k
+  __shared__ double shs[2][NT / 64];
   const int c = blockIdx.x, t = threadIdx.x;
   double s1 = 0.0, s2 = 0.0;
-  for (int k0 = t; k0 < nsplit; k0 += 256 * 8) {      // (eight loads in flight per thread, same order of additions: see bn_finalize_k)
+  for (int k0 = t; k0 < nsplit; k0 += NT * 8) {
     float2 p2[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const int k = k0 + 256 * u;
+      const int k = k0 + NT * u;
       p2[u] = k < nsplit ? *reinterpret_cast<const float2*>(partial + ((size_t)k * C + c) * 2) : make_float2(0.f, 0.f);
     }
 #pragma unroll
@@ -210,8 +217,12 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_k(const float* __restrict
     shs[1][t >> 6] = s2;
   }
   __syncthreads();
-  s1 = (shs[0][0] + shs[0][1]) + (shs[0][2] + shs[0][3]);
-  s2 = (shs[1][0] + shs[1][1]) + (shs[1][2] + shs[1][3]);
+  s1 = s2 = 0.0;
+#pragma unroll
+  for (int w = 0; w < NT / 64; ++w) {
+    s1 += shs[0][w];
+    s2 += shs[1][w];
+  }
   if (centred_s2) s2 *= (double)invstd[c];     // partials of a data-gradient epilogue: sum g * (y - mean), not yet / std
   if (t == 0) {
     if (sums_out) {
@@ -349,6 +360,17 @@ __global__ __launch_bounds__(1024) void bn_bwd_small_k(const float* __restrict__
   if (amax) amax_publish_block(amax, am, blockIdx.x);
 }
 
+static void bwd_finalize(hipStream_t st, const float* partial, int nsplit, int C, double count, const float* gamma, const float* mean,
+                         const float* invstd, float* dgamma, float* dbeta, int accumulate, float* coef, const float* global_sums,
+                         float* sums_out, int centred_s2) {
+  if (nsplit >= 2048)
+    hipLaunchKernelGGL(bn_bwd_finalize_k<1024>, dim3(C), dim3(1024), 0, st, partial, nsplit, C, count, gamma, mean, invstd, dgamma, dbeta,
+                       accumulate, coef, global_sums, sums_out, centred_s2);
+  else
+    hipLaunchKernelGGL(bn_bwd_finalize_k<256>, dim3(C), dim3(256), 0, st, partial, nsplit, C, count, gamma, mean, invstd, dgamma, dbeta,
+                       accumulate, coef, global_sums, sums_out, centred_s2);
+}
+
 static inline bool vec_ok(int HW, const void* a, const void* b, const void* c) {
   return HW % 4 == 0 && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & 15) == 0;
 }
@@ -370,9 +392,14 @@ extern "C" int wtpse_bn_finalize(const float* stats_partial, int nblk, int C, lo
                                  unsigned* act_amax, void* stream) {
   WTPSE_REQUIRE(stats_partial && gamma && beta && scale_shift && save_mean && save_invstd && nblk > 0 && C > 0 && count > 0);
   WTPSE_REQUIRE((running_mean == nullptr) == (running_var == nullptr));
-  hipLaunchKernelGGL(bn_finalize_k, dim3(C), dim3(256), 0, (hipStream_t)stream, stats_partial, nblk, C, (double)count,
-                     gamma, beta, running_mean, running_var, num_batches, momentum, eps, scale_shift, save_mean,
-                     save_invstd, act_amax);
+  if (nblk >= 2048)
+    hipLaunchKernelGGL(bn_finalize_k<1024>, dim3(C), dim3(1024), 0, (hipStream_t)stream, stats_partial, nblk, C, (double)count,
+                       gamma, beta, running_mean, running_var, num_batches, momentum, eps, scale_shift, save_mean,
+                       save_invstd, act_amax);
+  else
+    hipLaunchKernelGGL(bn_finalize_k<256>, dim3(C), dim3(256), 0, (hipStream_t)stream, stats_partial, nblk, C, (double)count,
+                       gamma, beta, running_mean, running_var, num_batches, momentum, eps, scale_shift, save_mean,
+                       save_invstd, act_amax);
   return wtpse_status();
 }
 
@@ -436,7 +463,7 @@ extern "C" int wtpse_bn_bwd(const float* dz, const float* y, const float* scale_
   else
     hipLaunchKernelGGL(bn_bwd_reduce_k<false>, dim3(C, ns), dim3(256), 0, st, dz, y, scale_shift, relu, save_mean,
                        save_invstd, B, C, HW, bn_bwd_segs(B, C, HW), partial);
-  hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(C), dim3(256), 0, st, partial, ns, C, (double)B * HW, gamma, save_mean,
+  bwd_finalize(st, partial, ns, C, (double)B * HW, gamma, save_mean,
                      save_invstd, dgamma, dbeta, accumulate, coef, (const float*)nullptr, (float*)nullptr, 0);
   launch_apply(dz, y, scale_shift, relu, coef, dy, B, C, HW, amax, st);
   return wtpse_status();
@@ -457,7 +484,7 @@ extern "C" int wtpse_bn_bwd_reduce(const float* dz, const float* y, const float*
   else
     hipLaunchKernelGGL(bn_bwd_reduce_k<false>, dim3(C, ns), dim3(256), 0, st, dz, y, scale_shift, relu, save_mean,
                        save_invstd, B, C, HW, bn_bwd_segs(B, C, HW), partial);
-  hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(C), dim3(256), 0, st, partial, ns, C, 1.0, (const float*)nullptr, save_mean,
+  bwd_finalize(st, partial, ns, C, 1.0, (const float*)nullptr, save_mean,
                      save_invstd, (float*)nullptr, (float*)nullptr, 0, (float*)nullptr, (const float*)nullptr, sums_local, 0);
   return wtpse_status();
 }
@@ -470,7 +497,7 @@ extern "C" int wtpse_bn_bwd_apply(const float* dz, const float* y, const float* 
                 dbeta && dy && B > 0 && C > 0 && HW > 0 && count_global > 0);
   hipStream_t st = (hipStream_t)stream;
   // sums_local viewed as a 1-slab partial: [1][C][2]
-  hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(C), dim3(256), 0, st, sums_local, 1, C, (double)count_global, gamma, save_mean,
+  bwd_finalize(st, sums_local, 1, C, (double)count_global, gamma, save_mean,
                      save_invstd, dgamma, dbeta, accumulate, coef, sums_global, (float*)nullptr, 0);
   launch_apply(dz, y, scale_shift, relu, coef, dy, B, C, HW, amax, st);
   return wtpse_status();
@@ -485,7 +512,7 @@ extern "C" int wtpse_bn_bwd_from_stats(const float* g, const float* y, const flo
   WTPSE_REQUIRE(g && y && stats_partial && gamma && save_mean && save_invstd && coef && dgamma && dbeta && dy);
   WTPSE_REQUIRE(nblk > 0 && B > 0 && C > 0 && HW > 0);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(C), dim3(256), 0, st, stats_partial, nblk, C, (double)B * HW, gamma, save_mean,
+  bwd_finalize(st, stats_partial, nblk, C, (double)B * HW, gamma, save_mean,
                      save_invstd, dgamma, dbeta, accumulate, coef, (const float*)nullptr, (float*)nullptr, 1);
   // (the scale/shift operand is only read for the ReLU mask: relu = 0 here, the coefficients stand in for it)
   launch_apply(g, y, coef, 0, coef, dy, B, C, HW, amax, st);
@@ -498,7 +525,7 @@ extern "C" int wtpse_bn_bwd_finalize_coef(const float* stats_partial, int nblk, 
                                           const float* save_mean, const float* save_invstd, float* coef, float* dgamma,
                                           float* dbeta, int accumulate, void* stream) {
   WTPSE_REQUIRE(stats_partial && gamma && save_mean && save_invstd && coef && dgamma && dbeta && nblk > 0 && C > 0 && count > 0);
-  hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(C), dim3(256), 0, (hipStream_t)stream, stats_partial, nblk, C, (double)count, gamma,
+  bwd_finalize((hipStream_t)stream, stats_partial, nblk, C, (double)count, gamma,
                      save_mean, save_invstd, dgamma, dbeta, accumulate, coef, (const float*)nullptr, (float*)nullptr, 1);
   return wtpse_status();
 }

@@ -466,8 +466,10 @@ static inline void bnf_tail_geometry(BnfTail& t, int ntiles, int Cout, double co
 // slot sees nWG / (256 x 2..3) workgroups in a row, so the hand-off wins where that is about one or less; beyond the threshold the
 // entry points launch the stand-alone finalize kernel themselves.
 #include <cstdlib>
+// (Round 6: with the fold's loads all in flight at once — tail_fold — the hand-off is cheaper than the stand-alone kernel up to the
+// 8192-workgroup launches of the step as well: 41.54 vs 41.66 ms per step, three alternations on one box; the threshold moves there.)
 static inline bool tail_in_launch(long long workgroups) {
-  static const long long max_wgs = [] { const char* e = getenv("WTPSE_TAIL_MAX_WGS"); return e ? atoll(e) : 2048ll; }();
+  static const long long max_wgs = [] { const char* e = getenv("WTPSE_TAIL_MAX_WGS"); return e ? atoll(e) : 8192ll; }();
   return workgroups <= max_wgs;
 }
 extern "C" int wtpse_bn_finalize(const float* stats_partial, int nblk, int C, long long count, const float* gamma, const float* beta,
