@@ -443,7 +443,6 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
   const __amdgpu_buffer_rsrc_t rs_m = MASK ? make_rsrc(a.mask + (size_t)b * a.Cout * HW, (unsigned)a.Cout * HW * 4u)
                                       : BNB ? make_rsrc(a.mask + (size_t)b * Cbn * HW, (unsigned)Cbn * HW * 4u) : rs_o0;
   const int clane = P16 ? (lane >> 4) * 4 : (lane >> 5) * 4;   // channel offset of this lane within a register's group
-  const float relu_lo = a.relu_out ? 0.f : -INFINITY;
   unsigned pvo[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) pvo[nt] = poff[nt] >= 0 ? (unsigned)(clane * HW + poff[nt]) * 4u : BUF_OOB;
@@ -463,6 +462,18 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt][r] = (cvalid && poff[nt] >= 0) ? acc[mt][nt][r] : 0.f;
       }
+  }
+  // The output ReLU, in place and only where a launch has one (a uniform branch): DeepWT's first / third convolution and the fusion
+  // conv — never together with statistics or Gram partials (host checks), so everything below takes the accumulators as they are.
+  // (Rounds 1-5 clamped every value of every launch with max(v, relu_lo), relu_lo = -inf without a ReLU: an instruction per value — two in
+  // the NaN-preserving form — in epilogues that are bound by their instruction count: profiles/NOTES_r06.md.)
+  if (a.relu_out) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < NACC; ++r) acc[mt][nt][r] = out_clamp<EPI>(acc[mt][nt][r], 0.f);
   }
   if constexpr (P16 && KS == 3) {
     // Gram of the output tile in the epilogue (the WT loss's G = z z^T, reference algorithms.py:1283): the DeepWT convs that
@@ -501,7 +512,7 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-          for (int r = 0; r < NACC; ++r) am = max(am, amax_bits(out_clamp<EPI>(acc[mt][nt][r], relu_lo)));
+          for (int r = 0; r < NACC; ++r) am = max(am, amax_bits(acc[mt][nt][r]));
       amax_publish_wave(a.out_amax, am, (unsigned)tile * 4u + (unsigned)wave);
     }
   }
@@ -552,7 +563,7 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
       }
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        float v = out_clamp<EPI>(acc[mt][nt][r], relu_lo);
+        float v = acc[mt][nt][r];
         if (MASK && !(mk[r][nt] > 0.f)) v = 0.f;
         if (BNB) {     // the ReLU decision of the forward pass: fmaf(y, scale, shift) > 0
           float zz = __builtin_fmaf(mk[r][nt], bsc, bsh);
@@ -576,7 +587,7 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
             s1 += v;
             s2 += v * (mk[r][nt] - bmu[r]);
           } else {
-            const float v = out_clamp<EPI>(acc[mt][nt][r], relu_lo);   // forward statistics are never combined with a ReLU mask (host check)
+            const float v = acc[mt][nt][r];   // forward statistics are never combined with a ReLU mask (host check)
             s1 += v;
             s2 += v * v;
           }
@@ -645,7 +656,7 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
         const __amdgpu_buffer_rsrc_t rs_o = second ? rs_o1 : rs_o0;
         const unsigned soff = (unsigned)(second ? min(cbase, a.Cout) - a.Csplit : min(cbase, a.Csplit)) * hw4;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) buf_store(rs_o, pvo[nt], soff, out_clamp<EPI>(acc[mt][nt][r], relu_lo));
+        for (int nt = 0; nt < NT; ++nt) buf_store(rs_o, pvo[nt], soff, acc[mt][nt][r]);
       }
     if constexpr (BNB)
       bnb_tail<CB>(tk, a.tail, a.stats, a.bn_mean, a.bn_c0, a.bn_c1, cout0, tile, cblk, tid,

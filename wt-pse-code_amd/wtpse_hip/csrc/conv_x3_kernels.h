@@ -214,7 +214,6 @@ __device__ __forceinline__ void x3_epilogue(const ConvX3Args& a, f32x16 (&acc)[M
   const __amdgpu_buffer_rsrc_t rs_m = MASK ? make_rsrc(a.mask + (size_t)b * a.Cout * HW, (unsigned)a.Cout * HW * 4u)
                                       : BNB ? make_rsrc(a.mask + (size_t)b * Cbn * HW, (unsigned)Cbn * HW * 4u) : rs_o0;
   const int clane = h * 4;
-  const float relu_lo = a.relu_out ? 0.f : -INFINITY;
   unsigned pvo[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) pvo[nt] = (live && poff[nt] >= 0) ? (unsigned)(clane * HW + poff[nt]) * 4u : BUF_OOB;
@@ -230,6 +229,18 @@ __device__ __forceinline__ void x3_epilogue(const ConvX3Args& a, f32x16 (&acc)[M
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt][r] = (cvalid && poff[nt] >= 0) ? acc[mt][nt][r] : 0.f;
       }
   }
+  // The output ReLU, in place and only where a launch has one (a uniform branch): DeepWT's first / third convolution and the fusion
+  // conv — never together with statistics or Gram partials (host checks), so everything below takes the accumulators as they are.
+  // (Rounds 1-5 clamped every value of every launch with max(v, relu_lo), relu_lo = -inf without a ReLU: an instruction per value — two in
+  // the NaN-preserving form — in epilogues that are bound by their instruction count: profiles/NOTES_r06.md.)
+  if (a.relu_out) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < NACC; ++r) acc[mt][nt][r] = out_clamp<EPI>(acc[mt][nt][r], 0.f);
+  }
   if constexpr (EPI == 0) {
     if (a.out_amax) {       // largest magnitude of what this wave stores (ragged parts are zero by now): one no-return atomic per wave
       unsigned am = 0u;
@@ -238,7 +249,7 @@ __device__ __forceinline__ void x3_epilogue(const ConvX3Args& a, f32x16 (&acc)[M
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-          for (int r = 0; r < NACC; ++r) am = max(am, amax_bits(out_clamp<EPI>(acc[mt][nt][r], relu_lo)));
+          for (int r = 0; r < NACC; ++r) am = max(am, amax_bits(acc[mt][nt][r]));
       amax_publish_wave(a.out_amax, live ? am : 0u, (unsigned)stats_row * 4u + (unsigned)(tid >> 6));
     }
   }
@@ -288,7 +299,7 @@ __device__ __forceinline__ void x3_epilogue(const ConvX3Args& a, f32x16 (&acc)[M
       }
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        float v = out_clamp<EPI>(acc[mt][nt][r], relu_lo);
+        float v = acc[mt][nt][r];
         if (MASK && !(mk[r][nt] > 0.f)) v = 0.f;
         if (BNB) {     // the ReLU decision of the forward pass: fmaf(y, scale, shift) > 0 (channels outside [bn_c0, bn_c1): 0, 1)
           // (opaque to the vectoriser on purpose: with the two pixels' decisions fused into one v_pk_fma_f32 the masks of a few
@@ -315,7 +326,7 @@ __device__ __forceinline__ void x3_epilogue(const ConvX3Args& a, f32x16 (&acc)[M
             s1 += v;
             s2 += v * (mk[r][nt] - bmu[r]);
           } else {
-            const float v = out_clamp<EPI>(acc[mt][nt][r], relu_lo);
+            const float v = acc[mt][nt][r];
             s1 += v;
             s2 += v * v;
           }
@@ -381,7 +392,7 @@ __device__ __forceinline__ void x3_epilogue(const ConvX3Args& a, f32x16 (&acc)[M
         const __amdgpu_buffer_rsrc_t rs_o = second ? rs_o1 : rs_o0;
         const unsigned soff = (unsigned)(second ? min(cbase, a.Cout) - a.Csplit : min(cbase, a.Csplit)) * hw4;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) buf_store(rs_o, pvo[nt], soff, out_clamp<EPI>(acc[mt][nt][r], relu_lo));
+        for (int nt = 0; nt < NT; ++nt) buf_store(rs_o, pvo[nt], soff, acc[mt][nt][r]);
       }
     if constexpr (BNB)
       bnb_tail<CB>(tk, a.tail, a.stats, a.bn_mean, a.bn_c0, a.bn_c1, cout0, stats_row, cblk, tid,
