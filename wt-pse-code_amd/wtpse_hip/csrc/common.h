@@ -195,10 +195,16 @@ __device__ __forceinline__ unsigned pack_h_rne(float a, float b) {
 // inf, its remainder -inf, and every product it feeds NaN — an out-of-range operand fails LOUDLY (the caller's NaN check fires, as it does
 // for any other divergence) instead of turning into a wrong finite number; a NaN operand stays NaN, as in fp32.  (A saturating form —
 // v_med3_f32 per element — swallowed NaNs: v_med3 returns the minimum when an input is NaN.)
+// Three instructions per pair: v_cvt_pk_f16_f32, then the remainders with the mixed-precision FMA — fma(h0 [fp16 half of p0], -1, a [fp32])
+// rounded to fp16 into the low / high half of p1.  a - h0 is exact in fp32, so this is bit for bit what the compiler's eight-instruction
+// rendering of `pack(a - float(h0(a)), b - float(h0(b)))` gave (two cvt_f16, two cvt_f32, cvt_pk, two sub, cvt_pk; it does not select
+// v_fma_mix for that by itself): tools/probe/mixsplit_test.hip compares the two over 4 M operands incl. inf / NaN / overflow / denormals.
 __device__ __forceinline__ void split2h_pair(float a, float b, unsigned& p0, unsigned& p1) {
-  const h16x2 v = {(_Float16)a, (_Float16)b};
-  p0 = __builtin_bit_cast(unsigned, v);
-  p1 = pack_h_rne(a - (float)v[0], b - (float)v[1]);
+  p0 = pack_h_rne(a, b);
+  unsigned r;
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(p0), "v"(a));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r) : "v"(p0), "v"(b));
+  p1 = r;
 }
 
 __device__ __forceinline__ f32x4 wt_mfma16x32h(u32x4 a, u32x4 b, f32x4 c) {

@@ -225,16 +225,17 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_k(ConvArgs a) {
         }
     }
     if (any_pro) {   // zero padding applies AFTER the fused affine/ReLU, as in the reference graph
-      const bool relu = a.pro_relu & 1;
+      const float lo = (a.pro_relu & 1) ? 0.f : -INFINITY;     // ReLU = one v_max against a uniform floor (conv_x3_kernels.h: convert_pair)
 #pragma unroll
-      for (int i = 0; i < NIT; ++i)
+      for (int i = 0; i < NIT; ++i) {
+        const int nc = iin[i] ? a.C0 - ihalf[i] * 8 : 0;     // channels of this item that exist (one compare per element below)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float sc = ihalf[i] ? psc[1][j] : psc[0][j], sh = ihalf[i] ? psh[1][j] : psh[0][j];
-          float v = fmaf(xv[i][j], sc, sh);
-          if (relu) v = fmaxf(v, 0.f);
-          xv[i][j] = (iin[i] && ihalf[i] * 8 + j < a.C0) ? v : 0.f;
+          const float v = fmaxf(fmaf(xv[i][j], sc, sh), lo);
+          xv[i][j] = j < nc ? v : 0.f;
         }
+      }
     }
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {

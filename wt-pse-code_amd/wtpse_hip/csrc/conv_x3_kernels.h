@@ -525,13 +525,13 @@ __global__ __launch_bounds__(256, 2) void conv_x3_k(ConvX3Args a) {
   auto convert_pair = [&](int c0, int i, int j, bool pro) __attribute__((always_inline)) {
     float v0 = xv[i][2 * j], v1 = xv[i][2 * j + 1];
     if (pro) {        // `true` between the MFMA groups (no branch there), any_pro behind a barrier
-      const bool relu = (c0 < a.C0) ? (a.pro_relu & 1) : (a.pro_relu & 2);
+      // ReLU as ONE v_max against a wave-uniform floor (0 or -inf) instead of v_max + v_cndmask on a flag; without ReLU a NaN leaves
+      // the max as -inf, whose split remainder (-inf + inf) is NaN again: the outputs it feeds are NaN either way
+      const float lo = ((c0 < a.C0) ? (a.pro_relu & 1) : (a.pro_relu & 2)) ? 0.f : -INFINITY;
       const int cg = min(c0 + ihalf[i] * 8 + 2 * j, PRO_MAX - 2);
       const float2 p0 = pro_s[cg], p1 = pro_s[cg + 1];
-      v0 = fmaf(v0, p0.x, p0.y);
-      v1 = fmaf(v1, p1.x, p1.y);
-      v0 = relu ? fmaxf(v0, 0.f) : v0;
-      v1 = relu ? fmaxf(v1, 0.f) : v1;
+      v0 = fmaxf(fmaf(v0, p0.x, p0.y), lo);
+      v1 = fmaxf(fmaf(v1, p1.x, p1.y), lo);
       v0 = iin[i] ? v0 : 0.f;
       v1 = iin[i] ? v1 : 0.f;
     } else if (TERMS == 2) {      // data gradients and block inputs: no prologue, out-of-range loads are zeros already
@@ -861,13 +861,13 @@ __global__ __launch_bounds__(256, 2) void conv_x3r_k(ConvX3Args a) {
         v1 *= sx;
       }
     } else {
-      const bool relu = (c0 < a.C0) ? (a.pro_relu & 1) : (a.pro_relu & 2);
+      // ReLU as ONE v_max against a wave-uniform floor (0 or -inf) instead of v_max + v_cndmask on a flag; without ReLU a NaN leaves
+      // the max as -inf, whose split remainder (-inf + inf) is NaN again: the outputs it feeds are NaN either way
+      const float lo = ((c0 < a.C0) ? (a.pro_relu & 1) : (a.pro_relu & 2)) ? 0.f : -INFINITY;
       const int cg = min(c0 + ihalf[i] * 8 + 2 * j, PRO_MAX - 2);
       const float2 p0 = pro_s[cg], p1 = pro_s[cg + 1];
-      v0 = fmaf(v0, p0.x, p0.y);
-      v1 = fmaf(v1, p1.x, p1.y);
-      v0 = relu ? fmaxf(v0, 0.f) : v0;
-      v1 = relu ? fmaxf(v1, 0.f) : v1;
+      v0 = fmaxf(fmaf(v0, p0.x, p0.y), lo);
+      v1 = fmaxf(fmaf(v1, p1.x, p1.y), lo);
       v0 = iin[i] ? v0 : 0.f;
       v1 = iin[i] ? v1 : 0.f;
     }
