@@ -271,66 +271,105 @@ __global__ __launch_bounds__((64 * WgradRGeom<MF, NF>::NW), 1) void wgrad_r_k(Wg
         }
       }
     };
-    // Conversion of stage s in raw slot S (-> X slot S, dY slot AS), cut into NP pieces of about a dozen vector instructions:
-    //   [0, 4 MF)            one pair of a dY fragment's 8 pixels: [BatchNorm-apply,] split into the three bf16 terms (+ bias sum)
-    //   4 MF                 AD = 1 only: the A loads of stage s + 1 (the slot was just consumed)
-    //   next 4 NF            one pair of an X fragment's 8 pixels: prologue, split
-    //   next NF              the edge pixel of an X fragment
-    //   last                 the loads of stage s + 2 (X; and A when AD = 2)
-    constexpr int PA = 4 * MF, PX = PA + (AD == 1 ? 1 : 0), PE_ = PX + 4 * NF, NP = PE_ + NF + 1;
-    auto piece = [&](auto Pc, auto Sc, auto ASc, int s_next) {   // s_next: the stage being converted + 1; < 0: no loads
-      constexpr int P = decltype(Pc)::value, S = decltype(Sc)::value, AS = decltype(ASc)::value, SA = S % AD;
-      if constexpr (P < PA) {
-        constexpr int m = P / 4, q = P % 4;
-        float v0 = rawy[SA][m][q >> 1][2 * (q & 1)], v1 = rawy[SA][m][q >> 1][2 * (q & 1) + 1];
-        if (AFF) {   // rows outside [y0, y1) load g = y = 0 and would come out as k3: the row validity rides in ak3v
-          v0 = fmaf(ak1[m], v0, fmaf(ak2[m], rawb[SA][m][q >> 1][2 * (q & 1)], ak3v[SA][m]));
-          v1 = fmaf(ak1[m], v1, fmaf(ak2[m], rawb[SA][m][q >> 1][2 * (q & 1) + 1], ak3v[SA][m]));
+    // Conversion of stage s in raw slot S (-> X slot S, dY slot AS), cut into NP pieces of about half a dozen vector instructions:
+    //   dY pair      one pair of a dY fragment's 8 pixels: [BatchNorm-apply,] split into the 16-bit terms (+ bias sum)
+    //   X pair       one pair of an X fragment's 8 pixels: prologue, split;      X edge: the edge pixel of an X fragment
+    //   halo         the neighbour exchange of the converted X row (two ds_bpermute per fragment and term) for the NEXT step — issued
+    //                here, a dozen chains in front of their use (round 6: issued where they were used, every 54 MFMAs the wave sat out
+    //                one to two LDS round trips behind `s_waitcnt lgkmcnt(0)`)
+    //   loads        of stage s + 2 (X; and A when AD = 2);   AD = 1 only: "A loads" of stage s + 1 (the slot was just consumed)
+    // AD = 2 (order of arrival: a stage's X loads are issued in front of its dY loads, and vmcnt counts in order):
+    //   X pairs, X edges, half of the dY pairs, halo, the other dY pairs, loads
+    // AD = 1:  dY pairs, A loads, X pairs, X edges, halo, loads
+    // The halo piece must sit behind the step's LAST build of shifted rows (fragment NF - 1: chain 9 MF (NF - 1)), whose operands it replaces.
+    constexpr int NPA = 4 * MF, NPX = 4 * NF, NP = NPA + NPX + NF + 2 + (AD == 1 ? 1 : 0);
+    constexpr int P_HALO = AD == 2 ? NPX + NF + NPA / 2 : NP - 2;
+    unsigned nbr[NF][TERMS], nbl[NF][TERMS];      // halo of the X row the next step multiplies: pixel 8 / pixel -1 of this lane's group
+    auto cvt_a = [&](auto Qc, auto Sc, auto ASc) {              // dY pair Q = (fragment, pair) of raw slot S -> dY slot AS
+      constexpr int Q = decltype(Qc)::value, SA = decltype(Sc)::value % AD, AS = decltype(ASc)::value;
+      constexpr int m = Q / 4, q = Q % 4;
+      float v0 = rawy[SA][m][q >> 1][2 * (q & 1)], v1 = rawy[SA][m][q >> 1][2 * (q & 1) + 1];
+      if (AFF) {   // rows outside [y0, y1) load g = y = 0 and would come out as k3: the row validity rides in ak3v
+        v0 = fmaf(ak1[m], v0, fmaf(ak2[m], rawb[SA][m][q >> 1][2 * (q & 1)], ak3v[SA][m]));
+        v1 = fmaf(ak1[m], v1, fmaf(ak2[m], rawb[SA][m][q >> 1][2 * (q & 1) + 1], ak3v[SA][m]));
+      }
+      if (BIAS) bsum[m] += (double)v0 + (double)v1;
+      if (TERMS == 2) { v0 *= sdy; v1 *= sdy; }
+      unsigned qq[TERMS];
+      split_pair(v0, v1, qq);
+#pragma unroll
+      for (int t = 0; t < TERMS; ++t) ay[AS][m][t][q] = qq[t];
+    };
+    auto cvt_x = [&](auto Qc, auto Sc) {                        // X pair Q of raw slot S -> X slot S
+      constexpr int Q = decltype(Qc)::value, S = decltype(Sc)::value;
+      constexpr int n = Q / 4, q = Q % 4;
+      float v0 = rawx[S][n][q >> 1][2 * (q & 1)], v1 = rawx[S][n][q >> 1][2 * (q & 1) + 1];
+      if (PRO) {
+        v0 = fmaxf(fmaf(v0, psc[n], psh[n]), plo[n]);
+        v1 = fmaxf(fmaf(v1, psc[n], psh[n]), plo[n]);
+        // an odd batch's missing twin image reads zeros, which the prologue turns into act(shift): harmless while its dY is zero
+        // too, but a non-finite shift would make 0 * inf of it — the dead lanes' X is zero, explicitly
+        if (TWIN && !lane_live) v0 = v1 = 0.f;
+      }
+      unsigned qq[TERMS];
+      split_pair(v0, v1, qq);
+#pragma unroll
+      for (int t = 0; t < TERMS; ++t) xb[S][n][t][q] = qq[t];
+    };
+    auto cvt_e = [&](auto Nc, auto Sc) {                        // edge pixel of X fragment n
+      constexpr int n = decltype(Nc)::value, S = decltype(Sc)::value;
+      float e = rawe[S][n];
+      if (PRO) e = evalid ? fmaxf(fmaf(e, psc[n], psh[n]), plo[n]) : 0.f;     // zero padding applies after the activation
+      unsigned qq[TERMS];
+      split_pair(e, 0.f, qq);
+#pragma unroll
+      for (int t = 0; t < TERMS; ++t) eq[S][n][t] = qq[t];
+    };
+    auto halo = [&](auto Sc) {                                  // neighbour exchange of the converted X row in slot S
+      constexpr int S = decltype(Sc)::value;
+#pragma unroll
+      for (int n = 0; n < NF; ++n)
+#pragma unroll
+        for (int t = 0; t < TERMS; ++t) {
+          const u32x4v d = xb[S][n][t];
+          // pixel 8 of this lane's group = pixel 0 of the next group (lane + 16); for the last group the strip's right edge,
+          // which lane group 0 holds.  Pixel -1 = pixel 7 of the previous group (lane - 16); for group 0 the left edge (group 3).
+          const unsigned sup_r = (g == 0 ? eq[S][n][t] : d[0]) & seam_r;
+          const unsigned sup_l = (g == 3 ? (eq[S][n][t] << 16) : d[3]) & seam_l;
+          nbr[n][t] = (unsigned)__builtin_amdgcn_ds_bpermute(src_up * 4, (int)sup_r);
+          nbl[n][t] = (unsigned)__builtin_amdgcn_ds_bpermute(src_dn * 4, (int)sup_l);
         }
-        if (BIAS) bsum[m] += (double)v0 + (double)v1;
-        if (TERMS == 2) { v0 *= sdy; v1 *= sdy; }
-        unsigned qq[TERMS];
-        split_pair(v0, v1, qq);
-#pragma unroll
-        for (int t = 0; t < TERMS; ++t) ay[AS][m][t][q] = qq[t];
-      } else if constexpr (P < PX) {
-        if (s_next >= 0) issue_a(Sc, s_next);
-      } else if constexpr (P < PE_) {
-        constexpr int n = (P - PX) / 4, q = (P - PX) % 4;
-        float v0 = rawx[S][n][q >> 1][2 * (q & 1)], v1 = rawx[S][n][q >> 1][2 * (q & 1) + 1];
-        if (PRO) {
-          v0 = fmaxf(fmaf(v0, psc[n], psh[n]), plo[n]);
-          v1 = fmaxf(fmaf(v1, psc[n], psh[n]), plo[n]);
-          // an odd batch's missing twin image reads zeros, which the prologue turns into act(shift): harmless while its dY is zero
-          // too, but a non-finite shift would make 0 * inf of it — the dead lanes' X is zero, explicitly
-          if (TWIN && !lane_live) v0 = v1 = 0.f;
-        }
-        unsigned qq[TERMS];
-        split_pair(v0, v1, qq);
-#pragma unroll
-        for (int t = 0; t < TERMS; ++t) xb[S][n][t][q] = qq[t];
-      } else if constexpr (P < NP - 1) {
-        constexpr int n = P - PE_;
-        float e = rawe[S][n];
-        if (PRO) e = evalid ? fmaxf(fmaf(e, psc[n], psh[n]), plo[n]) : 0.f;     // zero padding applies after the activation
-        unsigned qq[TERMS];
-        split_pair(e, 0.f, qq);
-#pragma unroll
-        for (int t = 0; t < TERMS; ++t) eq[S][n][t] = qq[t];
+    };
+    auto piece = [&](auto Pc, auto Sc, auto ASc, int s_next) {   // s_next: the stage being converted + 1
+      constexpr int P = decltype(Pc)::value;
+      if constexpr (P == NP - 1) {
+        issue_x(Sc, s_next + 1);
+        if (AD == 2) issue_a(Sc, s_next + 1);
+      } else if constexpr (P == P_HALO) {
+        halo(Sc);
+      } else if constexpr (AD == 2) {
+        if constexpr (P < NPX) cvt_x(IC<P>{}, Sc);
+        else if constexpr (P < NPX + NF) cvt_e(IC<P - NPX>{}, Sc);
+        else if constexpr (P < P_HALO) cvt_a(IC<P - NPX - NF>{}, Sc, ASc);
+        else cvt_a(IC<P - NPX - NF - 1>{}, Sc, ASc);
       } else {
-        if (s_next >= 0) {
-          issue_x(Sc, s_next + 1);
-          if (AD == 2) issue_a(Sc, s_next + 1);
-        }
+        if constexpr (P < NPA) cvt_a(IC<P>{}, Sc, ASc);
+        else if constexpr (P == NPA) issue_a(Sc, s_next);
+        else if constexpr (P < NPA + 1 + NPX) cvt_x(IC<P - NPA - 1>{}, Sc);
+        else cvt_e(IC<P - NPA - 1 - NPX>{}, Sc);
       }
     };
-    auto convert_a = [&](auto Sc, auto ASc) { static_for<PA>([&](auto p) { piece(p, Sc, ASc, -1); }); };
-    auto convert_x = [&](auto Sc) { static_for<4 * NF + NF>([&](auto p) { piece(IC<PX + decltype(p)::value>{}, Sc, IC<0>{}, -1); }); };
+    auto convert_a = [&](auto Sc, auto ASc) { static_for<NPA>([&](auto q) { cvt_a(q, Sc, ASc); }); };
+    auto convert_x = [&](auto Sc) {
+      static_for<NPX>([&](auto q) { cvt_x(q, Sc); });
+      static_for<NF>([&](auto n) { cvt_e(n, Sc); });
+    };
     // One X row r (k = r - rfirst, J = k & 3): its products with the dY rows r + 1, r, r - 1 — chains of six dependent MFMAs, one
     // per (cin fragment, vertical tap, cout fragment, horizontal tap) — with the conversion pieces of stage r + 1 dealt out
     // behind the chains.  A wave of the 32 x 32 blocks has its SIMD to itself and issues in order, so the ORDER of the stream is
     // the overlap: a 16x16x32 MFMA holds the vector issue for 8 of its 16 cycles, two vector instructions fit behind each.
     constexpr int NC = NF * 9 * MF;
+    static_assert((9 * MF * (NF - 1) * NP + NC - 1) / NC <= P_HALO, "the halo piece overwrites the operands of the step's last build of shifted rows");
     auto step = [&](auto Jc, int r) {
       constexpr int J = decltype(Jc)::value, XS = J & 1, CS = (J + 1) & 1, AS = (J + 2) & 3;
       static_for<NF>([&](auto nc) {
@@ -339,12 +378,7 @@ __global__ __launch_bounds__((64 * WgradRGeom<MF, NF>::NW), 1) void wgrad_r_k(Wg
 #pragma unroll
         for (int t = 0; t < TERMS; ++t) {
           const u32x4v d = xb[XS][n][t];
-          // pixel 8 of this lane's group = pixel 0 of the next group (lane + 16); for the last group the strip's right edge,
-          // which lane group 0 holds.  Pixel -1 = pixel 7 of the previous group (lane - 16); for group 0 the left edge (group 3).
-          const unsigned sup_r = (g == 0 ? eq[XS][n][t] : d[0]) & seam_r;
-          const unsigned sup_l = (g == 3 ? (eq[XS][n][t] << 16) : d[3]) & seam_l;
-          const unsigned nb_r = (unsigned)__builtin_amdgcn_ds_bpermute(src_up * 4, (int)sup_r);
-          const unsigned nb_l = (unsigned)__builtin_amdgcn_ds_bpermute(src_dn * 4, (int)sup_l);
+          const unsigned nb_r = nbr[n][t], nb_l = nbl[n][t];      // exchanged by the previous step's halo piece (or in front of the loop)
           xs[1][t] = d;
           xs[2][t][0] = __builtin_amdgcn_alignbit(d[1], d[0], 16);
           xs[2][t][1] = __builtin_amdgcn_alignbit(d[2], d[1], 16);
@@ -402,6 +436,7 @@ __global__ __launch_bounds__((64 * WgradRGeom<MF, NF>::NW), 1) void wgrad_r_k(Wg
       convert_a(IC<1>{}, IC<0>{});
       convert_a(IC<0>{}, IC<1>{});
       convert_x(IC<0>{});
+      halo(IC<0>{});
       issue_a(IC<1>{}, rfirst + 1);
       issue_x(IC<1>{}, rfirst + 1);
       issue_a(IC<0>{}, rfirst + 2);
@@ -412,6 +447,7 @@ __global__ __launch_bounds__((64 * WgradRGeom<MF, NF>::NW), 1) void wgrad_r_k(Wg
       convert_a(IC<0>{}, IC<0>{});
       issue_a(IC<0>{}, rfirst);
       convert_x(IC<0>{});
+      halo(IC<0>{});
       issue_x(IC<1>{}, rfirst + 1);
       convert_a(IC<0>{}, IC<1>{});
       issue_a(IC<0>{}, rfirst + 1);
