@@ -376,18 +376,29 @@ int wtpse_adam(float* p, const float* g, float* m, float* v, long long n, double
  * (mu_prior / logvar_prior, three layers, nc <= 4) and :1199-1200 (the segmentation net's `mu`, two layers: w3 = b3 = y =
  * NULL and the 8-channel result is h2).  Weights are the plain OIHW parameters ([32][32], [8][32], [nc][8]), HW % 32 == 0.
  * x takes the conv loaders' prologue (pro: [32][2] scale/shift or NULL, pro_relu).  h1 ([B][32][HW], post-ReLU) and h2
- * ([B][8][HW], post-ReLU for three layers) are what the backward needs; pass NULL to skip storing them (forward only;
- * h2 is mandatory for a two-layer head: it is the output). */
+ * ([B][8][HW], post-ReLU for three layers) are the tapes: pass NULL to skip storing them (h2 is mandatory for a two-layer
+ * head: it is the output).
+ * Arithmetic (round 6): under x2h (wtpse_x3_terms() == 2, the default) both layers run on the fp16 matrix cores at fp32 accuracy
+ * exactly as the convolutions do — every operand = two fp16 terms of a power-of-two multiple of the value, three products, fp32
+ * accumulation (12 v_mfma_f32_32x32x16_f16 per 32-pixel block where the fp32-input form needs 32 v_mfma_f32_32x32x2_f32: the
+ * kernels were bound by those, not by their bytes).  x_amax: the amax table BOUNDING THE ACTIVATED INPUT (wtpse_amax /
+ * wtpse_act_bound / a producer's table), or NULL: the fixed forward scale 2^2, i.e. |act(x)| < 2^13 or the outputs are NaN; W1 / W2
+ * are scaled by their own largest magnitude, h1 by max_m sum_k |W1[m][k]| * bound(x) + max |b1|.  In the other modes (x3, bf16)
+ * the fp32-input kernels of rounds 2-5 run and x_amax is ignored. */
 int wtpse_head_fwd(const float* x, const float* pro, int pro_relu, const float* w1, const float* b1, const float* w2,
-                   const float* b2, const float* w3, const float* b3, int nc, float* h1, float* h2, float* y, int B, int HW,
-                   void* stream);
+                   const float* b2, const float* w3, const float* b3, int nc, float* h1, float* h2, float* y,
+                   const unsigned* x_amax, int B, int HW, void* stream);
 /* dy: [B][nc][HW] (three layers) or [B][8][HW] (two layers: gradient of the h2 output).  dx: [B][32][HW] gradient wrt the
  * activated input.  dparams: [32*32 + 32 + 8*32 + 8 (+ 8*nc + nc)] = (dW1, db1, dW2, db2[, dW3, db3]) contiguous, which is
  * the order the head's parameters have in the flat gradient buffer; written, or added to when accumulate != 0.
- * slab: scratch of wtpse_head_slabs(B, HW) * that many floats. */
+ * slab: scratch of wtpse_head_slabs(B, HW) * that many floats.
+ * x2h: h1 is NOT read (may be NULL; the forward need not store it) — layer 1 is formed again from the x the kernel reads anyway, by
+ * the forward kernel's instruction sequence on its operands (the same bits, so the forward's ReLU mask): b1 and dy_amax (the amax
+ * table of dy) are required, x_amax as in wtpse_head_fwd (the SAME table, or the masks may differ in the last bit of h1).  The
+ * gradients' scales follow from bound(dy) through the weights' absolute row sums.  Other modes: h1 required, b1 / tables ignored. */
 int wtpse_head_bwd(const float* dy, const float* x, const float* pro, int pro_relu, const float* h1, const float* h2,
-                   const float* w1, const float* w2, const float* w3, int nc, float* dx, float* slab, float* dparams,
-                   int accumulate, int B, int HW, void* stream);
+                   const float* w1, const float* b1, const float* w2, const float* w3, int nc, float* dx, float* slab,
+                   float* dparams, int accumulate, const unsigned* x_amax, const unsigned* dy_amax, int B, int HW, void* stream);
 int wtpse_head_slabs(int B, int HW);
 
 /* ---- device-side training input pipeline (csrc/pipeline.hip) ---------------------------------- */

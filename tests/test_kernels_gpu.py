@@ -337,7 +337,7 @@ def test_fused_head(case):
     dy = rnd(*out.shape, seed=70)
     out.backward(dy)
     D = lambda t: t.detach().to(DEV).contiguous() if t is not None else None
-    got, h1d, h2d = o.head_fwd(D(x), D(pro), use_pro, D(w1), D(b1), D(w2), D(b2), D(w3), D(b3), True)
+    got, h1d, h2d = o.head_fwd(D(x), D(pro), use_pro, D(w1), D(b1), D(w2), D(b2), D(w3), D(b3), True, want_h1=True)
     close(got, out, what="head out")
     close(h1d, h1, what="h1")
     close(h2d, F.relu(h2) if three else h2, what="h2")
@@ -346,13 +346,60 @@ def test_fused_head(case):
     assert torch.equal(got2, got)
     ns = 1320 + 9 * nc
     dpar = torch.full((ns,), float("nan"), device=DEV)
-    dx = o.head_bwd(D(dy), D(x), D(pro), use_pro, h1d, h2d, D(w1), D(w2), D(w3), dpar)
+    dx = o.head_bwd(D(dy), D(x), D(pro), use_pro, h1d, h2d, D(w1), D(w2), D(w3), dpar, b1=D(b1))
     close(dx, xa.grad, what="dx")
     want = torch.cat([t.grad.reshape(-1) for t in (w1, b1, w2, b2) + ((w3, b3) if three else ())])
     scale = float(want.abs().max())
     close(dpar, want, rtol=2e-4, atol=2e-5 * max(scale, 1.0), what="head dparams")
-    o.head_bwd(D(dy), D(x), D(pro), use_pro, h1d, h2d, D(w1), D(w2), D(w3), dpar, accumulate=True)
+    o.head_bwd(D(dy), D(x), D(pro), use_pro, h1d, h2d, D(w1), D(w2), D(w3), dpar, accumulate=True, b1=D(b1))
     close(dpar, 2 * want, rtol=2e-4, atol=4e-5 * max(scale, 1.0), what="head dparams accumulate")
+    if o.x3_terms() == 2:
+        # what the training step runs: no layer-1 tape (the backward forms h1 again), scales from the operands' amax tables
+        xd = D(x)
+        xam = o.amax_of(xd) if not use_pro else o.act_bound(D(pro), o.amax_of(xd))
+        got3, none3, h2t = o.head_fwd(xd, D(pro), use_pro, D(w1), D(b1), D(w2), D(b2), D(w3), D(b3), True, x_amax=xam)
+        assert none3 is None
+        close(got3, out, what="head out (amax table)")
+        dpar3 = torch.full((ns,), float("nan"), device=DEV)
+        dx3 = o.head_bwd(D(dy), xd, D(pro), use_pro, None, h2t, D(w1), D(w2), D(w3), dpar3, b1=D(b1), x_amax=xam)
+        close(dx3, xa.grad, what="dx (no tape, amax tables)")
+        close(dpar3, want, rtol=2e-4, atol=2e-5 * max(scale, 1.0), what="head dparams (no tape, amax tables)")
+        with pytest.raises(ValueError):
+            o.head_bwd(D(dy), xd, D(pro), use_pro, None, h2t, D(w1), D(w2), D(w3), dpar3)
+
+
+@pytest.mark.parametrize("xs,gs", [(1e-4, 1e3), (300.0, 1e-5), (1.0, 1.0)])
+def test_fused_head_scales_follow_the_data(xs, gs):
+    """x2h heads: operands far from unit scale (inputs, weights, gradients) keep fp32-level accuracy — every operand is scaled by a
+    bound of its own tensor (amax tables, absolute row sums of the weights), not by a fixed constant."""
+    o = ops()
+    if o.x3_terms() != 2:
+        pytest.skip("x2h arithmetic only")
+    B, H, W, nc = 2, 16, 32, 1
+    x = (rnd(B, 32, H, W, seed=81) * xs).double()
+    w1 = (rnd(32, 32, 1, 1, seed=82, scale=0.3) / xs * 3.0).double().requires_grad_(True); b1 = rnd(32, seed=83, scale=0.2).double().requires_grad_(True)
+    w2 = rnd(8, 32, 1, 1, seed=84, scale=0.3).double().requires_grad_(True); b2 = rnd(8, seed=85, scale=0.2).double().requires_grad_(True)
+    w3 = rnd(nc, 8, 1, 1, seed=86, scale=0.5).double().requires_grad_(True); b3 = rnd(nc, seed=87, scale=0.2).double().requires_grad_(True)
+    xa = x.clone().requires_grad_(True)
+    h2 = F.conv2d(F.relu(F.conv2d(xa, w1, b1)), w2, b2)
+    out = F.conv2d(F.relu(h2), w3, b3)
+    dy = (rnd(*out.shape, seed=88) * gs).double()
+    out.backward(dy)
+    D = lambda t: t.detach().float().to(DEV).contiguous()
+    xd = D(x)
+    xam = o.amax_of(xd)
+    got, _, h2t = o.head_fwd(xd, None, False, D(w1), D(b1), D(w2), D(b2), D(w3), D(b3), True, x_amax=xam)
+    rel = lambda g, w: float((g.double().cpu() - w).norm() / w.norm())
+    assert rel(got, out.detach()) < 2e-6
+    ns = 1320 + 9 * nc
+    dpar = torch.full((ns,), float("nan"), device=DEV)
+    dx = o.head_bwd(D(dy), xd, None, False, None, h2t, D(w1), D(w2), D(w3), dpar, b1=D(b1), x_amax=xam)
+    assert rel(dx, xa.grad) < 2e-6
+    off = 0
+    for t in (w1, b1, w2, b2, w3, b3):
+        k = t.numel()
+        assert rel(dpar[off:off + k], t.grad.reshape(-1)) < 5e-6, t.shape
+        off += k
 
 
 @pytest.mark.parametrize("shape", [(3, 8, 9, 11), (5, 2, 256, 256)])   # the second takes the many-row reduction of (dw, db)

@@ -10,7 +10,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "wt-pse-code_amd")]
+sys.path[:0] = [ROOT, os.environ.get("WTPSE_PKG_DIR") or os.path.join(ROOT, "wt-pse-code_amd")]     # (WTPSE_PKG_DIR: another build of the package, same-box A/B)
 import torch  # noqa: E402
 from wtpse_hip import ops  # noqa: E402
 
@@ -117,15 +117,18 @@ def main():
         w2, b2 = torch.randn(8, 32, 1, 1, device=DEV) * 0.2, torch.randn(8, device=DEV)
         w3, b3 = torch.randn(1, 8, 1, 1, device=DEV) * 0.2, torch.randn(1, device=DEV)
         px = x.numel() / 32
-        med, _ = timeit(lambda: ops.head_fwd(x, pro, True, w1, b1, w2, b2, w3, b3, True), a.reps)
+        med, _ = timeit(lambda: ops.head_fwd(x, pro, True, w1, b1, w2, b2, w3, b3, True, want_h1=True), a.reps)
         print("head_fwd 32-32-8-1 +tape [%d,32,256,256]  %7.1f us  %6.0f GB/s (73 floats/px)" % (B, med, 73 * 4 * px / med / 1e3))
         med, _ = timeit(lambda: ops.head_fwd(x, pro, True, w1, b1, w2, b2, w3, b3, False), a.reps)
         print("head_fwd 32-32-8-1 no tape                 %7.1f us  %6.0f GB/s (33 floats/px)" % (med, 33 * 4 * px / med / 1e3))
-        y, h1, h2 = ops.head_fwd(x, pro, True, w1, b1, w2, b2, w3, b3, True)
+        y, h1, h2 = ops.head_fwd(x, pro, True, w1, b1, w2, b2, w3, b3, True, want_h1=True)
         dy = torch.randn_like(y)
         dpar = torch.zeros(1320 + 9, device=DEV)
-        med, _ = timeit(lambda: ops.head_bwd(dy, x, pro, True, h1, h2, w1, w2, w3, dpar), a.reps)
-        print("head_bwd 32-32-8-1                         %7.1f us  %6.0f GB/s (105 floats/px)" % (med, 105 * 4 * px / med / 1e3))
+        xam, dyam = ops.act_bound(pro, ops.amax_of(x)), ops.amax_of(dy)
+        med, _ = timeit(lambda: ops.head_fwd(x, pro, True, w1, b1, w2, b2, w3, b3, True, x_amax=xam), a.reps)
+        print("head_fwd 32-32-8-1 as the step calls it     %7.1f us  %6.0f GB/s (h2 tape only under x2h: 41 floats/px)" % (med, 41 * 4 * px / med / 1e3))
+        med, _ = timeit(lambda: ops.head_bwd(dy, x, pro, True, h1, h2, w1, w2, w3, dpar, b1=b1, x_amax=xam, dy_amax=dyam), a.reps)
+        print("head_bwd 32-32-8-1                         %7.1f us  %6.0f GB/s (x2h: no h1 read, 73 floats/px; fp32: 105)" % (med, 73 * 4 * px / med / 1e3))
     if a.only in ("", "bn"):
         for (C, H) in ((16, 256), (32, 256), (32, 128), (64, 64), (256, 16)):
             y = torch.randn(B, C, H, H, device=DEV)

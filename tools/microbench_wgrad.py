@@ -8,7 +8,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "wt-pse-code_amd"), os.path.join(ROOT, "tools")]
+sys.path[:0] = [ROOT, os.environ.get("WTPSE_PKG_DIR") or os.path.join(ROOT, "wt-pse-code_amd"), os.path.join(ROOT, "tools")]     # (WTPSE_PKG_DIR: another build of the package, same-box A/B)
 import torch  # noqa: E402
 from wtpse_hip import ops  # noqa: E402
 from microbench import SHAPES, timeit, DEV  # noqa: E402

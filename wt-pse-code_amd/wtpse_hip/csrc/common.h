@@ -199,6 +199,14 @@ __device__ __forceinline__ unsigned pack_h_rne(float a, float b) {
 // rounded to fp16 into the low / high half of p1.  a - h0 is exact in fp32, so this is bit for bit what the compiler's eight-instruction
 // rendering of `pack(a - float(h0(a)), b - float(h0(b)))` gave (two cvt_f16, two cvt_f32, cvt_pk, two sub, cvt_pk; it does not select
 // v_fma_mix for that by itself): tools/probe/mixsplit_test.hip compares the two over 4 M operands incl. inf / NaN / overflow / denormals.
+// NOTE: the hazard recogniser does not look inside inline assembly.  Use this form where the result goes to LDS or is consumed a
+// long way off (the convolutions' loaders, the weight gradient's conversion pieces); where a matrix instruction reads the result within
+// a few instructions (csrc/head.hip) use split2h_pair_c — there the asm form produced run-to-run differences of a remainder term's size.
+__device__ __forceinline__ void split2h_pair_c(float a, float b, unsigned& p0, unsigned& p1) {      // the same values, compiler-scheduled
+  const h16x2 v = {(_Float16)a, (_Float16)b};
+  p0 = __builtin_bit_cast(unsigned, v);
+  p1 = pack_h_rne(a - (float)v[0], b - (float)v[1]);
+}
 __device__ __forceinline__ void split2h_pair(float a, float b, unsigned& p0, unsigned& p1) {
   p0 = pack_h_rne(a, b);
   unsigned r;

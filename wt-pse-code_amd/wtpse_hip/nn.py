@@ -947,7 +947,7 @@ def head_fwd(seq, x, idxs, want_tape=True):
     if t.fused:
         w3, b3 = (ls[2].weight, ls[2].bias) if len(ls) == 3 else (None, None)
         out, t.h1, t.h2 = ops.head_fwd(t.x.t, t.x.pro, t.x.relu, ls[0].weight, ls[0].bias, ls[1].weight, ls[1].bias, w3, b3,
-                                       want_tape)
+                                       want_tape, x_amax=act_amax(t.x))
         return out, t
     h = t.x
     for n, i in enumerate(idxs):
@@ -967,7 +967,7 @@ def head_bwd(seq, t, d, idxs):
         off = root._offsets[root._pindex[id(ls[0].weight)]]
         dparams = root._gtarget[off:off + total]
         return ops.head_bwd(d, t.x.t, t.x.pro, t.x.relu, t.h1, t.h2, ls[0].weight, ls[1].weight,
-                            ls[2].weight if len(ls) == 3 else None, dparams)
+                            ls[2].weight if len(ls) == 3 else None, dparams, b1=ls[0].bias, x_amax=act_amax(t.x), dy_amax=_gamax(d))
     for n in reversed(range(len(idxs))):
         layer = seq[idxs[n]]
         inp = t.x if n == 0 else t.acts[n - 1]

@@ -693,25 +693,35 @@ def zero_(t):
 
 
 # ----------------------------------------------------------------------------------------------- fused 1x1 heads
-def head_fwd(x, pro, relu, w1, b1, w2, b2, w3, b3, want_tape=True):
+def head_fwd(x, pro, relu, w1, b1, w2, b2, w3, b3, want_tape=True, x_amax=None, want_h1=False):
     """32 -> 32 (ReLU) -> 8 [-> (ReLU) -> nc] in one kernel.  -> (out, h1 or None, h2): out is y [B,nc,H,W] for a
     three-layer head (w3 given), the 8-channel h2 for a two-layer head."""
     _chk(x, "x"); _chk(pro, "pro")
     B, C, H, W = x.shape
     three = w3 is not None
     nc = w3.shape[0] if three else 0
-    h1 = torch.empty((B, 32, H, W), dtype=torch.float32, device=x.device) if want_tape else None
+    # (x2h arithmetic: the backward forms layer 1 again from x — no h1 tape, 128 bytes per pixel less written here and read there)
+    h1 = torch.empty((B, 32, H, W), dtype=torch.float32, device=x.device) if (want_tape and (want_h1 or x3_terms() != 2)) else None
     h2 = torch.empty((B, 8, H, W), dtype=torch.float32, device=x.device) if (want_tape or not three) else None
     y = torch.empty((B, nc, H, W), dtype=torch.float32, device=x.device) if three else None
     lib().call("wtpse_head_fwd", ptr(x), ptr(pro), int(bool(relu)), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3), nc,
-               ptr(h1), ptr(h2), ptr(y), B, H * W, stream_ptr())
+               ptr(h1), ptr(h2), ptr(y), ptr(x_amax), B, H * W, stream_ptr())
     return (y if three else h2), h1, h2
 
 
-def head_bwd(dy, x, pro, relu, h1, h2, w1, w2, w3, dparams, accumulate=False):
+def head_bwd(dy, x, pro, relu, h1, h2, w1, w2, w3, dparams, accumulate=False, b1=None, x_amax=None, dy_amax=None):
     """-> dx (gradient wrt the activated input); the parameter gradients land in `dparams`, the contiguous flat-buffer
-    range (dW1, db1, dW2, db2[, dW3, db3])."""
+    range (dW1, db1, dW2, db2[, dW3, db3]).  x2h arithmetic (the default): h1 is not read — the kernel forms layer 1 again from
+    x (b1 required) — and the operand scales come from the amax tables of the activated x (None: the fixed forward scale) and
+    of dy (None: one extra pass over dy here); otherwise the fp32-input kernel, which reads the h1 tape."""
     _chk(dy, "dy"); _chk(x, "x"); _chk(h1, "h1"); _chk(h2, "h2")
+    if x3_terms() == 2:
+        if b1 is None:
+            raise ValueError("head_bwd (x2h): b1 is required — layer 1 is formed again from x")
+        if dy_amax is None:
+            dy_amax = amax_of(dy)
+    elif h1 is None:
+        raise ValueError("head_bwd: the fp32-input kernel reads the layer-1 tape h1 (head_fwd(..., want_h1=True))")
     B, C, H, W = x.shape
     nc = w3.shape[0] if w3 is not None else 0
     L = lib()
@@ -719,8 +729,8 @@ def head_bwd(dy, x, pro, relu, h1, h2, w1, w2, w3, dparams, accumulate=False):
     assert dparams.numel() == ns and dparams.is_contiguous()
     slab = workspace("head_slab", L.query("wtpse_head_slabs", B, H * W) * ns, x.device)
     dx = torch.empty_like(x)
-    L.call("wtpse_head_bwd", ptr(dy), ptr(x), ptr(pro), int(bool(relu)), ptr(h1), ptr(h2), ptr(w1), ptr(w2), ptr(w3), nc,
-           ptr(dx), ptr(slab), ptr(dparams), int(accumulate), B, H * W, stream_ptr())
+    L.call("wtpse_head_bwd", ptr(dy), ptr(x), ptr(pro), int(bool(relu)), ptr(h1), ptr(h2), ptr(w1), ptr(b1), ptr(w2), ptr(w3), nc,
+           ptr(dx), ptr(slab), ptr(dparams), int(accumulate), ptr(x_amax), ptr(dy_amax), B, H * W, stream_ptr())
     return dx
 
 
