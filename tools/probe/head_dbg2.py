@@ -23,9 +23,9 @@ for variant in ("plain", "w2 exact", "dy exact", "both exact", "both exact, mask
     h2.backward(dy)
     D = lambda t: t.detach().float().to(DEV).contiguous()
     xd = D(x); xam = o.amax_of(xd)
-    got, _, h2d = o.head_fwd(xd, None, False, D(w1), D(b1), D(w2), D(b2), None, None, True, x_amax=xam)
+    got, h1d, h2d = o.head_fwd(xd, None, False, D(w1), D(b1), D(w2), D(b2), None, None, True, x_amax=xam, want_h1=True)
     dpar = torch.full((1320,), float("nan"), device=DEV)
-    dx = o.head_bwd(D(dy), xd, None, False, None, h2d, D(w1), D(w2), None, dpar, b1=D(b1), x_amax=xam)
+    dx = o.head_bwd(D(dy), xd, None, False, h1d, h2d, D(w1), D(w2), None, dpar, b1=D(b1), x_amax=xam)
     rel = lambda g, w: float((g.double().cpu() - w).norm() / w.norm())
     print("%-22s out %.2e dx %.2e dW1 %.2e db1 %.2e dW2 %.2e db2 %.2e" % (variant, rel(got, h2.detach()), rel(dx, xa.grad), rel(dpar[:1024], w1.grad.reshape(-1)),
           rel(dpar[1024:1056], b1.grad), rel(dpar[1056:1312], w2.grad.reshape(-1)), rel(dpar[1312:1320], b2.grad)))
