@@ -368,6 +368,28 @@ def test_fused_head(case):
             o.head_bwd(D(dy), xd, D(pro), use_pro, None, h2t, D(w1), D(w2), D(w3), dpar3)
 
 
+def test_fused_head_keeps_a_nan_input_visible():
+    """x2h heads: a NaN in the head's input reaches the output at its pixel as NaN (the inner ReLUs keep it, as torch.relu does), so the
+    reference's isnan scrub of mu (shape_networks.py:490) still sees a diverged feature map; every other pixel stays finite."""
+    o = ops()
+    if o.x3_terms() != 2:
+        pytest.skip("x2h arithmetic only")
+    B, H, W = 2, 8, 8
+    x = rnd(B, 32, H, W, seed=91)
+    x[1, 5, 3, 4] = float("nan")
+    D = lambda t: t.detach().to(DEV).contiguous()
+    w1, b1 = rnd(32, 32, 1, 1, seed=92, scale=0.3), rnd(32, seed=93, scale=0.2)
+    w2, b2 = rnd(8, 32, 1, 1, seed=94, scale=0.3), rnd(8, seed=95, scale=0.2)
+    w3, b3 = rnd(1, 8, 1, 1, seed=96, scale=0.5), rnd(1, seed=97, scale=0.2)
+    y, _, h2 = o.head_fwd(D(x), None, False, D(w1), D(b1), D(w2), D(b2), D(w3), D(b3), True)
+    bad = torch.isnan(y.cpu())
+    assert bool(bad[1, 0, 3, 4]) and int(bad.sum()) == 1
+    assert bool(torch.isnan(h2.cpu())[1, :, 3, 4].all())
+    y2, _, _ = o.head_fwd(D(x), None, False, D(w1), D(b1), D(w2), D(b2), None, None, True)
+    bad2 = torch.isnan(y2.cpu())
+    assert bool(bad2[1, :, 3, 4].all()) and int(bad2.sum()) == 8
+
+
 @pytest.mark.parametrize("xs,gs", [(1e-4, 1e3), (300.0, 1e-5), (1.0, 1.0)])
 def test_fused_head_scales_follow_the_data(xs, gs):
     """x2h heads: operands far from unit scale (inputs, weights, gradients) keep fp32-level accuracy — every operand is scaled by a

@@ -16,6 +16,9 @@
 
 __device__ __forceinline__ int rho(int r, int u) { return (r & 3) + 8 * (r >> 2) + 4 * u; }
 typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+// the inner ReLUs of the x2h heads: a NaN stays a NaN (torch.relu keeps it; v_max_f32 would return 0 and hide a diverged input from the
+// reference's isnan scrub of mu, shape_networks.py:490)
+__device__ __forceinline__ float relu_keep_nan(float v) { return v < 0.f ? 0.f : v; }
 __device__ __forceinline__ f32x16 mfma32h(u32x4v a, u32x4v b, f32x16 c) {      // 32x32x16, fp16 operands, fp32 accumulation
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
 }
@@ -251,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void head_fwd_h_k(HeadArgs a) {
     }
     float h1v[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) h1v[r] = fmaxf(fmaf(acc1[r], inv1, bb1[r]), 0.f);
+    for (int r = 0; r < 16; ++r) h1v[r] = relu_keep_nan(fmaf(acc1[r], inv1, bb1[r]));
     if (a.h1) {
       const __amdgpu_buffer_rsrc_t ro = make_rsrc(a.h1 + (size_t)b * 32 * HW, 32u * HW4);
 #pragma unroll
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void head_fwd_h_k(HeadArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       h2v[r] = fmaf(acc2[r], inv2, bb2[r]);
-      if (L3) h2v[r] = fmaxf(h2v[r], 0.f);
+      if (L3) h2v[r] = relu_keep_nan(h2v[r]);
     }
     if (a.h2) {
       const __amdgpu_buffer_rsrc_t ro = make_rsrc(a.h2 + (size_t)b * 8 * HW, 8u * HW4);
@@ -706,7 +709,7 @@ __global__ __launch_bounds__(256, 2) void head_bwd_h_k(HeadArgs a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int r = 4 * q + i;
-        const float h = fmaxf(fmaf(acc1[r], inv1, bqv[i]), 0.f);
+        const float h = relu_keep_nan(fmaf(acc1[r], inv1, bqv[i]));
         Th1[rho(r, u) * TS + n] = h * sh;
         acc3[r] = h > 0.f ? acc3[r] * k3 : 0.f;
         Tdh1[rho(r, u) * TS + n] = acc3[r];
