@@ -963,7 +963,7 @@ def main():
             "dtype": ("bf16 (layers with > 16 output channels: operands rounded to one bf16 term, one MFMA product, fp32 accumulation; the "
                       "16-channel layers, the 1x1 heads, BatchNorm and Adam in fp32) — NOT within the 1e-4 parity bar"
                       if args.dtype == "bf16" else
-                      "f32 (layers with > 16 output channels: %s; the rest fp32-input MFMA / x3 on 16x16x32)" % X3_NAME[X3_TERMS]
+                      "f32 (layers with > 16 output channels and the fused 1x1 heads: %s; the 16-channel layers the same on 16x16x32, the 1-/3-channel input layers and small 1x1 convs fp32-input MFMA)" % X3_NAME[X3_TERMS]
                       if _x3_on() else "f32"), "data": "synthetic",
             "config": {"workload": (("BASELINE.json configs[2]: full WT-PSE (seg+shape nets + WT loss)" if H == 256 else
                                      "BASELINE.json configs[4] per-GPU share: full WT-PSE at high resolution") if full else
