@@ -368,6 +368,31 @@ def test_fused_head(case):
             o.head_bwd(D(dy), xd, D(pro), use_pro, None, h2t, D(w1), D(w2), D(w3), dpar3)
 
 
+def test_fused_head_backward_is_repeatable():
+    """Two runs of the head backward on the same operands give the same bits.  (Round 6's first x2h backward split its operands with
+    inline assembly right next to matrix instructions — the compiler's hazard recogniser does not look inside — and its gradients moved
+    by a remainder term's size from run to run; every accuracy test of the time passed at 1e-4.)"""
+    o = ops()
+    B, H, W, nc = 4, 64, 64, 1
+    x = rnd(B, 32, H, W, seed=101).to(DEV)
+    pro = torch.stack([rnd(32, seed=102) * 0.5 + 1.0, rnd(32, seed=103) * 0.3], 1).contiguous().to(DEV)
+    w1, b1 = rnd(32, 32, 1, 1, seed=104, scale=0.3).to(DEV), rnd(32, seed=105, scale=0.2).to(DEV)
+    w2, b2 = rnd(8, 32, 1, 1, seed=106, scale=0.3).to(DEV), rnd(8, seed=107, scale=0.2).to(DEV)
+    w3, b3 = rnd(nc, 8, 1, 1, seed=108, scale=0.5).to(DEV), rnd(nc, seed=109, scale=0.2).to(DEV)
+    dy = rnd(B, nc, H, W, seed=110).to(DEV)
+    y, h1, h2 = o.head_fwd(x, pro, True, w1, b1, w2, b2, w3, b3, True, want_h1=True)
+    ns = 1320 + 9 * nc
+    outs = []
+    for _ in range(3):
+        dpar = torch.full((ns,), float("nan"), device=DEV)
+        dx = o.head_bwd(dy, x, pro, True, h1, h2, w1, w2, w3, dpar, b1=b1)
+        outs.append((dx.clone(), dpar.clone()))
+    for dx, dpar in outs[1:]:
+        assert torch.equal(dx, outs[0][0]) and torch.equal(dpar, outs[0][1])
+    y2, _, h2b = o.head_fwd(x, pro, True, w1, b1, w2, b2, w3, b3, True, want_h1=True)
+    assert torch.equal(y2, y) and torch.equal(h2b, h2)
+
+
 def test_fused_head_keeps_a_nan_input_visible():
     """x2h heads: a NaN in the head's input reaches the output at its pixel as NaN (the inner ReLUs keep it, as torch.relu does), so the
     reference's isnan scrub of mu (shape_networks.py:490) still sees a diverged feature map; every other pixel stays finite."""
